@@ -1,0 +1,177 @@
+/*
+ * gemlite_hip.h — C ABI of libgemlite_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary for the fused unpack + dequant + matmul hot path of
+ * mobiusml/gemlite.  Each entry point replaces one seam of the reference (paths relative
+ * to the reference tree):
+ *
+ *   gemlite_hip_forward            <- GEMLITE_TRITON_MAPPING[matmul_type].forward(...)
+ *                                     gemlite/core.py:184-190; the identical 17-argument
+ *                                     launchers gemv_kernels.py:553-638,
+ *                                     gemv_revsplitK_kernels.py:391-462,
+ *                                     gemv_splitK_kernels.py:423-476,
+ *                                     gemm_splitK_kernels.py:595-652, gemm_kernels.py:549-601
+ *   gemlite_hip_workspace_bytes    <- the reference has no workspace: it zero-fills the
+ *                                     output and uses atomics (gemv_revsplitK_kernels.py:422,
+ *                                     gemm_splitK_kernels.py:141); we use caller-owned scratch
+ *   gemlite_hip_scale_activations_per_token
+ *                                  <- scale_activations_per_token_triton,
+ *                                     gemlite/quant_utils.py:268-347 (spec: :231-253)
+ *   gemlite_hip_pack_over_cols     <- pack_weights_over_cols_triton, gemlite/bitpack.py:77-144
+ *                                     (bit layout spec: pack_weights_over_cols_torch :36-60)
+ *   gemlite_hip_unpack_over_cols   <- unpack_over_cols_triton, gemlite/bitpack.py:175-241
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); the library
+ *     never allocates, frees or synchronises, so every call is hipGraph-capturable;
+ *   - return value: 0 on success, a negative gemlite_status_t otherwise;
+ *     gemlite_hip_status_string() maps it to text.  Nothing is launched on error;
+ *   - dtype arguments are the integer codes of gemlite/dtypes.py:8-29 (gemlite_dtype_t);
+ *   - strides are in ELEMENTS of the tensor's own dtype (what torch's .stride() returns).
+ */
+#ifndef GEMLITE_HIP_H
+#define GEMLITE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEMLITE_HIP_ABI_VERSION 1
+
+/* integer dtype codes — wire format shared with gemlite/dtypes.py:8-29 */
+typedef enum gemlite_dtype_t {
+    GEMLITE_DT_FP32 = 0,
+    GEMLITE_DT_FP16 = 1,
+    GEMLITE_DT_BF16 = 2,
+    GEMLITE_DT_FP8E4 = 3, /* OCP e4m3fn: the gfx950 MFMA flavour */
+    GEMLITE_DT_INT8 = 4,
+    GEMLITE_DT_UINT8 = 5,
+    GEMLITE_DT_INT32 = 6,
+    GEMLITE_DT_UINT32 = 7,
+    GEMLITE_DT_FP8E5 = 8, /* OCP e5m2 */
+    GEMLITE_DT_INT16 = 9,
+    GEMLITE_DT_UINT16 = 10,
+    GEMLITE_DT_INT64 = 11,
+    GEMLITE_DT_FP8E4NUZ = 12, /* MI300X flavour: rejected on gfx950 */
+    GEMLITE_DT_FP8E5NUZ = 13
+} gemlite_dtype_t;
+
+/* index into GEMLITE_MATMUL_TYPES (gemlite/core.py:56-66) */
+typedef enum gemlite_matmul_type_t {
+    GEMLITE_MATMUL_AUTO = -1, /* pick by M like get_matmul_type(), core.py:100-114 */
+    GEMLITE_MATMUL_GEMV = 0,
+    GEMLITE_MATMUL_GEMV_REVSPLITK = 1,
+    GEMLITE_MATMUL_GEMV_SPLITK = 2,
+    GEMLITE_MATMUL_GEMM_SPLITK = 3,
+    GEMLITE_MATMUL_GEMM = 4
+} gemlite_matmul_type_t;
+
+typedef enum gemlite_status_t {
+    GEMLITE_OK = 0,
+    GEMLITE_ERR_BAD_ARGUMENT = -1, /* null pointer, non-positive size, bad struct_size  */
+    GEMLITE_ERR_UNSUPPORTED = -2,  /* dtype / bit-width / mode combination not built     */
+    GEMLITE_ERR_BAD_SHAPE = -3,    /* K not a multiple of elements_per_sample / group    */
+    GEMLITE_ERR_WORKSPACE = -4,    /* workspace missing or smaller than required         */
+    GEMLITE_ERR_LAUNCH = -5,       /* hipLaunchKernel failed; see gemlite_hip_last_hip_error */
+    GEMLITE_ERR_NO_DEVICE = -6     /* current device is not gfx950                       */
+} gemlite_status_t;
+
+/* W_group_mode / channel_scale_mode follow gemlite/triton_kernels/utils.py:73-87 and
+ * gemm_kernels.py:392-404:
+ *   W_group_mode        0 none | 1 (q - z) | 2 q*s | 3 (q - z)*s | 4 fma(q, s, z')
+ *   channel_scale_mode  0 none | 1 acc*s_w[n] | 2 acc*s_x[m] | 3 acc*s_x[m]*s_w[n]          */
+typedef struct gemlite_hip_forward_args {
+    uint32_t struct_size; /* = sizeof(gemlite_hip_forward_args), ABI guard */
+    int32_t matmul_type;  /* gemlite_matmul_type_t */
+
+    const void* x;        /* [M, K] activations, dtype input_dtype, row stride stride_xm   */
+    const void* w_q;      /* packed: [K/e, N] words of w_pack_bits; unpacked: [K, N] view  */
+    const void* scales;   /* [K/group, N] meta_dtype, or [N] channel scales, or NULL       */
+    const void* zeros;    /* [K/group, N] meta_dtype, 1-elem int32 (scalar), or NULL       */
+    const void* scales_x; /* [M] fp32 per-token activation scales, or NULL                 */
+    void* out;            /* [M, N] output_dtype                                           */
+    void* workspace;      /* >= gemlite_hip_workspace_bytes(); zero-filled ONCE by the owner */
+    uint64_t workspace_bytes;
+
+    int64_t M, N, K;
+
+    int32_t W_nbits;             /* 1,2,4,8 packed; 8/16/32 unpacked                        */
+    int32_t group_size;          /* K elements per scale/zero row (1 when there is none)    */
+    int32_t unpack_mask;         /* 2^W_nbits - 1 (carried for signature parity; rederived) */
+    int32_t elements_per_sample; /* e = w_pack_bits / W_nbits; 1 for unpacked weights       */
+    int32_t w_pack_bits;         /* 8/16/32 for packed words; 0 when elements_per_sample==1 */
+    int32_t w_dtype;             /* gemlite_dtype_t of w_q when unpacked (int8/fp8/fp16...) */
+
+    int32_t input_dtype;  /* dtype of x as the kernel sees it (after activation quant)     */
+    int32_t output_dtype;
+    int32_t acc_dtype;    /* carried for parity; the HIP kernels accumulate fp32 / int32   */
+    int32_t meta_dtype;   /* dtype of scales / tensor zeros                                */
+    int32_t zeros_dtype;  /* meta_dtype for tensor zeros, GEMLITE_DT_INT32 for a scalar    */
+
+    int32_t channel_scale_mode;
+    int32_t W_group_mode;
+    int32_t zero_is_scalar; /* zeros holds exactly one element (gemm_kernels.py:597)       */
+    int32_t data_contiguous;
+    int32_t type_id;        /* input_dtype*100 + W_nbits (core.py:141-145); tuning key only */
+
+    int64_t stride_xm, stride_xk;
+    int64_t stride_wk, stride_wn;       /* of w_q as given (packed rows or K)               */
+    int64_t stride_om, stride_on;
+    int64_t stride_meta_g, stride_meta_n;
+    int64_t stride_sx_m;
+
+    int32_t tuning[4]; /* 0 = library default. [0] kernel variant, [1] split-K, [2..3] reserved */
+} gemlite_hip_forward_args;
+
+/* Library / ABI identification (host only, no device access). */
+int gemlite_hip_abi_version(void);
+const char* gemlite_hip_build_info(void);
+const char* gemlite_hip_status_string(int status);
+/* hipError_t of the last failed HIP runtime call made by this library on this thread. */
+int gemlite_hip_last_hip_error(void);
+
+/* 0 if the configuration has a native kernel, GEMLITE_ERR_* otherwise. Never launches. */
+int gemlite_hip_query(const gemlite_hip_forward_args* args);
+
+/* Scratch bytes gemlite_hip_forward needs for this configuration (split-K slabs + arrival
+ * counters).  The caller allocates it once, zero-fills it once, and then only passes it in:
+ * every launch leaves the counters at zero again.  One workspace per concurrently used stream. */
+uint64_t gemlite_hip_workspace_bytes(const gemlite_hip_forward_args* args);
+
+/* out[M,N] = epilogue( x[M,K] @ dequant(w_q, scales, zeros) ) — one fused launch. */
+int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream);
+
+/* Name of the kernel gemlite_hip_forward would launch for `args` (for profiles/tests). */
+const char* gemlite_hip_kernel_name(const gemlite_hip_forward_args* args);
+
+/* Optional: the NEXT gemlite_hip_forward on this thread is launched with
+ * hipExtLaunchKernel(start, stop) so that hipEventElapsedTime(start, stop) is that kernel's
+ * own device duration.  Pass NULL, NULL to clear.  Events are hipEvent_t passed as void*. */
+void gemlite_hip_set_profile_events(void* start_event, void* stop_event);
+
+/* Per-token dynamic activation quantisation: for each row m of x[M,K] (fp16/bf16/fp32)
+ *   s[m] = max(amax(|x[m,:]|) / qmax, 1e-6) (fp32);  y = clamp(x / s, qmin, qmax);
+ *   int8: round half away from zero;  fp8: round-to-nearest-even cast.
+ * out_dtype: GEMLITE_DT_INT8, GEMLITE_DT_FP8E4 or GEMLITE_DT_FP8E5. */
+int gemlite_hip_scale_activations_per_token(const void* x, void* y, float* scales, int64_t M,
+                                            int64_t K, int64_t stride_xm, int32_t in_dtype,
+                                            int32_t out_dtype, void* stream);
+
+/* Bit-pack W_q[N, K] (uint8 values < 2^W_nbits, row stride ld_in) along K into words of
+ * pack_bits: word(n, j) = OR_i W_q[n, j*e+i] << (W_nbits*i), e = pack_bits/W_nbits, stored
+ * TRANSPOSED and contiguous: out[j*N + n]  (shape [K/e, N]) — the layout GemLiteLinear.pack()
+ * produces with transpose=True + .contiguous() (core.py:384-398,478-480). */
+int gemlite_hip_pack_over_cols(const uint8_t* w_q, void* out, int64_t N, int64_t K, int64_t ld_in,
+                               int32_t W_nbits, int32_t pack_bits, void* stream);
+/* Inverse: out[N, K] uint8 from packed [K/e, N]. */
+int gemlite_hip_unpack_over_cols(const void* packed, uint8_t* out, int64_t N, int64_t K,
+                                 int32_t W_nbits, int32_t pack_bits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEMLITE_HIP_H */
