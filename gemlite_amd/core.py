@@ -1,0 +1,447 @@
+"""GemLiteLinear for MI355X: the reference's module / functional API over the HIP C ABI.
+
+Drop-in surface (reference: gemlite/core.py): ``GemLiteLinear(W_nbits, group_size, in_features,
+out_features, input_dtype, output_dtype, acc_dtype, scaled_activations)`` (:231-299), ``.pack(W_q, scales,
+zeros, bias, fma_mode, contiguous, packing_bitwidth)`` (:336-519), ``.forward`` / ``.forward_manual`` (:541-557),
+``.get_tensor_args`` / ``.get_meta_args`` (:522-538), the ``state_dict`` keys (:503-517, :301-333) and the
+functional ``forward_functional(x, bias, tensor_args, meta_args, matmul_type)`` (:128-195).
+
+What is different by design: there is no Triton and no autotuner.  ``forward`` builds one C struct
+(`gemlite_hip_forward_args`) and calls ``gemlite_hip_forward`` on the current torch stream; the five
+reference kernel families map onto hand-written CDNA4 kernels inside libgemlite_hip.so.  Tensors must live on
+the GPU — there is no CPU / eager fallback and a missing library raises.
+"""
+import json
+import logging
+import threading
+from typing import List, Optional, Union
+
+import torch
+from torch import Tensor
+
+from . import _hip
+from .bitpack import pack_weights_over_cols
+from .config import AUTOTUNE, KERNEL, MATMUL_DTYPES, set_autotune, set_kernel_caching  # noqa: F401 (re-exported)
+from .dtypes import (DTYPE_TO_TORCH, FP8_INT8_DTYPES, TORCH_TO_DTYPE, DType, is_mx_dtype)
+from .quant_utils import scale_activations_per_token
+
+logger = logging.getLogger(__name__)
+
+# kernel families, in the reference's order: the index is the wire value of `matmul_type`
+GEMLITE_MATMUL_TYPES = list(MATMUL_DTYPES)
+GEMLITE_MATMUL_TYPES_MAPPING = {name: i for i, name in enumerate(GEMLITE_MATMUL_TYPES)}
+
+# Accumulation dtype recorded in meta_args[7].  The reference picks fp16 accumulation only on a list of
+# GeForce parts (core.py:39-54, utils.py:115-122); on an MI355X that resolves to fp32 / int32, which is
+# also what the HIP kernels do.
+GEMLITE_ACC_DTYPE = {
+    DType.FP16: DType.FP32, DType.BF16: DType.FP32, DType.FP32: DType.FP32,
+    DType.FP8: DType.FP32, DType.FP8e5: DType.FP32, DType.FP8e4nuz: DType.FP32, DType.FP8e5nuz: DType.FP32,
+    DType.INT8: DType.INT32,
+    DType.MXFP16: DType.FP32, DType.MXBF16: DType.FP32, DType.MXFP8: DType.FP32, DType.MXFP4: DType.FP32,
+    DType.NVFP4: DType.FP32,
+}
+
+GEMLITE_HIP_CONFIG_CACHE: dict = {}  # tuning hints keyed like the reference's autotune cache
+GEMLITE_TRITON_CONFIG_CACHE = GEMLITE_HIP_CONFIG_CACHE  # reference name
+_FILE_LOCK = threading.Lock()
+
+
+# ------------------------------------------------------------------------------------------------------
+# small setters with the reference's names (core.py:86-97)
+# ------------------------------------------------------------------------------------------------------
+def _closest_m_default(M: int) -> int:
+    """Round M up to the reference's tuning buckets: powers of two plus the 1/2 and 1/4 interpolations for
+    2^i >= 32, capped at 4096 (triton_kernels/utils.py:140-174)."""
+    if M <= 0:
+        return 0
+    if M >= 4096:
+        return 4096
+    vals = set()
+    i = 0
+    while (1 << i) <= 4096:
+        v, nxt = 1 << i, 1 << (i + 1)
+        vals.add(v)
+        if v >= 32 and nxt <= 4096:
+            vals.update(((v + nxt) // 2, (v + nxt) // 4))
+        i += 1
+    return min(v for v in vals if v >= M)
+
+
+_closest_m = _closest_m_default
+
+
+def get_closest_m(M: int) -> int:
+    return _closest_m(M)
+
+
+def set_autotune_setting(fct):
+    global _closest_m
+    _closest_m = fct
+
+
+def set_packing_bitwidth(packing_bitwidth: int):
+    GemLiteLinearHIP.PACKING_BITWIDTH = packing_bitwidth
+
+
+def set_acc_dtype(dtype):
+    assert dtype in [DType.FP16, DType.FP32], "Invalid dtype (should be DType.FP16 or DType.FP32)."
+    GEMLITE_ACC_DTYPE[DType.FP16] = dtype  # recorded in meta_args; HIP kernels always accumulate in fp32
+
+
+def get_default_gemv(W_nbits: int, mx_dtype: bool = False) -> str:
+    if mx_dtype:
+        return "GEMM_SPLITK"
+    return "GEMV_REVSPLITK" if W_nbits < 8 else "GEMV_SPLITK"
+
+
+def get_matmul_type(batch_size: int, W_nbits: int, mx_dtype: bool = False) -> str:
+    """Kernel family by batch size, thresholds as in the reference (core.py:100-114)."""
+    if batch_size > 64:
+        return "GEMM"
+    if batch_size > 1:
+        return "GEMM_SPLITK"
+    return get_default_gemv(W_nbits, mx_dtype)
+
+
+# ------------------------------------------------------------------------------------------------------
+# launch: tensors + 12 meta ints  ->  gemlite_hip_forward_args  ->  one kernel on the current stream
+# ------------------------------------------------------------------------------------------------------
+_META_FIELDS = ("scaled_activations", "W_nbits", "group_size", "unpack_mask", "elements_per_sample", "input_dtype",
+                "output_dtype", "acc_dtype", "meta_dtype", "channel_scale_mode", "W_group_mode", "data_contiguous")
+_ARGS_CACHE: dict = {}
+
+
+def _static_args(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> _hip.ForwardArgs:
+    key = (W_q.data_ptr(), scales.data_ptr(), zeros.data_ptr(), tuple(meta_args), tuple(W_q.shape))
+    a = _ARGS_CACHE.get(key)
+    if a is not None:
+        return a
+    (_sa, W_nbits, group_size, unpack_mask, e, in_dt, out_dt, acc_dt, meta_dt, c_mode, w_mode, contiguous) = meta_args
+    a = _hip.ForwardArgs()
+    a.struct_size = _hip.C.sizeof(_hip.ForwardArgs)
+    a.w_q = W_q.data_ptr()
+    a.scales = scales.data_ptr() if scales.numel() > 0 else None
+    a.zeros = zeros.data_ptr() if zeros.numel() > 0 else None
+    a.N = W_q.shape[1]
+    a.K = W_q.shape[0] * e
+    a.W_nbits, a.group_size, a.unpack_mask, a.elements_per_sample = W_nbits, group_size, unpack_mask, e
+    if e > 1:
+        a.w_pack_bits, a.w_dtype = W_q.element_size() * 8, TORCH_TO_DTYPE[W_q.dtype].value
+    else:
+        a.w_pack_bits, a.w_dtype = 0, TORCH_TO_DTYPE[W_q.dtype].value
+    a.input_dtype, a.output_dtype, a.acc_dtype = in_dt, out_dt, acc_dt
+    a.meta_dtype = TORCH_TO_DTYPE[scales.dtype].value if scales.numel() > 0 else meta_dt
+    a.zeros_dtype = TORCH_TO_DTYPE[zeros.dtype].value if zeros.numel() > 0 else meta_dt
+    a.channel_scale_mode, a.W_group_mode = c_mode, w_mode
+    a.zero_is_scalar = int(zeros.numel() == 1)
+    a.data_contiguous = int(contiguous)
+    base_in = DType.FP16.value if in_dt == DType.BF16.value else in_dt
+    a.type_id = base_in * 100 + W_nbits
+    a.stride_wk, a.stride_wn = W_q.stride(0), W_q.stride(1)
+    if scales.dim() == 2 and scales.numel() > 0:
+        a.stride_meta_g, a.stride_meta_n = scales.stride(0), scales.stride(1)
+    elif zeros.dim() == 2 and zeros.numel() > 1:
+        a.stride_meta_g, a.stride_meta_n = zeros.stride(0), zeros.stride(1)
+    else:
+        a.stride_meta_g, a.stride_meta_n = 0, 1
+    if len(_ARGS_CACHE) > 4096:
+        _ARGS_CACHE.clear()
+    _ARGS_CACHE[key] = a
+    return a
+
+
+def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x: Optional[Tensor], meta_args,
+                matmul_type: int, tuning=None) -> Tensor:
+    """out[M, N] = epilogue(x[M, K] @ dequant(W_q)) — the seam the reference fills with
+    GEMLITE_TRITON_MAPPING[...].forward (core.py:184-190)."""
+    lib = _hip.load()
+    _hip.require_gpu_tensor(x, "x")
+    _hip.require_gpu_tensor(W_q, "W_q")
+    a = _static_args(W_q, scales, zeros, meta_args)
+    M, K = x.shape
+    if K != a.K:
+        raise ValueError(f"x has {K} input features, the packed weight expects {a.K}")
+    out = torch.empty((M, a.N), dtype=DTYPE_TO_TORCH[a.output_dtype], device=x.device)
+    a.matmul_type = matmul_type
+    a.x, a.out, a.M = x.data_ptr(), out.data_ptr(), M
+    a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
+    a.stride_xm, a.stride_xk = x.stride(0), x.stride(1)
+    a.stride_om, a.stride_on = out.stride(0), out.stride(1)
+    if scales_x is not None:
+        a.scales_x, a.stride_sx_m = scales_x.data_ptr(), scales_x.stride(0)
+    else:
+        a.scales_x, a.stride_sx_m = None, 0
+    for i in range(4):
+        a.tuning[i] = 0 if tuning is None else int(tuning[i])
+    stream = _hip.current_stream_handle(x.device)
+    need = lib.gemlite_hip_workspace_bytes(_hip.C.byref(a))
+    if need:
+        ws = _hip.workspace(x.device, stream, need)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    else:
+        a.workspace, a.workspace_bytes = None, 0
+    rc = lib.gemlite_hip_forward(_hip.C.byref(a), stream)
+    if rc != 0:
+        _hip.raise_for_status(rc, "gemlite_hip_forward")
+    return out
+
+
+def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], meta_args: List[int],
+                  matmul_type: int = -1) -> Tensor:
+    W_q, scales, zeros = tensor_args
+    W_nbits = meta_args[1]
+    out_features = W_q.shape[1]
+    if not x.is_contiguous():
+        x = x.contiguous()
+    out_shape = x.shape[:-1] + (out_features,)
+    in_code = meta_args[5]
+    if is_mx_dtype(in_code):
+        raise NotImplementedError("MX / NV block-scaled dtypes are outside this build's scope")
+    scales_x = None
+    if bool(meta_args[0]) and DType(in_code) in FP8_INT8_DTYPES:
+        # dynamic per-token activation quantisation (core.py:155-175)
+        x, scales_x = scale_activations_per_token(x, w_dtype=DTYPE_TO_TORCH[in_code])
+    x2 = x.view(-1, x.shape[-1])
+    if matmul_type < 0:
+        matmul_type = GEMLITE_MATMUL_TYPES_MAPPING[get_matmul_type(x2.shape[0], W_nbits, False)]
+    out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type).view(out_shape)
+    if bias is not None:
+        out += bias
+    return out
+
+
+@torch.library.custom_op("gemlite_amd::forward_functional", mutates_args=())
+def forward_functional(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], meta_args: List[int],
+                       matmul_type: int = -1) -> Tensor:
+    return _forward_impl(x, bias, tensor_args, meta_args, matmul_type)
+
+
+@torch.library.register_fake("gemlite_amd::forward_functional")
+def _forward_functional_fake(x, bias, tensor_args, meta_args, matmul_type=-1):
+    return torch.empty(x.shape[:-1] + (tensor_args[0].shape[1],), device=x.device, dtype=x.dtype)
+
+
+# ------------------------------------------------------------------------------------------------------
+# pack(): which dequant / epilogue modes a given (scales, zeros, activation-scaling) combination selects
+# ------------------------------------------------------------------------------------------------------
+def select_modes(*, has_scales: bool, channelwise: bool, zeros_kind: str, scaled_activations: bool, fma_mode: bool):
+    """-> (W_group_mode, channel_scale_mode, fold_zeros).  Semantics of core.py:408-464, as a decision table.
+
+    W_group_mode:        0 none | 1 q - z | 2 q*s | 3 (q - z)*s | 4 fma(q, s, z')   with z' = -z*s folded at pack time
+    channel_scale_mode:  0 none | 1 weight | 2 activation | 3 both (applied after the K reduction)
+    """
+    assert zeros_kind in ("none", "tensor", "int")
+    fold = False
+    if channelwise:
+        # per-output-channel scales move to the epilogue; inside the K loop only the shift remains
+        w_mode = 0 if zeros_kind == "none" else 1
+        c_mode = 3 if scaled_activations else 1
+        return w_mode, c_mode, fold
+    if zeros_kind == "none":
+        w_mode = 2 if has_scales else 0
+    elif zeros_kind == "tensor":
+        if not has_scales:
+            w_mode = 1  # shift only (the reference would fail folding zeros without scales)
+        elif fma_mode:
+            w_mode, fold = 4, True
+        else:
+            w_mode = 3
+    else:
+        w_mode = 3 if has_scales else 1
+    c_mode = 2 if scaled_activations else 0
+    return w_mode, c_mode, fold
+
+
+class GemLiteLinearHIP(torch.nn.Module):
+    SUPPORTED_BITS_TRITON = [1, 2, 4, 8, 16]
+    SUPPORTED_DTYPES = [DType.FP16, DType.BF16, DType.FP32, DType.FP8, DType.FP8e4, DType.FP8e5, DType.INT8]
+    # accepted by the constructor for API parity, rejected at forward time (not gfx950 formats / out of scope)
+    _DEFERRED_DTYPES = [DType.FP8e4nuz, DType.FP8e5nuz, DType.MXFP16, DType.MXBF16, DType.MXFP8, DType.MXFP4,
+                        DType.NVFP4]
+    MIN_SIZE = 32
+    PACKING_BITWIDTH = 32
+
+    def __init__(self, W_nbits=4, group_size=64, in_features=None, out_features=None, input_dtype=DType.FP16,
+                 output_dtype=DType.FP16, acc_dtype=None, scaled_activations=False):
+        super().__init__()
+        if W_nbits not in self.SUPPORTED_BITS_TRITON:
+            raise NotImplementedError("Only " + str(self.SUPPORTED_BITS_TRITON) + " W_nbits are supported.")
+        if in_features is not None and out_features is not None:
+            bad = in_features % self.MIN_SIZE != 0
+            if group_size is not None and in_features % group_size != 0:
+                bad = True
+            if bad:
+                raise NotImplementedError(f"Invalid input shapes: {in_features} , {out_features}. "
+                                          "in_features should be divisible by 32 or the group_size")
+        if input_dtype not in self.SUPPORTED_DTYPES + self._DEFERRED_DTYPES:
+            raise NotImplementedError("Unsupport input dtype: " + str(input_dtype))
+        if group_size is not None and group_size < 16:
+            raise NotImplementedError("Only group_size >= 16 is supported.")
+
+        self.in_features, self.out_features = in_features, out_features
+        self.orig_shape = (out_features, in_features)
+        self.W_nbits = W_nbits
+        self.group_size = 1 if group_size is None else group_size
+        self.unpack_mask = 2 ** W_nbits - 1
+        self.elements_per_sample = None
+        self.signature = (in_features, out_features, W_nbits, self.group_size)
+        self.input_dtype, self.output_dtype = input_dtype, output_dtype
+        self.compute_dtype = DTYPE_TO_TORCH[input_dtype.value]
+        self.meta_dtype = input_dtype
+        self.acc_dtype = GEMLITE_ACC_DTYPE[input_dtype] if acc_dtype is None else acc_dtype
+        # 16/32-bit float activations are never dynamically quantised (core.py:293-296)
+        float_in = self.compute_dtype in (torch.float16, torch.bfloat16, torch.float32)
+        self.scaled_activations = False if float_in else bool(scaled_activations)
+        self.forward = self.forward_auto_no_warmup
+
+    # ------------------------------------------------------------------------------------------ pack
+    def pack(self, W_q: Tensor, scales: Optional[Tensor], zeros: Union[Tensor, int, None], bias: Optional[Tensor] = None,
+             fma_mode: bool = True, contiguous: Optional[bool] = None, packing_bitwidth: Optional[int] = None):
+        if zeros is not None and self.input_dtype == DType.INT8:
+            fractional = isinstance(zeros, float) or (isinstance(zeros, Tensor) and bool((zeros != zeros.round()).any()))
+            if fractional:
+                raise Exception("INT8 inputs is not compatible with floating-point zeros.")
+        if is_mx_dtype(self.input_dtype):
+            raise NotImplementedError("MX / NV block-scaled formats are outside this build's scope")
+        if packing_bitwidth is None:
+            packing_bitwidth = GemLiteLinearHIP.PACKING_BITWIDTH
+
+        packed = W_q.dtype == torch.uint8
+        if packed:
+            self.W_q, self.elements_per_sample = pack_weights_over_cols(
+                W_q.view(self.orig_shape), W_nbits=self.W_nbits, packing_bitwidth=packing_bitwidth, transpose=True)
+            want_contiguous = True if contiguous is None else bool(contiguous)
+        elif W_q.dtype == torch.int8 or W_q.is_floating_point():
+            expect = {torch.float32: 32, torch.float16: 16, torch.bfloat16: 16}.get(W_q.dtype, 8)
+            assert self.W_nbits == expect, f"Invalid {expect}-bit weights."
+            self.W_q = W_q.t()  # [K, N] view with strides (1, K): K-contiguous per output column
+            self.elements_per_sample = 1
+            want_contiguous = False if contiguous is None else bool(contiguous)
+        else:
+            raise Exception("Weights were not packed, please check your W_q.dtype")
+
+        self.device = self.W_q.device
+        self.bias = None if bias is None else bias.to(device=self.device)
+
+        N = self.out_features
+        zeros_kind = "none" if zeros is None else ("tensor" if isinstance(zeros, Tensor) else "int")
+        channelwise = scales is not None and scales.numel() == N
+        self.meta_is_channelwise = channelwise
+        self.W_group_mode, self.channel_scale_mode, fold = select_modes(
+            has_scales=scales is not None, channelwise=channelwise, zeros_kind=zeros_kind,
+            scaled_activations=self.scaled_activations, fma_mode=fma_mode)
+
+        def rows_by_group(t: Tensor) -> Tensor:  # [N * K/g (,1)] -> [K/g, N], N fastest
+            return t.view((N, -1)).t()
+
+        self.scales = None if scales is None else rows_by_group(scales)
+        if zeros_kind == "tensor":
+            if fold:  # z' = -z * s, computed in fp32 and rounded to the zeros dtype (core.py:433-436)
+                zeros = (-zeros.float() * scales.float()).to(zeros.dtype)
+            self.zeros = rows_by_group(zeros)
+        elif zeros_kind == "int":
+            self.zeros = torch.tensor(int(zeros), dtype=torch.int32, device=self.device)
+        else:
+            self.zeros = None
+        if self.channel_scale_mode in (1, 3):
+            assert self.W_group_mode not in (3, 4), "Can't use channel_scale_mode with W_group_mode == 3 or 4."
+
+        # absent metadata travels as empty int32 tensors so the functional signature stays List[Tensor]
+        if self.zeros is None:
+            self.zeros = torch.tensor([[]], dtype=torch.int32, device=self.device)
+        if self.scales is None:
+            self.scales = torch.tensor([[]], dtype=torch.int32, device=self.device)
+
+        self.data_contiguous = want_contiguous
+        if want_contiguous:
+            self.W_q = self.W_q.contiguous()
+        self.scales = self.scales.contiguous()
+        self.zeros = self.zeros.contiguous()
+        self.meta_dtype = TORCH_TO_DTYPE[self.scales.dtype]
+
+        as_param = lambda t: torch.nn.Parameter(t, requires_grad=False)  # noqa: E731
+        self.W_q, self.scales, self.zeros = as_param(self.W_q), as_param(self.scales), as_param(self.zeros)
+        self.bias = as_param(self.bias) if self.bias is not None else None
+        self.metadata = as_param(torch.tensor(self.get_meta_args(), device=self.device, dtype=torch.int32))
+        self.orig_shape = as_param(torch.tensor([self.out_features, self.in_features], device=self.device,
+                                                dtype=torch.int32))
+        return self
+
+    # ---------------------------------------------------------------------------------- (de)serialise
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        self.W_q = state_dict.pop("W_q", None)
+        self.bias = state_dict.pop("bias", None)
+        self.scales = state_dict.pop("scales", None)
+        self.zeros = state_dict.pop("zeros", None)
+        self.metadata = [int(v) for v in state_dict.pop("metadata")]
+        self.orig_shape = tuple(int(v) for v in state_dict.pop("orig_shape"))
+        for name, val in zip(_META_FIELDS, self.metadata):
+            setattr(self, name, val)
+        for name in ("input_dtype", "output_dtype", "acc_dtype", "meta_dtype"):
+            setattr(self, name, DType(getattr(self, name)))
+        self.scaled_activations, self.data_contiguous = bool(self.scaled_activations), bool(self.data_contiguous)
+        self.out_features, self.in_features = self.orig_shape
+        self.compute_dtype = DTYPE_TO_TORCH[self.input_dtype.value]
+        self.signature = (self.in_features, self.out_features, self.W_nbits, self.group_size)
+        self.device = self.W_q.device
+
+    # ------------------------------------------------------------------------------------- arguments
+    def get_tensor_args(self):
+        return [self.W_q, self.scales, self.zeros]
+
+    def get_meta_args(self):
+        return [int(self.scaled_activations), self.W_nbits, self.group_size, self.unpack_mask,
+                self.elements_per_sample, self.input_dtype.value, self.output_dtype.value, self.acc_dtype.value,
+                self.meta_dtype.value, self.channel_scale_mode, self.W_group_mode, int(self.data_contiguous)]
+
+    # --------------------------------------------------------------------------------------- forward
+    def _call(self, x: Tensor, matmul_type: int) -> Tensor:
+        if torch.compiler.is_compiling():
+            return forward_functional(x, self.bias, self.get_tensor_args(), self.get_meta_args(), matmul_type)
+        return _forward_impl(x, self.bias, self.get_tensor_args(), self.get_meta_args(), matmul_type)
+
+    def forward_manual(self, x: Tensor, matmul_type: str = "GEMM") -> Tensor:
+        return self._call(x, GEMLITE_MATMUL_TYPES_MAPPING[matmul_type])
+
+    def forward_auto_no_warmup(self, x: Tensor) -> Tensor:
+        return self._call(x, -1)
+
+    # ----------------------------------------------------------------------- tuning-hint JSON cache
+    @staticmethod
+    def cache_config(filename: str):
+        """Merge the in-memory hint table into `filename` (JSON: family -> "(M,N,K,g,e,type_id)" -> dict)."""
+        try:
+            with _FILE_LOCK, open(filename, "r") as f:
+                config = json.load(f)
+        except Exception:
+            config = {}
+        for name in GEMLITE_MATMUL_TYPES:
+            config.setdefault(name, {}).update(GEMLITE_HIP_CONFIG_CACHE.get(name, {}))
+        with _FILE_LOCK, open(filename, "w") as f:
+            json.dump(config, f)
+
+    @staticmethod
+    def load_config(filename: str, print_error: bool = True, overwrite: bool = False):
+        if filename is None:
+            return False
+        try:
+            with _FILE_LOCK, open(filename, "r") as f:
+                config = json.load(f)
+            if overwrite:
+                GEMLITE_HIP_CONFIG_CACHE.clear()
+            for name, entries in config.items():
+                GEMLITE_HIP_CONFIG_CACHE.setdefault(name, {}).update(entries)
+        except Exception as e:  # same contract as the reference: log and report failure
+            if print_error:
+                logger.error(f"Failed to load the cache file '{filename}': {e}")
+            return False
+        return True
+
+    @staticmethod
+    def reset_config():
+        GEMLITE_HIP_CONFIG_CACHE.clear()
+
+
+GemLiteLinear = GemLiteLinearHIP
+GemLiteLinearTriton = GemLiteLinearHIP  # the reference's class name; there is no Triton here

@@ -1,0 +1,316 @@
+// api.hip — the C ABI of libgemlite_hip.so (include/gemlite_hip.h): validation, kernel selection,
+// workspace carving and launch.  Host code only; the kernels live in gemv_wn.hip, gemm_wn_stream.hip,
+// gemm_wn_tiled.hip and generic.hip.
+//
+// Selection mirrors get_matmul_type() (gemlite/core.py:100-114) in spirit: the caller's matmul_type names
+// a kernel FAMILY; inside a family the library picks the CDNA4 kernel that covers the configuration, and
+// everything else goes to the generic coverage kernel — never to a CPU path.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gl_common.h"
+
+namespace gl {
+// planners (defined next to their kernels)
+bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+const void* generic_kernel_fn();
+const void* kmajor_kernel_fn(int mb);
+const void* act_quant_kernel_fn();
+const void* pack_kernel_fn();
+const void* unpack_kernel_fn();
+
+}  // namespace gl
+
+using namespace gl;
+
+static thread_local int tl_last_hip_error = 0;
+static thread_local void* tl_evt_start = nullptr;
+static thread_local void* tl_evt_stop = nullptr;
+
+static int dtype_size(int dt) {
+    switch (dt) {
+        case GEMLITE_DT_FP32: case GEMLITE_DT_INT32: case GEMLITE_DT_UINT32: return 4;
+        case GEMLITE_DT_FP16: case GEMLITE_DT_BF16: case GEMLITE_DT_INT16: case GEMLITE_DT_UINT16: return 2;
+        case GEMLITE_DT_INT64: return 8;
+        case GEMLITE_DT_FP8E4: case GEMLITE_DT_FP8E5: case GEMLITE_DT_INT8: case GEMLITE_DT_UINT8: return 1;
+        default: return 0;
+    }
+}
+
+enum Kind { K_NONE = 0, K_GEMV_WN, K_STREAM_WN, K_TILED_WN, K_KMAJOR, K_GENERIC };
+
+struct Resolved {
+    Kind kind = K_NONE;
+    LaunchPlan lp{};
+    WnParams wn{};
+    GenericParams gp{};
+    int status = GEMLITE_OK;
+};
+
+static Epilogue make_epilogue(const gemlite_hip_forward_args& a) {
+    Epilogue e{};
+    e.out = a.out;
+    e.scales_w = a.scales;
+    e.scales_x = (const float*)a.scales_x;
+    e.stride_om = a.stride_om;
+    e.stride_on = a.stride_on;
+    e.stride_sx_m = a.stride_sx_m;
+    e.out_dt = a.output_dtype;
+    e.meta_dt = a.meta_dtype;
+    e.c_mode = a.channel_scale_mode;
+    return e;
+}
+
+static int validate(const gemlite_hip_forward_args* a) {
+    if (!a || a->struct_size != sizeof(gemlite_hip_forward_args)) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (!a->x || !a->w_q || !a->out) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (a->M > 0x7FFFFFFF || a->N > 0x7FFFFFFF || a->K > 0x7FFFFFFF) return GEMLITE_ERR_BAD_SHAPE;
+    if (a->W_group_mode < 0 || a->W_group_mode > 4) return GEMLITE_ERR_UNSUPPORTED;
+    if (a->channel_scale_mode < 0 || a->channel_scale_mode > 3) return GEMLITE_ERR_UNSUPPORTED;  // 4 = MX
+    if (a->elements_per_sample < 1) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (a->K % a->elements_per_sample != 0) return GEMLITE_ERR_BAD_SHAPE;
+    if (a->input_dtype == GEMLITE_DT_FP8E4NUZ || a->input_dtype == GEMLITE_DT_FP8E5NUZ) return GEMLITE_ERR_UNSUPPORTED;
+    if (a->input_dtype > GEMLITE_DT_FP8E5NUZ) return GEMLITE_ERR_UNSUPPORTED;  // MX / NV formats: out of scope
+    if (dtype_size(a->input_dtype) == 0) return GEMLITE_ERR_UNSUPPORTED;
+    if (!(a->output_dtype == GEMLITE_DT_FP32 || a->output_dtype == GEMLITE_DT_FP16 || a->output_dtype == GEMLITE_DT_BF16))
+        return GEMLITE_ERR_UNSUPPORTED;
+    const bool need_s = a->W_group_mode >= 2 || a->channel_scale_mode == 1 || a->channel_scale_mode == 3;
+    const bool need_z = a->W_group_mode == 1 || a->W_group_mode >= 3;
+    if (need_s && !a->scales) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (need_z && !a->zeros) return GEMLITE_ERR_BAD_ARGUMENT;
+    if ((a->channel_scale_mode == 2 || a->channel_scale_mode == 3) && !a->scales_x) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (a->elements_per_sample > 1) {
+        if (a->w_pack_bits != 8 && a->w_pack_bits != 16 && a->w_pack_bits != 32 && a->w_pack_bits != 64)
+            return GEMLITE_ERR_BAD_ARGUMENT;
+        if (a->W_nbits * a->elements_per_sample != a->w_pack_bits) return GEMLITE_ERR_BAD_ARGUMENT;
+    } else if (dtype_size(a->w_dtype) == 0) {
+        return GEMLITE_ERR_UNSUPPORTED;
+    }
+    const bool grouped = a->W_group_mode >= 2 || (need_z && !a->zero_is_scalar);
+    if (grouped && a->group_size <= 0) return GEMLITE_ERR_BAD_SHAPE;
+    if (a->input_dtype == GEMLITE_DT_INT8 && a->W_group_mode >= 2) return GEMLITE_ERR_UNSUPPORTED;
+    return GEMLITE_OK;
+}
+
+static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
+    r.status = validate(&a);
+    if (r.status != GEMLITE_OK) return;
+    const bool packed = a.elements_per_sample > 1;
+    const bool x16 = a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_BF16;
+    // metadata rows actually indexed by K: channel-wise / scalar metadata behaves like one K-long group
+    const bool per_group_meta = a.W_group_mode >= 2 || ((a.W_group_mode == 1) && !a.zero_is_scalar &&
+                                                        !(a.channel_scale_mode == 1 || a.channel_scale_mode == 3));
+    const int eff_group = per_group_meta ? a.group_size : (int)a.K;
+
+    // ---- specialised packed-weight kernels ---------------------------------------------------------
+    if (packed && a.w_pack_bits == 32 && x16 && a.stride_wn == 1 && a.stride_xk == 1 && a.stride_on == 1 &&
+        (a.stride_meta_n == 1 || !per_group_meta) && (a.K % eff_group == 0)) {
+        WnParams p{};
+        p.x = a.x; p.w = (const uint32_t*)a.w_q; p.scales = a.scales; p.zeros = a.zeros;
+        p.epi = make_epilogue(a);
+        p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
+        p.group_size = eff_group;
+        p.w_mode = a.W_group_mode;
+        p.meta_dt = a.meta_dtype; p.zeros_dt = a.zeros_dtype; p.zero_is_scalar = a.zero_is_scalar;
+        p.stride_xm = a.stride_xm; p.stride_xk = a.stride_xk; p.stride_wk = a.stride_wk;
+        p.stride_meta_g = per_group_meta ? a.stride_meta_g : 0;
+        const int mt = a.matmul_type;
+        const bool want_gemv = (mt == GEMLITE_MATMUL_GEMV || mt == GEMLITE_MATMUL_GEMV_REVSPLITK ||
+                                mt == GEMLITE_MATMUL_GEMV_SPLITK || (mt == GEMLITE_MATMUL_AUTO && a.M <= 8));
+        const bool meta_ok_f16 = a.input_dtype != GEMLITE_DT_FP16 || a.W_group_mode == 0 ||
+                                 ((a.W_group_mode < 2 || a.meta_dtype == GEMLITE_DT_FP16) &&
+                                  (!(a.W_group_mode == 1 || a.W_group_mode >= 3) || a.zero_is_scalar ||
+                                   a.zeros_dtype == GEMLITE_DT_FP16));
+        LaunchPlan lp{};
+        if (want_gemv && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }
+        if (!want_gemv && meta_ok_f16) {
+            const bool want_tiled = (mt == GEMLITE_MATMUL_GEMM || (mt == GEMLITE_MATMUL_AUTO && a.M > 64));
+            if (want_tiled && a.tuning[0] != 1 && plan_gemm_wn_tiled(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
+            if (plan_gemm_wn_stream(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
+        }
+        // AUTO with small M that the GEMV planner rejected may still fit the streaming kernel
+        if (want_gemv && mt == GEMLITE_MATMUL_AUTO && meta_ok_f16 && plan_gemm_wn_stream(a, p, lp)) {
+            r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return;
+        }
+    }
+
+    // ---- coverage kernels ---------------------------------------------------------------------------
+    GenericParams g{};
+    g.x = a.x; g.w = a.w_q; g.scales = a.scales; g.zeros = a.zeros;
+    g.epi = make_epilogue(a);
+    g.M = (int)a.M; g.N = (int)a.N; g.K = (int)a.K;
+    g.nbits = a.W_nbits; g.e = a.elements_per_sample; g.pack_bits = a.w_pack_bits;
+    g.w_dt = a.w_dtype; g.x_dt = a.input_dtype;
+    g.group_size = eff_group; g.w_mode = a.W_group_mode;
+    g.meta_dt = a.meta_dtype; g.zeros_dt = a.zeros_dtype; g.zero_is_scalar = a.zero_is_scalar;
+    g.int_acc = (a.input_dtype == GEMLITE_DT_INT8 && (packed || a.w_dtype == GEMLITE_DT_INT8)) ? 1 : 0;
+    g.stride_xm = a.stride_xm; g.stride_xk = a.stride_xk; g.stride_wk = a.stride_wk; g.stride_wn = a.stride_wn;
+    g.stride_meta_g = per_group_meta ? a.stride_meta_g : 0;
+    g.stride_meta_n = per_group_meta ? a.stride_meta_n : ((a.W_group_mode == 1 && !a.zero_is_scalar) ? 1 : 0);
+    r.gp = g;
+    const int esz = dtype_size(a.w_dtype);
+    if (!packed && a.W_group_mode == 0 && a.stride_wk == 1 && a.stride_xk == 1 && a.w_dtype == a.input_dtype &&
+        esz > 0 && (a.K % (16 / esz) == 0) && ((a.stride_wn * esz) % 16 == 0) && ((a.stride_xm * esz) % 16 == 0) &&
+        (((uintptr_t)a.w_q | (uintptr_t)a.x) % 16 == 0)) {
+        const int mb = a.M == 1 ? 1 : 4;
+        r.kind = K_KMAJOR;
+        r.lp.fn = kmajor_kernel_fn(mb);
+        r.lp.name = "kmajor_matmul_kernel";
+        r.lp.grid = dim3((unsigned)((a.N + 3) / 4), (unsigned)((a.M + mb - 1) / mb), 1);
+        r.lp.block = dim3(256, 1, 1);
+        return;
+    }
+    if (a.M > 65535) { r.status = GEMLITE_ERR_BAD_SHAPE; return; }
+    r.kind = K_GENERIC;
+    r.lp.fn = generic_kernel_fn();
+    r.lp.name = "generic_matmul_kernel";
+    r.lp.grid = dim3((unsigned)((a.N + 255) / 256), (unsigned)a.M, 1);
+    r.lp.block = dim3(256, 1, 1);
+}
+
+static int launch(const void* fn, dim3 grid, dim3 block, void** kargs, size_t lds, hipStream_t stream) {
+    hipError_t err;
+    if (tl_evt_start || tl_evt_stop) {
+        err = hipExtLaunchKernel(fn, grid, block, kargs, lds, stream, (hipEvent_t)tl_evt_start, (hipEvent_t)tl_evt_stop, 0);
+        tl_evt_start = tl_evt_stop = nullptr;
+    } else {
+        err = hipLaunchKernel(fn, grid, block, kargs, lds, stream);
+    }
+    if (err != hipSuccess) {
+        tl_last_hip_error = (int)err;
+        (void)hipGetLastError();
+        return GEMLITE_ERR_LAUNCH;
+    }
+    return GEMLITE_OK;
+}
+
+static int ensure_lds(const void* fn, size_t lds) {
+    if (lds <= 65536) return GEMLITE_OK;
+    static thread_local const void* done[8] = {nullptr};  // raise the dynamic-LDS cap once per kernel
+    for (const void* d : done) if (d == fn) return GEMLITE_OK;
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) { tl_last_hip_error = (int)err; (void)hipGetLastError(); return GEMLITE_ERR_LAUNCH; }
+    for (const void*& d : done) if (!d) { d = fn; break; }
+    return GEMLITE_OK;
+}
+
+extern "C" {
+
+int gemlite_hip_abi_version(void) { return GEMLITE_HIP_ABI_VERSION; }
+
+const char* gemlite_hip_build_info(void) {
+    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_stream, gemm_wn_tiled, kmajor, generic, "
+           "act_quant_per_token, pack/unpack_over_cols";
+}
+
+const char* gemlite_hip_status_string(int status) {
+    switch (status) {
+        case GEMLITE_OK: return "ok";
+        case GEMLITE_ERR_BAD_ARGUMENT: return "bad argument (null pointer, non-positive size or ABI struct_size mismatch)";
+        case GEMLITE_ERR_UNSUPPORTED: return "unsupported dtype / bit-width / mode combination";
+        case GEMLITE_ERR_BAD_SHAPE: return "bad shape (K not divisible by elements_per_sample / group_size, or too large)";
+        case GEMLITE_ERR_WORKSPACE: return "workspace missing or too small";
+        case GEMLITE_ERR_LAUNCH: return "HIP launch failed (see gemlite_hip_last_hip_error)";
+        case GEMLITE_ERR_NO_DEVICE: return "current device is not gfx950";
+        default: return "unknown status";
+    }
+}
+
+int gemlite_hip_last_hip_error(void) { return tl_last_hip_error; }
+
+int gemlite_hip_query(const gemlite_hip_forward_args* args) {
+    const int v = validate(args);
+    if (v != GEMLITE_OK) return v;
+    Resolved r;
+    resolve(*args, r);
+    return r.status;
+}
+
+uint64_t gemlite_hip_workspace_bytes(const gemlite_hip_forward_args* args) {
+    if (validate(args) != GEMLITE_OK) return 0;
+    Resolved r;
+    resolve(*args, r);
+    return r.status == GEMLITE_OK ? r.lp.ws_bytes : 0;
+}
+
+const char* gemlite_hip_kernel_name(const gemlite_hip_forward_args* args) {
+    if (validate(args) != GEMLITE_OK) return "invalid";
+    Resolved r;
+    resolve(*args, r);
+    return r.status == GEMLITE_OK ? r.lp.name : "unsupported";
+}
+
+void gemlite_hip_set_profile_events(void* start_event, void* stop_event) {
+    tl_evt_start = start_event;
+    tl_evt_stop = stop_event;
+}
+
+int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
+    const int v = validate(args);
+    if (v != GEMLITE_OK) return v;
+    Resolved r;
+    resolve(*args, r);
+    if (r.status != GEMLITE_OK) return r.status;
+    hipStream_t st = (hipStream_t)stream;
+    if (r.kind == K_GEMV_WN || r.kind == K_STREAM_WN || r.kind == K_TILED_WN) {
+        if (r.lp.ws_bytes > 0) {
+            if (!args->workspace || args->workspace_bytes < r.lp.ws_bytes) return GEMLITE_ERR_WORKSPACE;
+            r.wn.slabs = (float*)args->workspace;
+            r.wn.counters = (unsigned*)((char*)args->workspace + r.lp.slab_bytes);
+        }
+        const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes);
+        if (e != GEMLITE_OK) return e;
+        void* kargs[] = {(void*)&r.wn};
+        return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
+    }
+    void* kargs[] = {(void*)&r.gp};
+    return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, 0, st);
+}
+
+int gemlite_hip_scale_activations_per_token(const void* x, void* y, float* scales, int64_t M, int64_t K,
+                                            int64_t stride_xm, int32_t in_dtype, int32_t out_dtype, void* stream) {
+    if (!x || !y || !scales || M <= 0 || K <= 0) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (!(in_dtype == GEMLITE_DT_FP16 || in_dtype == GEMLITE_DT_BF16 || in_dtype == GEMLITE_DT_FP32)) return GEMLITE_ERR_UNSUPPORTED;
+    if (!(out_dtype == GEMLITE_DT_INT8 || out_dtype == GEMLITE_DT_FP8E4 || out_dtype == GEMLITE_DT_FP8E5)) return GEMLITE_ERR_UNSUPPORTED;
+    if (M > 0x7FFFFFFF) return GEMLITE_ERR_BAD_SHAPE;
+    int in_dt = in_dtype, out_dt = out_dtype;
+    void* kargs[] = {(void*)&x, (void*)&y, (void*)&scales, (void*)&K, (void*)&stride_xm, (void*)&in_dt, (void*)&out_dt};
+    return launch(act_quant_kernel_fn(), dim3((unsigned)M, 1, 1), dim3(256, 1, 1), kargs, 0, (hipStream_t)stream);
+}
+
+static int check_pack(int64_t N, int64_t K, int32_t nbits, int32_t pack_bits) {
+    if (N <= 0 || K <= 0) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (!(nbits == 1 || nbits == 2 || nbits == 4 || nbits == 8)) return GEMLITE_ERR_UNSUPPORTED;
+    if (!(pack_bits == 8 || pack_bits == 16 || pack_bits == 32 || pack_bits == 64) || pack_bits < nbits) return GEMLITE_ERR_UNSUPPORTED;
+    if (K % (pack_bits / nbits) != 0) return GEMLITE_ERR_BAD_SHAPE;
+    if ((K / (pack_bits / nbits)) * N > 0x7FFFFFFFll * 256) return GEMLITE_ERR_BAD_SHAPE;
+    return GEMLITE_OK;
+}
+
+int gemlite_hip_pack_over_cols(const uint8_t* w_q, void* out, int64_t N, int64_t K, int64_t ld_in, int32_t W_nbits,
+                               int32_t pack_bits, void* stream) {
+    if (!w_q || !out) return GEMLITE_ERR_BAD_ARGUMENT;
+    const int c = check_pack(N, K, W_nbits, pack_bits);
+    if (c != GEMLITE_OK) return c;
+    const int64_t total = (K / (pack_bits / W_nbits)) * N;
+    int nb = W_nbits, pb = pack_bits;
+    void* kargs[] = {(void*)&w_q, (void*)&out, (void*)&N, (void*)&K, (void*)&ld_in, (void*)&nb, (void*)&pb};
+    return launch(pack_kernel_fn(), dim3((unsigned)((total + 255) / 256), 1, 1), dim3(256, 1, 1), kargs, 0, (hipStream_t)stream);
+}
+
+int gemlite_hip_unpack_over_cols(const void* packed, uint8_t* out, int64_t N, int64_t K, int32_t W_nbits,
+                                 int32_t pack_bits, void* stream) {
+    if (!packed || !out) return GEMLITE_ERR_BAD_ARGUMENT;
+    const int c = check_pack(N, K, W_nbits, pack_bits);
+    if (c != GEMLITE_OK) return c;
+    const int64_t total = (K / (pack_bits / W_nbits)) * N;
+    int nb = W_nbits, pb = pack_bits;
+    void* kargs[] = {(void*)&packed, (void*)&out, (void*)&N, (void*)&K, (void*)&nb, (void*)&pb};
+    return launch(unpack_kernel_fn(), dim3((unsigned)((total + 255) / 256), 1, 1), dim3(256, 1, 1), kargs, 0, (hipStream_t)stream);
+}
+
+}  // extern "C"

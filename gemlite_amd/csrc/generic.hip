@@ -1,0 +1,229 @@
+// generic.hip — coverage kernels: every (W_group_mode, channel_scale_mode, dtype, stride) combination of
+// the reference's five kernels that has no specialised CDNA4 kernel yet lands here.  Still native HIP on
+// the GPU (there is no CPU fallback anywhere in the product), just not tuned.
+//
+//   generic_matmul_kernel : lane = output column; walks K; any packed width / unpacked dtype / strides.
+//   kmajor_matmul_kernel  : unpacked K-contiguous weights (W_q = W.t() view, strides (1, K),
+//                           core.py:369-381): one wave per output column, lanes along K with 16-byte
+//                           loads — the streaming GEMV for A8W8 / FP8xFP8 / FP16xFP16 at small M.
+//
+// Numerics follow triton_kernels/utils.py:57-89 + gemm_kernels.py:347-413 with fp32 (int32 for int8 x int8)
+// accumulation.  One deliberate fidelity point: for fp8 activations the reference casts the dequantised
+// weight to the input dtype before the dot (`b.to(input_dtype)`, gemm_kernels.py:384) — so do we.
+#include "gl_common.h"
+
+namespace gl {
+
+
+__device__ __forceinline__ uint32_t load_word(const void* w, int64_t idx, int pack_bits) {
+    switch (pack_bits) {
+        case 8: return ((const uint8_t*)w)[idx];
+        case 16: return ((const uint16_t*)w)[idx];
+        default: return ((const uint32_t*)w)[idx];
+    }
+}
+
+__device__ __forceinline__ float round_to_input(float v, int x_dt) {
+    if (x_dt == GEMLITE_DT_FP8E4) return fp8e4m3_to_float(float_to_fp8e4m3(v));
+    if (x_dt == GEMLITE_DT_FP8E5) return fp8e5m2_to_float(float_to_fp8e5m2(v));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void generic_matmul_kernel(const GenericParams p) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t m = blockIdx.y;
+    if (n >= p.N) return;
+    const float zs = p.zero_is_scalar ? load_as_float(p.zeros, 0, p.zeros_dt) : 0.f;
+    const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3);
+    const bool packed64 = p.pack_bits == 64;
+    float accf = 0.f;
+    int acci = 0;
+    int64_t cur_g = -1;
+    float s = 1.f, z = 0.f;
+    const uint32_t mask = p.nbits >= 32 ? 0xFFFFFFFFu : ((1u << p.nbits) - 1u);
+    for (int64_t k = 0; k < p.K; ++k) {
+        float q;
+        if (p.e > 1) {
+            const int64_t j = k / p.e;
+            const int sh = (int)(k - j * p.e) * p.nbits;
+            if (packed64) {
+                const uint64_t wd = ((const uint64_t*)p.w)[j * p.stride_wk + n * p.stride_wn];
+                q = (float)(uint32_t)((wd >> sh) & mask);
+            } else {
+                const uint32_t wd = load_word(p.w, j * p.stride_wk + n * p.stride_wn, p.pack_bits);
+                q = (float)((wd >> sh) & mask);
+            }
+        } else {
+            q = load_as_float(p.w, k * p.stride_wk + n * p.stride_wn, p.w_dt);
+        }
+        if (need_s || (need_z && !p.zero_is_scalar)) {
+            const int64_t gidx = k / p.group_size;
+            if (gidx != cur_g) {
+                cur_g = gidx;
+                if (need_s) s = load_as_float(p.scales, gidx * p.stride_meta_g + n * p.stride_meta_n, p.meta_dt);
+                if (need_z && !p.zero_is_scalar)
+                    z = load_as_float(p.zeros, gidx * p.stride_meta_g + n * p.stride_meta_n, p.zeros_dt);
+            }
+        }
+        if (p.zero_is_scalar) z = zs;
+        const float wv = dequant_f32(q, s, z, p.w_mode);
+        if (p.int_acc) {
+            acci += (int)load_as_float(p.x, m * p.stride_xm + k * p.stride_xk, p.x_dt) * (int)wv;
+        } else {
+            const float xv = load_as_float(p.x, m * p.stride_xm + k * p.stride_xk, p.x_dt);
+            accf = __builtin_fmaf(xv, round_to_input(wv, p.x_dt), accf);
+        }
+    }
+    epilogue_store(p.epi, p.int_acc ? (float)acci : accf, m, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// unpacked, K-contiguous weights, W_group_mode 0: wave per column, 16-byte loads along K
+// ---------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int MB>
+__global__ __launch_bounds__(256) void kmajor_matmul_kernel(const GenericParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t m0 = (int64_t)blockIdx.y * MB;
+    if (n >= p.N) return;
+    const int esz = (p.w_dt == GEMLITE_DT_FP32) ? 4 : ((p.w_dt == GEMLITE_DT_FP16 || p.w_dt == GEMLITE_DT_BF16) ? 2 : 1);
+    const int per = 16 / esz;  // elements per 16-byte load
+    const uint8_t* wcol = (const uint8_t*)p.w + n * p.stride_wn * esz;
+    float accf[MB];
+    int acci[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) { accf[i] = 0.f; acci[i] = 0; }
+    for (int64_t k = (int64_t)lane * per; k < p.K; k += 64 * per) {
+        const u32x4 wv = *(const u32x4*)(wcol + k * esz);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            if (m0 + i >= p.M) continue;
+            const uint8_t* xrow = (const uint8_t*)p.x + ((m0 + i) * p.stride_xm + k) * esz;
+            const u32x4 xv = *(const u32x4*)xrow;
+            if (p.w_dt == GEMLITE_DT_INT8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acci[i] = __builtin_amdgcn_sdot4((int)xv[q], (int)wv[q], acci[i], false);
+            } else if (p.w_dt == GEMLITE_DT_FP16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) accf[i] = F16Traits<half_tag>::dot2(xv[q], wv[q], accf[i]);
+            } else if (p.w_dt == GEMLITE_DT_BF16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) accf[i] = F16Traits<bf16_tag>::dot2(xv[q], wv[q], accf[i]);
+            } else if (p.w_dt == GEMLITE_DT_FP32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    accf[i] = __builtin_fmaf(__builtin_bit_cast(float, xv[q]), __builtin_bit_cast(float, wv[q]), accf[i]);
+            } else {  // fp8 e4m3 / e5m2
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint8_t xb = (xv[q] >> (8 * b)) & 0xFF, wb = (wv[q] >> (8 * b)) & 0xFF;
+                        const float xf = p.w_dt == GEMLITE_DT_FP8E4 ? fp8e4m3_to_float(xb) : fp8e5m2_to_float(xb);
+                        const float wf = p.w_dt == GEMLITE_DT_FP8E4 ? fp8e4m3_to_float(wb) : fp8e5m2_to_float(wb);
+                        accf[i] = __builtin_fmaf(xf, wf, accf[i]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        float v = p.w_dt == GEMLITE_DT_INT8 ? 0.f : accf[i];
+        int vi = acci[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            v += __shfl_xor(v, off);
+            vi += __shfl_xor(vi, off);
+        }
+        if (lane == 0 && m0 + i < p.M) epilogue_store(p.epi, p.w_dt == GEMLITE_DT_INT8 ? (float)vi : v, m0 + i, n);
+    }
+}
+
+const void* generic_kernel_fn() { return (const void*)generic_matmul_kernel; }
+const void* kmajor_kernel_fn(int mb) {
+    return mb == 1 ? (const void*)kmajor_matmul_kernel<1> : (const void*)kmajor_matmul_kernel<4>;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-token dynamic activation quantisation  (spec: gemlite/quant_utils.py:231-253; the Triton kernel
+// :268-305 uses floor(x + 0.5) on AMD, :259-266).  One block per row; x is read twice (second pass from L2).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_quant_per_token_kernel(const void* x, void* y, float* scales, int64_t K,
+                                                                 int64_t stride_xm, int in_dt, int out_dt) {
+    __shared__ float wmax[4];
+    const int64_t m = blockIdx.x;
+    const int tid = threadIdx.x;
+    float amax = 0.f;
+    for (int64_t k = tid; k < K; k += 256) amax = fmaxf(amax, fabsf(load_as_float(x, m * stride_xm + k, in_dt)));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if ((tid & 63) == 0) wmax[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    float qmin, qmax;
+    if (out_dt == GEMLITE_DT_INT8) { qmin = -128.f; qmax = 127.f; }
+    else if (out_dt == GEMLITE_DT_FP8E4) { qmin = -448.f; qmax = 448.f; }
+    else { qmin = -57344.f; qmax = 57344.f; }
+    const float s = fmaxf(__fdiv_rn(amax, qmax), 1e-6f);
+    if (tid == 0) scales[m] = s;
+    for (int64_t k = tid; k < K; k += 256) {
+        float v = __fdiv_rn(load_as_float(x, m * stride_xm + k, in_dt), s);
+        v = fminf(fmaxf(v, qmin), qmax);
+        if (out_dt == GEMLITE_DT_INT8) {
+            ((int8_t*)y)[m * K + k] = (int8_t)floorf(v + 0.5f);
+        } else if (out_dt == GEMLITE_DT_FP8E4) {
+            ((uint8_t*)y)[m * K + k] = float_to_fp8e4m3(v);
+        } else {
+            ((uint8_t*)y)[m * K + k] = float_to_fp8e5m2(v);
+        }
+    }
+}
+const void* act_quant_kernel_fn() { return (const void*)act_quant_per_token_kernel; }
+
+// ---------------------------------------------------------------------------------------------
+// bit packing along K, output transposed [K/e, N]  (layout spec: gemlite/bitpack.py:36-60 + core.py:384-398)
+// thread = one packed word; consecutive threads = consecutive n (coalesced stores; the uint8 reads of a
+// wave are 64 rows x e contiguous bytes)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_over_cols_kernel(const uint8_t* w, void* out, int64_t N, int64_t K,
+                                                            int64_t ld_in, int nbits, int pack_bits) {
+    const int e = pack_bits / nbits;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (K / e) * N;
+    if (idx >= total) return;
+    const int64_t j = idx / N, n = idx - j * N;
+    const uint8_t* src = w + n * ld_in + j * e;
+    uint64_t word = 0;
+    for (int i = 0; i < e; ++i) word |= (uint64_t)src[i] << (nbits * i);
+    switch (pack_bits) {
+        case 8: ((uint8_t*)out)[idx] = (uint8_t)word; break;
+        case 16: ((uint16_t*)out)[idx] = (uint16_t)word; break;
+        case 32: ((uint32_t*)out)[idx] = (uint32_t)word; break;
+        default: ((uint64_t*)out)[idx] = word; break;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_over_cols_kernel(const void* packed, uint8_t* out, int64_t N, int64_t K,
+                                                              int nbits, int pack_bits) {
+    const int e = pack_bits / nbits;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (K / e) * N;
+    if (idx >= total) return;
+    const int64_t j = idx / N, n = idx - j * N;
+    uint64_t word;
+    switch (pack_bits) {
+        case 8: word = ((const uint8_t*)packed)[idx]; break;
+        case 16: word = ((const uint16_t*)packed)[idx]; break;
+        case 32: word = ((const uint32_t*)packed)[idx]; break;
+        default: word = ((const uint64_t*)packed)[idx]; break;
+    }
+    const uint64_t mask = (1ull << nbits) - 1ull;
+    uint8_t* dst = out + n * K + j * e;
+    for (int i = 0; i < e; ++i) dst[i] = (uint8_t)((word >> (nbits * i)) & mask);
+}
+const void* pack_kernel_fn() { return (const void*)pack_over_cols_kernel; }
+const void* unpack_kernel_fn() { return (const void*)unpack_over_cols_kernel; }
+
+}  // namespace gl

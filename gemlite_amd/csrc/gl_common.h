@@ -1,0 +1,299 @@
+// gl_common.h — shared device/host definitions for libgemlite_hip.so (gfx950 only).
+//
+// Data layout facts every kernel relies on (reference: gemlite/core.py:384-398,419-420,478-485;
+// gemlite/bitpack.py:36-60):
+//   W_q packed   : int32 [K/e, N], N-contiguous; word (j, n) holds k = j*e .. j*e+e-1 of column n,
+//                  element i at bits [b*i, b*i+b)  (e = 32 / W_nbits)
+//   scales/zeros : [K/group, N], N-contiguous (or [N] channel-wise, or a scalar zero)
+//   x            : [M, K] row-major,  out : [M, N] row-major
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gemlite_hip.h"
+
+namespace gl {
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct half_tag {};
+struct bf16_tag {};
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit float traits: the "magic number" unpack (q | MAGIC is the float OFF + q), packed dot2
+// ---------------------------------------------------------------------------------------------
+template <typename Tag>
+struct F16Traits;
+
+template <>
+struct F16Traits<half_tag> {
+    static constexpr uint32_t MAGIC2 = 0x64006400u;  // two fp16 1024.0
+    static constexpr float OFF = 1024.0f;             // exact for q < 1024
+    static constexpr int MAX_QBITS = 8;
+    static constexpr uint32_t ONES2 = 0x3C003C00u;  // (1.0h, 1.0h)
+    static constexpr int DT = GEMLITE_DT_FP16;
+    typedef h8_t frag8;
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
+    }
+    static __device__ __forceinline__ float to_float(uint16_t v) {
+        return (float)__builtin_bit_cast(_Float16, v);
+    }
+    static __device__ __forceinline__ uint16_t from_float(float f) {
+        return __builtin_bit_cast(uint16_t, (_Float16)f);
+    }
+};
+
+template <>
+struct F16Traits<bf16_tag> {
+    static constexpr uint32_t MAGIC2 = 0x43004300u;  // two bf16 128.0
+    static constexpr float OFF = 128.0f;              // exact for q < 128
+    static constexpr int MAX_QBITS = 4;
+    static constexpr uint32_t ONES2 = 0x3F803F80u;
+    static constexpr int DT = GEMLITE_DT_BF16;
+    typedef b8_t frag8;
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, a), __builtin_bit_cast(b2_t, b), c, false);
+    }
+    static __device__ __forceinline__ float to_float(uint16_t v) {
+        return __builtin_bit_cast(float, (uint32_t)v << 16);
+    }
+    static __device__ __forceinline__ uint16_t from_float(float f) {
+        return __builtin_bit_cast(uint16_t, (__bf16)f);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// generic scalar load / store by dtype code (metadata, epilogue). Uniform branches only.
+// ---------------------------------------------------------------------------------------------
+#define GL_HD __host__ __device__ __forceinline__
+
+GL_HD float fp8e4m3_to_float(uint8_t v) {
+    // OCP e4m3fn: bias 7, no inf, NaN = S.1111.111
+    const uint32_t s = (uint32_t)(v & 0x80) << 24;
+    const uint32_t em = v & 0x7F;
+    if (em == 0x7F) return __builtin_bit_cast(float, s | 0x7FC00000u);
+    const uint32_t e = em >> 3, m = em & 7;
+    if (e == 0) {  // subnormal: m * 2^-9
+        const float f = (float)m * 0.001953125f;
+        return s ? -f : f;
+    }
+    return __builtin_bit_cast(float, s | ((e + 120u) << 23) | (m << 20));
+}
+
+GL_HD float fp8e5m2_to_float(uint8_t v) {
+    // e5m2 is the top byte of an fp16
+    const uint16_t h = (uint16_t)v << 8;
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+
+// round-to-nearest-even, saturating to +-448 like torch's .to(float8_e4m3fn) for finite inputs
+GL_HD uint8_t float_to_fp8e4m3(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    const uint8_t s = (u >> 24) & 0x80;
+    u &= 0x7FFFFFFFu;
+    if (u > 0x7F800000u) return s | 0x7F;  // NaN
+    const float a = __builtin_bit_cast(float, u);
+    if (a > 464.0f) return s | 0x7F;  // torch: overflow -> NaN pattern (no inf in e4m3fn)
+    if (a < 0.015625f) {               // below 2^-6: subnormal grid of 2^-9
+        const float r = __builtin_rintf(a * 512.0f);
+        return s | (uint8_t)r;          // r in 0..8 (8 == smallest normal 0x08)
+    }
+    // normal: keep 3 mantissa bits with RNE
+    const uint32_t lsb = (u >> 20) & 1u;
+    u += 0x7FFFFu + lsb;
+    const uint32_t e = (u >> 23) - 120u, m = (u >> 20) & 7u;
+    return s | (uint8_t)((e << 3) | m);
+}
+
+GL_HD uint8_t float_to_fp8e5m2(float f) {
+    // direct fp32 -> e5m2 RNE (bias 15, 2 mantissa bits); overflow -> inf like torch
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    const uint8_t s = (u >> 24) & 0x80;
+    u &= 0x7FFFFFFFu;
+    if (u > 0x7F800000u) return s | 0x7F;  // NaN
+    const float a = __builtin_bit_cast(float, u);
+    if (a >= 61440.0f) return s | 0x7C;    // >= midpoint(57344, 65536) -> inf
+    if (a < 6.103515625e-05f) {            // below 2^-14: subnormal grid of 2^-16
+        const float r = __builtin_rintf(a * 65536.0f);
+        return s | (uint8_t)r;
+    }
+    const uint32_t lsb = (u >> 21) & 1u;
+    u += 0xFFFFFu + lsb;
+    const uint32_t e = (u >> 23) - 112u, m = (u >> 21) & 3u;
+    return s | (uint8_t)((e << 2) | m);
+}
+
+__device__ __forceinline__ float load_as_float(const void* p, int64_t i, int dt) {
+    switch (dt) {
+        case GEMLITE_DT_FP32: return ((const float*)p)[i];
+        case GEMLITE_DT_FP16: return (float)((const _Float16*)p)[i];
+        case GEMLITE_DT_BF16: return __builtin_bit_cast(float, (uint32_t)((const uint16_t*)p)[i] << 16);
+        case GEMLITE_DT_INT8: return (float)((const int8_t*)p)[i];
+        case GEMLITE_DT_UINT8: return (float)((const uint8_t*)p)[i];
+        case GEMLITE_DT_INT32: return (float)((const int32_t*)p)[i];
+        case GEMLITE_DT_FP8E4: return fp8e4m3_to_float(((const uint8_t*)p)[i]);
+        case GEMLITE_DT_FP8E5: return fp8e5m2_to_float(((const uint8_t*)p)[i]);
+        default: return 0.0f;
+    }
+}
+
+__device__ __forceinline__ void store_from_float(void* p, int64_t i, int dt, float v) {
+    switch (dt) {
+        case GEMLITE_DT_FP32: ((float*)p)[i] = v; break;
+        case GEMLITE_DT_FP16: ((_Float16*)p)[i] = (_Float16)v; break;
+        case GEMLITE_DT_BF16: ((__bf16*)p)[i] = (__bf16)v; break;
+        case GEMLITE_DT_INT32: ((int32_t*)p)[i] = (int32_t)__builtin_rintf(v); break;
+        default: break;
+    }
+}
+
+// 4 consecutive metadata values (one per owned column) as floats
+__device__ __forceinline__ f32x4 load_meta4(const void* p, int64_t i, int dt) {
+    f32x4 r;
+    if (dt == GEMLITE_DT_FP16) {
+        const u32x2 v = *(const u32x2*)((const uint16_t*)p + i);
+        const h2_t a = __builtin_bit_cast(h2_t, v[0]), b = __builtin_bit_cast(h2_t, v[1]);
+        r[0] = (float)a[0]; r[1] = (float)a[1]; r[2] = (float)b[0]; r[3] = (float)b[1];
+    } else if (dt == GEMLITE_DT_BF16) {
+        const u32x2 v = *(const u32x2*)((const uint16_t*)p + i);
+        r[0] = __builtin_bit_cast(float, v[0] << 16); r[1] = __builtin_bit_cast(float, v[0] & 0xFFFF0000u);
+        r[2] = __builtin_bit_cast(float, v[1] << 16); r[3] = __builtin_bit_cast(float, v[1] & 0xFFFF0000u);
+    } else if (dt == GEMLITE_DT_FP32) {
+        r = *(const f32x4*)((const float*)p + i);
+    } else {
+        for (int j = 0; j < 4; ++j) r[j] = load_as_float(p, i + j, dt);
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// epilogue: channel scaling (gemm_kernels.py:392-404), cast, store
+// ---------------------------------------------------------------------------------------------
+struct Epilogue {
+    void* out;
+    const void* scales_w;   // [N] channel scales (channel_scale_mode 1/3)
+    const float* scales_x;  // [M] per-token scales (channel_scale_mode 2/3)
+    int64_t stride_om, stride_on, stride_sx_m;
+    int out_dt, meta_dt, c_mode;
+};
+
+__device__ __forceinline__ float epilogue_scale(const Epilogue& e, float v, int64_t m, int64_t n) {
+    if (e.c_mode == 1) {
+        v *= load_as_float(e.scales_w, n, e.meta_dt);
+    } else if (e.c_mode == 2) {
+        v *= e.scales_x[m * e.stride_sx_m];
+    } else if (e.c_mode == 3) {
+        v *= e.scales_x[m * e.stride_sx_m] * load_as_float(e.scales_w, n, e.meta_dt);
+    }
+    return v;
+}
+
+__device__ __forceinline__ void epilogue_store(const Epilogue& e, float v, int64_t m, int64_t n) {
+    store_from_float(e.out, m * e.stride_om + n * e.stride_on, e.out_dt, epilogue_scale(e, v, m, n));
+}
+
+// dequant of an integer code q (as float) for W_group_mode (triton_kernels/utils.py:73-87),
+// evaluated in fp32 on the stored scale / zero
+__device__ __forceinline__ float dequant_f32(float q, float s, float z, int w_mode) {
+    switch (w_mode) {
+        case 1: return q - z;
+        case 2: return q * s;
+        case 3: return (q - z) * s;
+        case 4: return __builtin_fmaf(q, s, z);
+        default: return q;
+    }
+}
+
+// (a, b) such that  sum_k x_k * dequant(q_k) = a * sum_k x_k q_k + b * sum_k x_k  inside one group
+__device__ __forceinline__ void group_affine(float s, float z, int w_mode, float& a, float& b) {
+    switch (w_mode) {
+        case 1: a = 1.0f; b = -z; break;
+        case 2: a = s; b = 0.0f; break;
+        case 3: a = s; b = -z * s; break;
+        case 4: a = s; b = z; break;
+        default: a = 1.0f; b = 0.0f; break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-K hand-off words: write-through (sc1) stores / loads at agent scope
+// (MI355X: per-XCD L2s are not coherent; see DESIGN.md "split-K combine")
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slab_store(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float slab_load(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every storing wave drains its write-through stores, the block joins, one lane takes a ticket.
+// Returns true in every thread of the LAST block to arrive for `counter`.
+__device__ __forceinline__ bool splitk_arrive_is_last(unsigned* counter, unsigned nslices, unsigned* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *lds_flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return *lds_flag == nslices - 1u;
+}
+__device__ __forceinline__ void splitk_reset(unsigned* counter) {
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel parameter block shared by the packed-weight kernels
+// ---------------------------------------------------------------------------------------------
+struct WnParams {
+    const void* x;
+    const uint32_t* w;   // packed int32 words [K/e, N]
+    const void* scales;
+    const void* zeros;
+    Epilogue epi;
+    float* slabs;        // split-K partial sums (workspace)
+    unsigned* counters;  // split-K arrival counters (workspace, zero between launches)
+    int M, N, K;
+    int group_size;      // K elements per metadata row; == K for channel-wise / none
+    int w_mode;          // W_group_mode
+    int meta_dt, zeros_dt;
+    int zero_is_scalar;
+    int splitk;          // K slices (gridDim.y)
+    int rows_per_slice;  // packed rows per K slice
+    int64_t stride_xm, stride_xk, stride_wk, stride_meta_g;
+};
+
+// parameter block of the coverage kernels (generic.hip)
+struct GenericParams {
+    const void* x;
+    const void* w;
+    const void* scales;
+    const void* zeros;
+    Epilogue epi;
+    int M, N, K;
+    int nbits, e, pack_bits;  // e == 1: unpacked
+    int w_dt;                 // dtype of unpacked weights
+    int x_dt;
+    int group_size, w_mode, meta_dt, zeros_dt, zero_is_scalar;
+    int int_acc;              // int8 x integer weights: exact int32 accumulation
+    int64_t stride_xm, stride_xk, stride_wk, stride_wn, stride_meta_g, stride_meta_n;
+};
+
+// host-side launch description produced by the dispatcher
+struct LaunchPlan {
+    const void* fn;
+    const char* name;
+    dim3 grid, block;
+    size_t lds_bytes;
+    uint64_t ws_bytes;    // total workspace needed
+    uint64_t slab_bytes;  // offset of the counters inside the workspace
+};
+
+}  // namespace gl

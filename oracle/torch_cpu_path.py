@@ -1,0 +1,53 @@
+"""CPU BASELINE — TEST / BENCH INFRASTRUCTURE ONLY (kind = "port").
+
+The reference has no CPU forward path (forward_functional always launches Triton, gemlite/core.py:184-190),
+so the CPU baseline BASELINE.md §3 names is the reference's *test oracle* restated with torch CPU ops:
+    unpack along K  (bitpack.py:146-162 unpack_over_cols_torch semantics)
+ -> W = (W_u.float() - zeros) * scales          (tests/test_gemlitelineartriton.py:36-37)
+ -> y = x.float() @ W.T                         (:141)
+run on all host cores (torch.set_num_threads(os.cpu_count())).  Imported only by bench.py's cpu_baseline leg
+and by tests; never by gemlite_amd/.
+"""
+import os
+import time
+
+import torch
+
+
+def unpack_over_k(packed_kn: torch.Tensor, W_nbits: int) -> torch.Tensor:
+    """packed int32 [K/e, N] -> uint8 [N, K]."""
+    e = 32 // W_nbits
+    shifts = torch.arange(e, dtype=torch.int32) * W_nbits
+    q = (packed_kn.t().unsqueeze(-1) >> shifts) & ((1 << W_nbits) - 1)  # [N, K/e, e]
+    return q.reshape(packed_kn.shape[1], -1).to(torch.uint8)
+
+
+def forward_cpu(x: torch.Tensor, packed_kn: torch.Tensor, scales_g: torch.Tensor, zeros_g: torch.Tensor, W_nbits: int,
+                group_size: int) -> torch.Tensor:
+    """x [M,K] (any float), packed [K/e,N] int32, scales/zeros [N*K/group, 1] (the un-laid-out originals)."""
+    N = packed_kn.shape[1]
+    W_u = unpack_over_k(packed_kn, W_nbits)
+    W = ((W_u.reshape(-1, group_size).float() - zeros_g.float()) * scales_g.float()).reshape(N, -1)
+    return x.float() @ W.t()
+
+
+def time_cpu_baseline(M: int, N: int, K: int, W_nbits: int, group_size: int, budget_s: float = 12.0, seed: int = 0):
+    """Bounded timing of the CPU path on all host cores.  Returns (seconds_per_call, calls, threads)."""
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(seed)
+    W_q = torch.randint(0, 2 ** W_nbits, (N, K), generator=g, dtype=torch.int32)
+    e = 32 // W_nbits
+    shifts = torch.arange(e, dtype=torch.int32) * W_nbits
+    packed = (W_q.reshape(N, K // e, e) << shifts).sum(-1).to(torch.int32).t().contiguous()
+    scales = torch.rand(N * K // group_size, 1, generator=g) * 0.01 + 0.001
+    zeros = torch.rand(N * K // group_size, 1, generator=g) * (2 ** W_nbits - 1)
+    x = torch.randn(M, K, generator=g) / 10
+    forward_cpu(x, packed, scales, zeros, W_nbits, group_size)  # warm-up
+    calls, t0 = 0, time.perf_counter()
+    while True:
+        forward_cpu(x, packed, scales, zeros, W_nbits, group_size)
+        calls += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or calls >= 2000:
+            return el / calls, calls, threads

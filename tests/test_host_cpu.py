@@ -1,0 +1,215 @@
+"""CPU-only checks of the host side: pack() mode selection / layout against the reference's golden
+outputs, the C-ABI library (loads, exports every symbol of include/gemlite_hip.h, struct ABI), kernel
+selection, and loud failure without a GPU.  No compute is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import gemlite_amd
+from gemlite_amd import DType, GemLiteLinear, _hip, bitpack
+from gemlite_amd.core import get_closest_m, get_matmul_type
+from tests.golden_util import GOLDEN, as_torch, load_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = load_cases()
+
+
+# ------------------------------------------------------------------------------------------- C ABI
+def test_library_exports_every_header_symbol():
+    lib = _hip.load()
+    header = open(os.path.join(ROOT, "include", "gemlite_hip.h")).read()
+    declared = set(re.findall(r"\b(gemlite_hip_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_hip.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), f"libgemlite_hip.so does not export {name}"
+    assert lib.gemlite_hip_abi_version() == 1
+    assert b"gfx950" in lib.gemlite_hip_build_info()
+
+
+def _args(M=1, N=4096, K=4096, nbits=4, gs=128, in_dt=1, w_mode=4, c_mode=0, e=None, mt=-1, **kw):
+    a = _hip.ForwardArgs()
+    a.struct_size = C.sizeof(_hip.ForwardArgs)
+    a.matmul_type = mt
+    a.x = a.w_q = a.scales = a.zeros = a.out = 0x1000  # never dereferenced by query / planning
+    a.M, a.N, a.K = M, N, K
+    e = 32 // nbits if e is None else e
+    a.W_nbits, a.group_size, a.unpack_mask, a.elements_per_sample = nbits, gs, 2 ** nbits - 1, e
+    a.w_pack_bits, a.w_dtype = (32, 6) if e > 1 else (0, kw.get("w_dtype", in_dt))
+    a.input_dtype = a.output_dtype = a.meta_dtype = a.zeros_dtype = in_dt
+    a.output_dtype = kw.get("out_dt", in_dt if in_dt in (0, 1, 2) else 1)
+    a.channel_scale_mode, a.W_group_mode = c_mode, w_mode
+    a.stride_xm, a.stride_xk = K, 1
+    a.stride_wk, a.stride_wn = (N, 1) if e > 1 else (1, K)
+    a.stride_om, a.stride_on = N, 1
+    a.stride_meta_g, a.stride_meta_n = N, 1
+    return a
+
+
+def test_struct_abi_and_validation():
+    lib = _hip.load()
+    a = _args()
+    assert lib.gemlite_hip_query(C.byref(a)) == 0
+    a.struct_size += 4
+    assert lib.gemlite_hip_query(C.byref(a)) == _hip.ERR_BAD_ARGUMENT
+    a = _args()
+    a.x = None
+    assert lib.gemlite_hip_query(C.byref(a)) == _hip.ERR_BAD_ARGUMENT
+    a = _args(in_dt=12)  # e4m3fnuz: not a gfx950 format
+    assert lib.gemlite_hip_query(C.byref(a)) == _hip.ERR_UNSUPPORTED
+    a = _args(c_mode=4)  # MX block scales
+    assert lib.gemlite_hip_query(C.byref(a)) == _hip.ERR_UNSUPPORTED
+    a = _args(K=4100)
+    assert lib.gemlite_hip_query(C.byref(a)) == _hip.ERR_BAD_SHAPE
+    assert "unsupported" in _hip.status_string(_hip.ERR_UNSUPPORTED)
+    with pytest.raises(NotImplementedError):
+        _hip.raise_for_status(_hip.ERR_UNSUPPORTED, "x")
+    with pytest.raises(_hip.GemliteHipError):
+        _hip.raise_for_status(_hip.ERR_WORKSPACE, "x")
+
+
+@pytest.mark.parametrize("kw,kernel", [
+    (dict(M=1), "gemv_wn_kernel"),
+    (dict(M=1, in_dt=2), "gemv_wn_kernel"),
+    (dict(M=8), "gemv_wn_kernel"),
+    (dict(M=1, nbits=2), "gemv_wn_kernel"),
+    (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel"),
+    (dict(M=16), "gemm_wn_stream_kernel"),
+    (dict(M=1, mt=4), "gemm_wn_stream_kernel"),      # manual GEMM family at M=1 -> an MFMA kernel
+    (dict(M=4, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK
+    (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
+    (dict(M=1, N=1000), "generic_matmul_kernel"),    # N not a multiple of 64
+    (dict(M=1, in_dt=4, w_mode=1, c_mode=1, out_dt=0), "generic_matmul_kernel"),  # int8 x W4
+])
+def test_kernel_selection(kw, kernel):
+    lib = _hip.load()
+    a = _args(**kw)
+    if kw.get("c_mode", 0) in (2, 3):
+        a.scales_x = 0x1000
+    assert lib.gemlite_hip_query(C.byref(a)) == 0
+    assert lib.gemlite_hip_kernel_name(C.byref(a)).decode() == kernel
+
+
+def test_workspace_sizing_cfgA():
+    lib = _hip.load()
+    a = _args(M=1)  # 4096x4096 W4: 64 column tiles x split-K 8 slabs of 64 fp32 + 64 counters
+    assert lib.gemlite_hip_workspace_bytes(C.byref(a)) == 64 * 8 * 64 * 4 + 64 * 4
+    a.tuning[1] = 1  # forced split-K 1: no workspace at all
+    assert lib.gemlite_hip_workspace_bytes(C.byref(a)) == 0
+
+
+# ------------------------------------------------------------------------------ bit packing (host)
+def test_bitpack_cpu_matches_reference_bits():
+    z = np.load(os.path.join(GOLDEN, "bitpack.npz"))
+    for nb in (1, 2, 4, 8):
+        for pb in (8, 16, 32):
+            if f"in_{nb}_{pb}" not in z.files:
+                continue
+            W = torch.from_numpy(z[f"in_{nb}_{pb}"])
+            packed, e = bitpack.pack_weights_over_cols(W, nb, pb, True)
+            assert e == pb // nb
+            ref = torch.from_numpy(z[f"out_{nb}_{pb}"])
+            assert packed.dtype == ref.dtype and torch.equal(packed.contiguous(), ref)
+            back = bitpack.unpack_over_cols(packed.t().contiguous(), nb, W.shape[1])
+            assert torch.equal(back, W)
+    W = torch.randint(0, 4, (8, 64), dtype=torch.uint8)
+    p64, e = bitpack.pack_weights_over_cols(W, 2, 64, False)
+    assert e == 32 and p64.dtype == torch.int64 and torch.equal(bitpack.unpack_over_cols(p64, 2, 64), W)
+    rows, e = bitpack.pack_weights_over_rows(W.t().contiguous(), 2, 32, False)
+    assert torch.equal(bitpack.unpack_over_rows(rows, 2, 64), W.t())
+
+
+# ---------------------------------------------------------------- pack(): modes, layout, meta_args
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_pack_matches_reference(case):
+    cfg = case["cfg"]
+    tdt = cfg["tdt"]
+    nb = cfg["nb"]
+    unpacked = case["meta_args"][4] == 1
+    if unpacked:
+        w_code = 1 if nb == 16 else (4 if cfg["in_dt"] == 4 else 3)
+        W_in = as_torch(case["W_in"], w_code)
+    else:
+        W_in = torch.from_numpy(case["W_in"])
+    sdt = 0 if case["scales_in"].dtype == np.float32 else tdt
+    scales = as_torch(case["scales_in"], sdt) if cfg["scales_kind"] else None
+    zeros = {0: None, 1: (int(case["zeros_in"][0]) if cfg["zeros_kind"] == 1 else None),
+             2: as_torch(case["zeros_in"], tdt)}[cfg["zeros_kind"]]
+    lin = GemLiteLinear(nb, None if cfg["gs"] < 0 else cfg["gs"], cfg["K"], cfg["N"], DType(cfg["in_dt"]),
+                        DType(cfg["out_dt"]), scaled_activations=bool(cfg["scaled_act"]))
+    lin.pack(W_in, scales, zeros, None, fma_mode=bool(cfg["fma"]), packing_bitwidth=None if cfg["pb"] < 0 else cfg["pb"])
+    if case["name"] == "a8w4_int8_dyn_intzero":
+        lin.meta_dtype = DType.FP32  # the golden generator applied the reference test's override
+    assert lin.get_meta_args() == case["meta_args"]
+    assert tuple(lin.W_q.shape) == case["W_q"].shape and list(lin.W_q.stride()) == list(case["W_q_stride"])
+    w_ref = as_torch(case["W_q"], TORCH_DT_CODE(lin.W_q.dtype))
+    assert torch.equal(lin.W_q.data.contiguous().view(torch.uint8), w_ref.contiguous().view(torch.uint8))
+    for name in ("scales", "zeros"):
+        mine, ref = getattr(lin, name).data, case[name]
+        assert tuple(mine.shape) == ref.shape, name
+        if ref.size:
+            ref_t = as_torch(ref, TORCH_DT_CODE(mine.dtype))
+            assert mine.dtype == ref_t.dtype, name
+            assert torch.equal(mine.reshape(-1).view(torch.uint8), ref_t.reshape(-1).view(torch.uint8)), name
+    sd = lin.state_dict()
+    assert set(sd) >= {"W_q", "scales", "zeros", "metadata", "orig_shape"}
+    lin2 = GemLiteLinear()
+    lin2.load_state_dict(dict(sd))
+    if case["name"] != "a8w4_int8_dyn_intzero":  # attribute overridden after pack(): saved metadata is older
+        assert lin2.get_meta_args() == lin.get_meta_args()
+    assert all(torch.equal(a.contiguous().reshape(-1).view(torch.uint8), b.contiguous().reshape(-1).view(torch.uint8))
+               for a, b in zip(lin2.get_tensor_args(), lin.get_tensor_args()) if a.numel())
+
+
+def TORCH_DT_CODE(dt):
+    return gemlite_amd.dtypes.TORCH_TO_DTYPE[dt].value
+
+
+def test_constructor_and_pack_errors():
+    with pytest.raises(NotImplementedError):
+        GemLiteLinear(3, 64, 128, 128)
+    with pytest.raises(NotImplementedError):
+        GemLiteLinear(4, 64, 100, 128)
+    with pytest.raises(NotImplementedError):
+        GemLiteLinear(4, 8, 128, 128)
+    lin = GemLiteLinear(4, 64, 128, 64, DType.INT8, DType.FP32)
+    with pytest.raises(Exception, match="INT8"):
+        lin.pack(torch.zeros(64, 128, dtype=torch.uint8), torch.ones(64, 1), torch.full((64, 1), 0.5))
+    lin = GemLiteLinear(4, 64, 128, 64)
+    with pytest.raises(Exception, match="not packed"):
+        lin.pack(torch.zeros(64, 128, dtype=torch.int32), None, None)
+
+
+def test_forward_on_cpu_fails_loudly():
+    """No silent fallback: CPU tensors are refused by the product path."""
+    lin = GemLiteLinear(4, 64, 128, 64)
+    lin.pack(torch.randint(0, 16, (64, 128), dtype=torch.uint8), torch.rand(128, 1).half(), torch.rand(128, 1).half())
+    with pytest.raises(_hip.GemliteHipError, match="no CPU fallback"):
+        lin(torch.randn(1, 128).half())
+
+
+def test_dispatch_thresholds_and_m_buckets():
+    assert [get_matmul_type(m, 4) for m in (1, 2, 64, 65)] == ["GEMV_REVSPLITK", "GEMM_SPLITK", "GEMM_SPLITK", "GEMM"]
+    assert get_matmul_type(1, 8) == "GEMV_SPLITK"
+    buckets = [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]
+    assert sorted({get_closest_m(m) for m in range(1, 5000)}) == buckets
+    assert get_closest_m(17) == 24 and get_closest_m(5000) == 4096
+
+
+def test_config_shims(tmp_path):
+    gemlite_amd.reset_config()
+    gemlite_amd.set_autotune(False)
+    assert gemlite_amd.core.AUTOTUNE.GEMM == "default"
+    gemlite_amd.set_autotune("max", use_cuda_graph=True)
+    assert gemlite_amd.core.AUTOTUNE.GEMV == "max" and gemlite_amd.core.AUTOTUNE.USE_CUDA_GRAPH
+    f = tmp_path / "cfg.json"
+    gemlite_amd.core.GEMLITE_HIP_CONFIG_CACHE["GEMM"] = {"(256, 4096, 4096, 128, 8, 104)": {"splitk": 2}}
+    gemlite_amd.cache_config(str(f))
+    gemlite_amd.reset_config()
+    assert gemlite_amd.load_config(str(f)) and "GEMM" in gemlite_amd.core.GEMLITE_HIP_CONFIG_CACHE
+    assert gemlite_amd.load_config(str(tmp_path / "missing.json"), print_error=False) is False
+    gemlite_amd.set_autotune("fast", use_cuda_graph=False)

@@ -113,3 +113,44 @@ def test_act_quant_matches_reference():
             q, s = O.scale_activations_per_token(torch.from_numpy(x), code)
             assert np.array_equal(s.astype(np.float32), s_ref.astype(np.float32)), tag
             assert np.array_equal(q, q_ref.astype(np.float64)), tag
+
+
+def test_c_oracle_matches_numpy_oracle():
+    """The plain-C restatement (oracle/oracle.c) agrees with the numpy oracle on every packed golden case."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "_build", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True)
+    lib = ctypes.CDLL(so)
+    fp, ip, dp = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)
+    lib.oracle_forward_packed.restype = ctypes.c_int
+    lib.oracle_forward_packed.argtypes = [fp, ip, fp, fp, fp, fp, dp] + [ctypes.c_int64] * 3 + [ctypes.c_int] * 6
+    n_checked = 0
+    for case in CASES:
+        meta, cfg = case["meta_args"], case["cfg"]
+        (_sa, nb, gs, _mask, e, in_dt, out_dt, _acc, meta_dt, csm, wgm, _c) = meta
+        if e == 1 or cfg["scaled_act"] or case["W_q"].dtype != np.int32:
+            continue
+        M = sorted(case["x"])[0]
+        x = O.to_f64(as_torch(case["x"][M], in_dt)).astype(np.float32)
+        s = O.to_f64(as_torch(case["scales"], meta_dt)).astype(np.float32) if case["scales"].size else np.zeros(1, np.float32)
+        zk = cfg["zeros_kind"]
+        z = (O.to_f64(as_torch(case["zeros"], meta_dt)) if zk == 2 else case["zeros"].astype(np.float64).reshape(-1)
+             if zk == 1 else np.zeros(1)).astype(np.float32)
+        K, N = cfg["K"], cfg["N"]
+        y = np.zeros((M, N), np.float64)
+        w = np.ascontiguousarray(case["W_q"])
+        eff_gs = gs if (wgm >= 2 or (wgm == 1 and zk == 2 and csm not in (1, 3))) else K
+        rc = lib.oracle_forward_packed(x.ctypes.data_as(fp), w.ctypes.data_as(ip), np.ascontiguousarray(s).ctypes.data_as(fp),
+                                       np.ascontiguousarray(z).ctypes.data_as(fp),
+                                       np.ascontiguousarray(s.reshape(-1)).ctypes.data_as(fp), None, y.ctypes.data_as(dp),
+                                       M, N, K, nb, 32, eff_gs, wgm, csm, int(zk == 1))
+        assert rc == 0
+        y_np = O.forward_packed(x.astype(np.float64), case["W_q"], O.to_f64(as_torch(case["scales"], meta_dt)) if case["scales"].size else None,
+                                z.astype(np.float64) if zk else None, W_nbits=nb, group_size=gs, W_group_mode=wgm,
+                                channel_scale_mode=csm, zero_is_scalar=(zk == 1))
+        assert np.allclose(y, y_np, rtol=1e-9, atol=1e-12), case["name"]
+        n_checked += 1
+    assert n_checked >= 8
