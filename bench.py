@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-samples", type=int, default=256, help="launches timed individually for roofline")
+    ap.add_argument("--tuning", default="", help="development: comma-separated tuning[] override, e.g. 4,8")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +123,10 @@ def main():
 
     from gemlite_amd import _hip
     lib = _hip.load()  # fails loudly if the HIP library is missing
+    if args.tuning:
+        import gemlite_amd.core as _core
+        t = [int(v) for v in args.tuning.split(",")]
+        _core.TUNING_OVERRIDE = tuple(t + [0] * (4 - len(t)))
 
     N, K, nbits, group, M, dt, layers, bound = WORKLOADS[args.workload]
     mods, x = build_layers(args.workload, device)
@@ -191,7 +196,7 @@ def main():
             kernel_us = float(durs.mean())
         from gemlite_amd.core import _static_args
         a0 = _static_args(mods[0].W_q, mods[0].scales, mods[0].zeros, mods[0].get_meta_args())
-        kernel_name = lib.gemlite_hip_kernel_name(ctypes.byref(a0)).decode()
+        kernel_name = lib.gemlite_hip_kernel_name(ctypes.byref(a0)).decode()  # a0 still holds the last launch's args
     except Exception as e:  # keep the bench line even if the event path is unavailable
         print(f"[bench] per-kernel event timing unavailable: {e}", file=sys.stderr)
 

@@ -110,6 +110,7 @@ def get_matmul_type(batch_size: int, W_nbits: int, mx_dtype: bool = False) -> st
 _META_FIELDS = ("scaled_activations", "W_nbits", "group_size", "unpack_mask", "elements_per_sample", "input_dtype",
                 "output_dtype", "acc_dtype", "meta_dtype", "channel_scale_mode", "W_group_mode", "data_contiguous")
 _ARGS_CACHE: dict = {}
+TUNING_OVERRIDE = None  # development hook: 4 ints forwarded as gemlite_hip_forward_args.tuning (0 = library default)
 
 
 def _static_args(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> _hip.ForwardArgs:
@@ -172,6 +173,8 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
         a.scales_x, a.stride_sx_m = scales_x.data_ptr(), scales_x.stride(0)
     else:
         a.scales_x, a.stride_sx_m = None, 0
+    if tuning is None:
+        tuning = TUNING_OVERRIDE
     for i in range(4):
         a.tuning[i] = 0 if tuning is None else int(tuning[i])
     stream = _hip.current_stream_handle(x.device)

@@ -121,19 +121,15 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         const int mt = a.matmul_type;
         const bool want_gemv = (mt == GEMLITE_MATMUL_GEMV || mt == GEMLITE_MATMUL_GEMV_REVSPLITK ||
                                 mt == GEMLITE_MATMUL_GEMV_SPLITK || (mt == GEMLITE_MATMUL_AUTO && a.M <= 8));
-        const bool meta_ok_f16 = a.input_dtype != GEMLITE_DT_FP16 || a.W_group_mode == 0 ||
-                                 ((a.W_group_mode < 2 || a.meta_dtype == GEMLITE_DT_FP16) &&
-                                  (!(a.W_group_mode == 1 || a.W_group_mode >= 3) || a.zero_is_scalar ||
-                                   a.zeros_dtype == GEMLITE_DT_FP16));
         LaunchPlan lp{};
         if (want_gemv && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }
-        if (!want_gemv && meta_ok_f16) {
+        if (!want_gemv) {
             const bool want_tiled = (mt == GEMLITE_MATMUL_GEMM || (mt == GEMLITE_MATMUL_AUTO && a.M > 64));
             if (want_tiled && a.tuning[0] != 1 && plan_gemm_wn_tiled(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
             if (plan_gemm_wn_stream(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
         }
         // AUTO with small M that the GEMV planner rejected may still fit the streaming kernel
-        if (want_gemv && mt == GEMLITE_MATMUL_AUTO && meta_ok_f16 && plan_gemm_wn_stream(a, p, lp)) {
+        if (want_gemv && mt == GEMLITE_MATMUL_AUTO && plan_gemm_wn_stream(a, p, lp)) {
             r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return;
         }
     }
@@ -259,8 +255,8 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
     if (r.kind == K_GEMV_WN || r.kind == K_STREAM_WN || r.kind == K_TILED_WN) {
         if (r.lp.ws_bytes > 0) {
             if (!args->workspace || args->workspace_bytes < r.lp.ws_bytes) return GEMLITE_ERR_WORKSPACE;
-            r.wn.slabs = (float*)args->workspace;
-            r.wn.counters = (unsigned*)((char*)args->workspace + r.lp.slab_bytes);
+            r.wn.counters = (unsigned*)args->workspace;
+            r.wn.slabs = (float*)((char*)args->workspace + COUNTER_BYTES);
         }
         const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes);
         if (e != GEMLITE_OK) return e;

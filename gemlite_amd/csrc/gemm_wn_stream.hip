@@ -173,10 +173,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wn_stream_kernel(const WnParams p
             if (grp != cur_grp) {
                 cur_grp = grp;
                 f32x4 s = {1.f, 1.f, 1.f, 1.f}, z = {0.f, 0.f, 0.f, 0.f};
-                if (p.w_mode >= 2) s = load_meta4(p.scales, grp * p.stride_meta_g + n0, p.meta_dt);
+                if (p.w_mode >= 2) s = load4_t<Tag>(p.scales, grp * p.stride_meta_g + n0);
                 if (p.w_mode == 1 || p.w_mode >= 3) {
                     if (p.zero_is_scalar) z[0] = z[1] = z[2] = z[3] = (float)scalar_zero;
-                    else z = load_meta4(p.zeros, grp * p.stride_meta_g + n0, p.zeros_dt);
+                    else z = load4_t<Tag>(p.zeros, grp * p.stride_meta_g + n0);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dq[j].set(s[j], z[j], p.w_mode);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wn_stream_kernel(const WnParams p
 #pragma unroll
         for (int it = 0; it < OPT; ++it) {
             const int o = tid + it * 256, m = m0 + (o >> 6);
-            if (m < p.M) epilogue_store(p.epi, part[it], m, (int64_t)tile * 64 + (o & 63));
+            if (m < p.M) store_out_t<Tag>(p.epi, part[it], m, (int64_t)tile * 64 + (o & 63));
         }
         return;
     }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wn_stream_kernel(const WnParams p
         const int o = tid + it * 256, m = m0 + (o >> 6);
         float v = 0.f;
         for (int s = 0; s < p.splitk; ++s) v += slab_load(slab + (int64_t)s * NOUT + o);
-        if (m < p.M) epilogue_store(p.epi, v, m, (int64_t)tile * 64 + (o & 63));
+        if (m < p.M) store_out_t<Tag>(p.epi, v, m, (int64_t)tile * 64 + (o & 63));
     }
     if (tid == 0) splitk_reset(p.counters + tile_lin);
 }
@@ -287,6 +287,12 @@ bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     const int e = 32 / nbits;
     if (a.N % 64 != 0 || a.K % PIECE_K != 0) return false;
     if (p.group_size % e != 0) return false;
+    if (a.output_dtype != a.input_dtype) return false;  // typed epilogue / metadata
+    const bool uses_s = a.W_group_mode >= 2 || a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
+    if (uses_s && a.meta_dtype != a.input_dtype) return false;
+    if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
+    if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
     const int rows = (int)(a.K / e);
     const int piece_rows = PIECE_K / e;
     const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
@@ -311,7 +317,8 @@ bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     lp.lds_bytes = (xs_b > red_b ? xs_b : red_b) + 16;
     const uint64_t ntl = (uint64_t)tiles * mtiles;
     lp.slab_bytes = splitk > 1 ? ntl * splitk * bm * 64 * 4 : 0;
-    lp.ws_bytes = lp.slab_bytes + (splitk > 1 ? ntl * 4 : 0);
+    if (splitk > 1 && ntl > (uint64_t)MAX_SPLITK_COUNTERS) return false;
+    lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
     return true;
 }
 

@@ -4,80 +4,113 @@
 // (gemlite/triton_kernels/gemv_revsplitK_kernels.py:226-462, gemv_kernels.py:230-388,
 // gemv_splitK_kernels.py:240-420) for packed int32 weights.  HBM-bound: the only large stream is W_q.
 //
-// Mapping (CDNA4, 64-wide waves, block = 4 waves):
-//   * a block owns a 64-column tile and one K slice (gridDim.y slices, combined in-launch);
-//   * lane = (g = lane>>4, c = lane&15): it owns the 4 adjacent columns 4c..4c+3 (one 16-byte
-//     global_load_dwordx4 per packed row) and packed rows  wave_base + chunk*4R + R*g + i, i < R (R=4).
-//     One wave-level load instruction therefore reads 4 row segments of 256 contiguous bytes;
-//     a lane's 4 rows are consecutive, so for group_size 128 they share one (scale, zero) pair;
-//   * weights go HBM -> VGPR directly (no LDS round trip: every byte is used by exactly one lane);
-//     the K slice of x (<= 8 KB per row) is staged in LDS once, pair-permuted so one 32-bit LDS
-//     word is exactly the (k, k + e/2) pair that one AND/OR "magic number" unpack produces;
-//   * math: inside one quantisation group  sum_k x_k (a q_k + b) = a * sum_k x_k q_k + b * sum_k x_k,
-//     so the inner loop is  AND/OR -> v_dot2(c)_f32_{f16,bf16}  on (OFF + q) pairs with fp32
-//     accumulation; the OFF * sum(x) term is removed once per run of rows;
-//   * reduction: 2 ds_bpermute/DPP xor-shuffles across the 4 row sub-groups of a wave, LDS across
-//     the 4 waves, then split-K slabs: write-through (sc1) stores + arrival ticket, last block
-//     sums the slabs in fixed slice order (deterministic), applies the epilogue and stores.
+// Mapping (CDNA4, 64-wide waves, block = 4 waves).  A lane owns 4 adjacent columns (one 16-byte
+// global_load_dwordx4 per packed row = 4 columns x e k-values) and R consecutive packed rows per step:
+//     lane = (g = lane >> CQ, c = lane & (2^CQ - 1));  columns 4c..4c+3 of the tile;
+//     rows  wave_base + step*G*R + g*R + i,  i < R,  G = 64 >> CQ row sub-groups per wave.
+//   CQ = 2  ("narrow"): 16-column tiles (64-byte row segments), 16 row sub-groups per wave.  N/16 tiles fill
+//           the chip without splitting K (4096 columns -> 256 blocks): no cross-block reduction at all.
+//           Tiles 2p, 2p+1 (the two halves of one 128-byte line) are mapped to the same XCD (block b runs on
+//           XCD b % 8) so the line is fetched into one L2 only.
+//   CQ = 4  ("wide"): 64-column tiles (256-byte row segments), 4 row sub-groups; used when N/16 is too small or
+//           K too large for the LDS copy of x; K is then split over gridDim.y and combined in-launch.
+//   * weights go HBM -> VGPR directly (no LDS round trip: every byte is used by exactly one lane); loads for
+//     the next step are issued before the current one is consumed (two register sets);
+//   * x[k-slice] is staged in LDS once, "pair-permuted": one 32-bit LDS word is exactly the (k, k + e/2)
+//     pair that one AND/OR magic-number unpack of a packed word produces (x is loaded before W is issued so
+//     that its latency is not queued behind the weight stream);
+//   * math: inside one quantisation group  sum_k x_k (a q_k + b) = a * sum_k x_k q_k + b * sum_k x_k, so the
+//     inner loop is  shift -> AND/OR -> v_dot2c_f32_{f16,bf16}  on (OFF + q) pairs, fp32 accumulation; the
+//     OFF * sum(x) term is removed once per run of R rows; (a, b) per W_group_mode from group_affine();
+//   * reduction: xor-shuffles (ds_bpermute/DPP) over the row sub-groups of a wave, LDS over the 4 waves, and —
+//     only if K was split — write-through (sc1) slabs + an arrival ticket; the last block adds the slabs in
+//     fixed slice order (run-to-run deterministic), applies the epilogue and stores.
 #include "gl_common.h"
 
 namespace gl {
 
-template <typename Tag, int NBITS, int MB, int R>
-__global__ __launch_bounds__(256, (MB * (16 / NBITS) >= 32 ? 1 : 2)) void gemv_wn_kernel(const WnParams p) {
+template <typename Tag, int NBITS, int MB, int R, int CQ>
+__global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1 : 2)) void gemv_wn_kernel(const WnParams p) {
     using TR = F16Traits<Tag>;
     constexpr int E = 32 / NBITS;    // elements per packed word
     constexpr int HALF = E / 2;      // (k, k+HALF) pairs per word == LDS dwords per packed row
     constexpr uint32_t QMASK2 = ((1u << NBITS) - 1u) * 0x00010001u;
-    constexpr int CHUNK = 4 * R;     // packed rows one wave consumes per iteration (4 sub-groups x R)
+    constexpr int G = 64 >> CQ;      // row sub-groups per wave
+    constexpr int CHUNK = G * R;     // packed rows one wave consumes per step
+    constexpr int TC = 4 << CQ;      // tile columns
     static_assert(NBITS <= TR::MAX_QBITS, "q + OFF must be exact in the 16-bit float type");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x, slice = blockIdx.y;
-    const int n0 = tile * 64 + c * 4;
+    const int c = lane & ((1 << CQ) - 1), g = lane >> CQ;
+    int tile = blockIdx.x;
+    if constexpr (CQ == 2) {  // adjacent half-line tiles on one XCD (speed only; any mapping is correct)
+        const int nb = gridDim.x;
+        if ((nb & 15) == 0) {
+            const int xcd = tile & 7, idx = tile >> 3;
+            tile = (((idx >> 1) << 3) + xcd) * 2 + (idx & 1);
+        }
+    }
+    const int slice = blockIdx.y;
+    const int n0 = tile * TC + c * 4;
 
-    const int rows_slice = p.rows_per_slice;          // multiple of 4*CHUNK (= 16*R)
+    const int rows_slice = p.rows_per_slice;          // multiple of 4*CHUNK
     const int rows_wave = rows_slice >> 2;            // each wave takes a contiguous quarter
     const int row_s0 = slice * rows_slice;            // first packed row of the slice
     const int row_w0 = wave * rows_wave;              // wave start, relative to the slice
     const int pairs = rows_slice * HALF;              // LDS dwords per x row
 
     uint32_t* xs = (uint32_t*)smem;                               // [MB][pairs]
-    float* red = (float*)(smem + (size_t)MB * pairs * 4);          // [4][MB][64]
-    unsigned* flag = (unsigned*)(red + 4 * MB * 64);
+    float* red = (float*)(smem + (size_t)MB * pairs * 4);          // [4][MB][TC]
+    unsigned* flag = (unsigned*)(red + 4 * MB * TC);
+
+    // ---- x[k-slice]: global -> registers (pair-permuted), issued AHEAD of the weight stream ---------------
+    constexpr int XPT = 4;  // LDS dwords staged per thread per pass
+    const uint16_t* xg = (const uint16_t*)p.x;
+    const int64_t k0 = (int64_t)row_s0 * E;
+    const int xtotal = MB * pairs;
+    const int npass = (xtotal + 256 * XPT - 1) / (256 * XPT);
+    auto fetch_x = [&](uint32_t (&v)[XPT], int pass) {
+#pragma unroll
+        for (int t = 0; t < XPT; ++t) {
+            const int idx = (pass * XPT + t) * 256 + tid;
+            v[t] = 0;
+            if (idx < xtotal) {
+                const int m = idx / pairs, pi = idx - m * pairs;
+                const int word = pi / HALF, d = pi - word * HALF;
+                if (m < p.M) {
+                    const int64_t k = k0 + (int64_t)word * E + d;
+                    v[t] = (uint32_t)xg[m * p.stride_xm + k] | ((uint32_t)xg[m * p.stride_xm + k + HALF] << 16);
+                }
+            }
+        }
+    };
+    auto put_x = [&](const uint32_t (&v)[XPT], int pass) {
+#pragma unroll
+        for (int t = 0; t < XPT; ++t) {
+            const int idx = (pass * XPT + t) * 256 + tid;
+            if (idx < xtotal) xs[idx] = v[t];
+        }
+    };
 
     const uint32_t* wbase = p.w + (int64_t)(row_s0 + row_w0 + g * R) * p.stride_wk + n0;
     const int nchunks = rows_wave / CHUNK;
-
     u32x4 wa[R], wb[R];
     auto load_w = [&](u32x4 (&dst)[R], int chunk) {
 #pragma unroll
         for (int i = 0; i < R; ++i)
             dst[i] = *(const u32x4*)(wbase + (int64_t)(chunk * CHUNK + i) * p.stride_wk);
     };
-    // issue the first weight loads before anything else: they are the long pole
-    load_w(wa, 0);
-    if (nchunks > 1) load_w(wb, 1);
 
-    // ---- stage x[k-slice] into LDS, pair-permuted -------------------------------------------
     {
-        const uint16_t* xg = (const uint16_t*)p.x;
-        const int64_t k0 = (int64_t)row_s0 * E;
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            for (int pi = tid; pi < pairs; pi += 256) {
-                const int word = pi / HALF, d = pi - word * HALF;
-                uint32_t v = 0;
-                if (m < p.M) {
-                    const int64_t k = k0 + (int64_t)word * E + d;
-                    const uint32_t lo = xg[m * p.stride_xm + k * p.stride_xk];
-                    const uint32_t hi = xg[m * p.stride_xm + (k + HALF) * p.stride_xk];
-                    v = lo | (hi << 16);
-                }
-                xs[m * pairs + pi] = v;
-            }
+        uint32_t xv[XPT];
+        fetch_x(xv, 0);
+        load_w(wa, 0);
+        if (nchunks > 1) load_w(wb, 1);
+        put_x(xv, 0);
+        for (int pass = 1; pass < npass; ++pass) {  // large K * MB only
+            fetch_x(xv, pass);
+            put_x(xv, pass);
         }
     }
     __syncthreads();
@@ -88,26 +121,20 @@ __global__ __launch_bounds__(256, (MB * (16 / NBITS) >= 32 ? 1 : 2)) void gemv_w
 #pragma unroll
         for (int j = 0; j < 4; ++j) tot[m][j] = 0.f;
 
-    const int scalar_zero = p.zero_is_scalar ? ((const int32_t*)p.zeros)[0] : 0;
+    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
+    const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
+    // (a, b) of group_affine() without per-column branches: a = s (s == 1 when unused),
+    // b = bz * z * (mode 3 ? s : 1) with bz = -1 (modes 1, 3), +1 (mode 4), 0 otherwise
+    const float bz = (p.w_mode == 1 || p.w_mode == 3) ? -1.f : (p.w_mode == 4 ? 1.f : 0.f);
+    const bool b_times_s = p.w_mode == 3;
 
     auto compute = [&](const u32x4 (&wv)[R], int chunk) {
         const int row_rel = row_w0 + chunk * CHUNK + g * R;  // first of this lane's R rows (slice-relative)
         // metadata of the (single) group these R rows live in
-        float a[4], b[4];
-        {
-            const int64_t grp = ((int64_t)(row_s0 + row_rel) * E) / p.group_size;
-            f32x4 s = {1.f, 1.f, 1.f, 1.f}, z = {0.f, 0.f, 0.f, 0.f};
-            if (p.w_mode >= 2) s = load_meta4(p.scales, grp * p.stride_meta_g + n0, p.meta_dt);
-            if (p.w_mode == 1 || p.w_mode >= 3) {
-                if (p.zero_is_scalar) {
-                    z[0] = z[1] = z[2] = z[3] = (float)scalar_zero;
-                } else {
-                    z = load_meta4(p.zeros, grp * p.stride_meta_g + n0, p.zeros_dt);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) group_affine(s[j], z[j], p.w_mode, a[j], b[j]);
-        }
+        const int64_t grp = ((int64_t)(row_s0 + row_rel) * E) / p.group_size;
+        f32x4 s = {1.f, 1.f, 1.f, 1.f}, z = {scalar_zero, scalar_zero, scalar_zero, scalar_zero};
+        if (need_s) s = load4_t<Tag>(p.scales, grp * p.stride_meta_g + n0);
+        if (need_z) z = load4_t<Tag>(p.zeros, grp * p.stride_meta_g + n0);
         float acc[MB][4], accx[MB];
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
@@ -148,10 +175,12 @@ __global__ __launch_bounds__(256, (MB * (16 / NBITS) >= 32 ? 1 : 2)) void gemv_w
             }
         }
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const float a = s[j];
+            const float b = bz * z[j] * (b_times_s ? s[j] : 1.f);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                tot[m][j] += a[j] * (acc[m][j] - TR::OFF * accx[m]) + b[j] * accx[m];
+            for (int m = 0; m < MB; ++m) tot[m][j] += a * (acc[m][j] - TR::OFF * accx[m]) + b * accx[m];
+        }
     };
 
     for (int ch = 0; ch < nchunks; ch += 2) {
@@ -163,27 +192,27 @@ __global__ __launch_bounds__(256, (MB * (16 / NBITS) >= 32 ? 1 : 2)) void gemv_w
         }
     }
 
-    // ---- reduce over the 4 row sub-groups of the wave (lanes l, l^16, l^32, l^48) --------------
+    // ---- reduce over the G row sub-groups of the wave (lane bits CQ..5) --------------------------------
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v = tot[m][j];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+#pragma unroll
+            for (int off = 1 << CQ; off < 64; off <<= 1) v += __shfl_xor(v, off);
             tot[m][j] = v;
         }
     if (g == 0) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            f32x4 v = {tot[m][0], tot[m][1], tot[m][2], tot[m][3]};
-            *(f32x4*)(red + (wave * MB + m) * 64 + c * 4) = v;
+            const f32x4 v = {tot[m][0], tot[m][1], tot[m][2], tot[m][3]};
+            *(f32x4*)(red + (wave * MB + m) * TC + c * 4) = v;
         }
     }
     __syncthreads();
 
-    // ---- across the 4 waves; output o = m*64 + col, o < MB*64, strided over the 256 threads ----
-    constexpr int NOUT = MB * 64;
+    // ---- across the 4 waves; output o = m*TC + col, o < MB*TC, strided over the 256 threads ------------
+    constexpr int NOUT = MB * TC;
     constexpr int OPT = (NOUT + 255) / 256;  // outputs per thread
     float part[OPT];
 #pragma unroll
@@ -191,9 +220,9 @@ __global__ __launch_bounds__(256, (MB * (16 / NBITS) >= 32 ? 1 : 2)) void gemv_w
         const int o = tid + it * 256;
         float v = 0.f;
         if (o < NOUT) {
-            const int m = o >> 6, col = o & 63;
+            const int m = o / TC, col = o % TC;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[(w * MB + m) * 64 + col];
+            for (int w = 0; w < 4; ++w) v += red[(w * MB + m) * TC + col];
         }
         part[it] = v;
     }
@@ -201,7 +230,7 @@ __global__ __launch_bounds__(256, (MB * (16 / NBITS) >= 32 ? 1 : 2)) void gemv_w
 #pragma unroll
         for (int it = 0; it < OPT; ++it) {
             const int o = tid + it * 256;
-            if (o < NOUT && (o >> 6) < p.M) epilogue_store(p.epi, part[it], o >> 6, (int64_t)tile * 64 + (o & 63));
+            if (o < NOUT && (o / TC) < p.M) store_out_t<Tag>(p.epi, part[it], o / TC, (int64_t)tile * TC + (o % TC));
         }
         return;
     }
@@ -218,7 +247,7 @@ __global__ __launch_bounds__(256, (MB * (16 / NBITS) >= 32 ? 1 : 2)) void gemv_w
         if (o < NOUT) {
             float v = 0.f;
             for (int s = 0; s < p.splitk; ++s) v += slab_load(slab + (int64_t)s * NOUT + o);
-            if ((o >> 6) < p.M) epilogue_store(p.epi, v, o >> 6, (int64_t)tile * 64 + (o & 63));
+            if ((o / TC) < p.M) store_out_t<Tag>(p.epi, v, o / TC, (int64_t)tile * TC + (o % TC));
         }
     }
     if (tid == 0) splitk_reset(p.counters + tile);
@@ -228,71 +257,109 @@ __global__ __launch_bounds__(256, (MB * (16 / NBITS) >= 32 ? 1 : 2)) void gemv_w
 // host-side planning
 // ---------------------------------------------------------------------------------------------
 template <typename Tag, int NBITS, int MB>
-static const void* pick_r(int r) {
-    return r == 4 ? (const void*)gemv_wn_kernel<Tag, NBITS, MB, 4> : (const void*)gemv_wn_kernel<Tag, NBITS, MB, 1>;
+static const void* pick_shape(int cq, int r) {
+    if (cq == 2) {
+        if constexpr (NBITS == 4 || NBITS == 2) {
+            if (r == 8) return (const void*)gemv_wn_kernel<Tag, NBITS, MB, 8, 2>;
+            if (r == 2) return (const void*)gemv_wn_kernel<Tag, NBITS, MB, 2, 2>;
+        }
+        return nullptr;
+    }
+    if (r == 4) return (const void*)gemv_wn_kernel<Tag, NBITS, MB, 4, 4>;
+    if (r == 1) return (const void*)gemv_wn_kernel<Tag, NBITS, MB, 1, 4>;
+    return nullptr;
 }
 template <typename Tag, int NBITS>
-static const void* pick_mb(int mb, int r) {
+static const void* pick_mb(int mb, int cq, int r) {
     switch (mb) {
-        case 1: return pick_r<Tag, NBITS, 1>(r);
-        case 2: return pick_r<Tag, NBITS, 2>(r);
-        case 4: return pick_r<Tag, NBITS, 4>(r);
-        default: return pick_r<Tag, NBITS, 8>(r);
+        case 1: return pick_shape<Tag, NBITS, 1>(cq, r);
+        case 2: return pick_shape<Tag, NBITS, 2>(cq, r);
+        case 4: return pick_shape<Tag, NBITS, 4>(cq, r);
+        default: return pick_shape<Tag, NBITS, 8>(cq, r);
     }
 }
 template <typename Tag>
-static const void* pick_bits(int nbits, int mb, int r) {
+static const void* pick_bits(int nbits, int mb, int cq, int r) {
     switch (nbits) {
-        case 1: return pick_mb<Tag, 1>(mb, r);
-        case 2: return pick_mb<Tag, 2>(mb, r);
-        case 4: return pick_mb<Tag, 4>(mb, r);
+        case 1: return pick_mb<Tag, 1>(mb, cq, r);
+        case 2: return pick_mb<Tag, 2>(mb, cq, r);
+        case 4: return pick_mb<Tag, 4>(mb, cq, r);
         case 8:
-            if constexpr (F16Traits<Tag>::MAX_QBITS >= 8) return pick_mb<Tag, 8>(mb, r);
+            if constexpr (F16Traits<Tag>::MAX_QBITS >= 8) return pick_mb<Tag, 8>(mb, cq, r);
             return nullptr;
         default: return nullptr;
     }
 }
 
-// Decide grid / split-K / LDS for the GEMV kernel.  Returns false if this shape is not covered.
+// Decide variant / grid / split-K / LDS for the GEMV kernel.  Returns false if this shape is not covered.
+// tuning[0]: 0 auto | 2 force narrow (16-column tiles) | 4 force wide (64-column tiles); tuning[1]: split-K.
 bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
-    const int nbits = a.W_nbits, e = 32 / nbits;
-    if (a.M > 8 || a.N % 64 != 0 || a.K % e != 0) return false;
+    const int nbits = a.W_nbits;
+    if (nbits != 1 && nbits != 2 && nbits != 4 && nbits != 8) return false;
+    const int e = 32 / nbits;
+    if (a.M > 8 || a.K % e != 0) return false;
+    if (a.output_dtype != a.input_dtype) return false;  // typed epilogue
+    const bool uses_s = a.W_group_mode >= 2 || a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
+    if (uses_s && a.meta_dtype != a.input_dtype) return false;
+    if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
+    if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
     const int rows = (int)(a.K / e);
     const int64_t gs = p.group_size;
     if (gs % e != 0) return false;
     const int rpg = (int)(gs / e);  // packed rows per group
-    // rows a lane consumes per chunk must stay inside one group
-    const int r = (rpg % 4 == 0 && rows % 64 == 0) ? 4 : 1;
-    const int chunk_rows = 16 * r;  // 4 waves * 4 sub-groups * r packed rows per block iteration
-    if (rows % chunk_rows != 0) return false;
     const int mb = a.M <= 1 ? 1 : (a.M <= 2 ? 2 : (a.M <= 4 ? 4 : 8));
-    const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, r)
-                                                       : pick_bits<bf16_tag>(nbits, mb, r);
-    if (!fn) return false;
+    const int64_t x_bytes_full = (int64_t)mb * a.K * 2;
 
-    // split K so that (a) >= ~2 blocks per CU exist, (b) the x slice fits LDS comfortably
-    const int tiles = (int)(a.N / 64);
-    const int units = rows / chunk_rows;  // max number of slices
-    int splitk = a.tuning[1] > 0 ? a.tuning[1] : 1;
-    if (a.tuning[1] <= 0) {
-        const int target_blocks = 512;
-        while (splitk < units && tiles * splitk < target_blocks && (units % (splitk * 2) == 0)) splitk *= 2;
-    }
-    if (units % splitk != 0) return false;
-    // LDS cap: MB * k_slice * 2 bytes <= 64 KiB
-    while (((int64_t)mb * (rows / splitk) * e * 2 > 65536) && (units % (splitk * 2) == 0)) splitk *= 2;
-    if ((int64_t)mb * (rows / splitk) * e * 2 > 65536) return false;
+    auto try_plan = [&](int cq) -> bool {
+        const int tc = 4 << cq, G = 64 >> cq;
+        if (a.N % tc != 0) return false;
+        int r;
+        if (cq == 2) {
+            if (!(nbits == 4 || nbits == 2)) return false;
+            r = (rpg % 8 == 0 && rows % (4 * G * 8) == 0) ? 8 : 2;
+            if (rpg % r != 0) return false;
+        } else {
+            r = (rpg % 4 == 0 && rows % (4 * G * 4) == 0) ? 4 : 1;
+            if (nbits == 1 && mb == 8) r = 1;  // register budget
+        }
+        const int block_rows = 4 * G * r;  // packed rows per block step
+        if (rows % block_rows != 0) return false;
+        const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r)
+                                                           : pick_bits<bf16_tag>(nbits, mb, cq, r);
+        if (!fn) return false;
+        const int tiles = (int)(a.N / tc);
+        const int units = rows / block_rows;  // max number of K slices
+        int splitk = 1;
+        if (a.tuning[1] > 0) {
+            splitk = a.tuning[1];
+        } else if (cq == 4) {
+            while (splitk < units && tiles * splitk < 512 && (units % (splitk * 2) == 0)) splitk *= 2;
+        }
+        if (units % splitk != 0) return false;
+        // LDS cap for the x slice: MB * k_slice * 2 bytes <= 64 KiB
+        while (((int64_t)mb * (rows / splitk) * e * 2 > 65536) && (units % (splitk * 2) == 0)) splitk *= 2;
+        if ((int64_t)mb * (rows / splitk) * e * 2 > 65536) return false;
+        if (tiles > MAX_SPLITK_COUNTERS && splitk > 1) return false;
+        p.splitk = splitk;
+        p.rows_per_slice = rows / splitk;
+        lp.fn = fn;
+        lp.name = cq == 2 ? "gemv_wn_kernel<narrow16>" : "gemv_wn_kernel<wide64>";
+        lp.grid = dim3(tiles, splitk, 1);
+        lp.block = dim3(256, 1, 1);
+        lp.lds_bytes = (size_t)mb * p.rows_per_slice * (e / 2) * 4 + (size_t)4 * mb * tc * 4 + 16;
+        lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * mb * tc * 4 : 0;
+        lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
+        return true;
+    };
 
-    p.splitk = splitk;
-    p.rows_per_slice = rows / splitk;
-    lp.fn = fn;
-    lp.name = "gemv_wn_kernel";
-    lp.grid = dim3(tiles, splitk, 1);
-    lp.block = dim3(256, 1, 1);
-    lp.lds_bytes = (size_t)mb * p.rows_per_slice * (e / 2) * 4 + (size_t)4 * mb * 64 * 4 + 16;
-    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * mb * 64 * 4 : 0;
-    lp.ws_bytes = lp.slab_bytes + (splitk > 1 ? (uint64_t)tiles * 4 : 0);
-    return true;
+    const int force = a.tuning[0];
+    if (force == 2) return try_plan(2);
+    if (force == 4) return try_plan(4);
+    // narrow tiles when they alone give >= ~0.75 blocks per CU and x fits LDS; otherwise wide + split-K
+    if (a.N / 16 >= 192 && x_bytes_full <= 65536 && try_plan(2)) return true;
+    if (try_plan(4)) return true;
+    return try_plan(2);
 }
 
 }  // namespace gl

@@ -159,9 +159,7 @@ __device__ __forceinline__ void store_from_float(void* p, int64_t i, int dt, flo
 __device__ __forceinline__ f32x4 load_meta4(const void* p, int64_t i, int dt) {
     f32x4 r;
     if (dt == GEMLITE_DT_FP16) {
-        const u32x2 v = *(const u32x2*)((const uint16_t*)p + i);
-        const h2_t a = __builtin_bit_cast(h2_t, v[0]), b = __builtin_bit_cast(h2_t, v[1]);
-        r[0] = (float)a[0]; r[1] = (float)a[1]; r[2] = (float)b[0]; r[3] = (float)b[1];
+        for (int j = 0; j < 4; ++j) r[j] = (float)((const _Float16*)p)[i + j];
     } else if (dt == GEMLITE_DT_BF16) {
         const u32x2 v = *(const u32x2*)((const uint16_t*)p + i);
         r[0] = __builtin_bit_cast(float, v[0] << 16); r[1] = __builtin_bit_cast(float, v[0] & 0xFFFF0000u);
@@ -200,6 +198,39 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& e, float v, int64
     store_from_float(e.out, m * e.stride_om + n * e.stride_on, e.out_dt, epilogue_scale(e, v, m, n));
 }
 
+// typed (compile-time dtype) variants used by the specialised kernels: no runtime dtype switches in hot loops
+template <typename Tag>
+__device__ __forceinline__ f32x4 load4_t(const void* p, int64_t i) {  // 4 consecutive 16-bit floats -> fp32
+    const u32x2 v = *(const u32x2*)((const uint16_t*)p + i);
+    f32x4 r;
+    const uint32_t v0 = v[0], v1 = v[1];
+    if constexpr (F16Traits<Tag>::DT == GEMLITE_DT_FP16) {
+        // NOTE: going through bit_cast<h2_t>(v[1]) here was miscompiled by hipcc 7.2 (second dword dropped,
+        // r[2], r[3] left undefined); extract the halves as integers instead.
+        r[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v0 & 0xFFFFu));
+        r[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v0 >> 16));
+        r[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v1 & 0xFFFFu));
+        r[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v1 >> 16));
+    } else {
+        r[0] = __builtin_bit_cast(float, v0 << 16); r[1] = __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+        r[2] = __builtin_bit_cast(float, v1 << 16); r[3] = __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+    }
+    return r;
+}
+
+template <typename Tag>
+__device__ __forceinline__ void store_out_t(const Epilogue& e, float v, int64_t m, int64_t n) {
+    using TR = F16Traits<Tag>;
+    if (e.c_mode == 1) {
+        v *= TR::to_float(((const uint16_t*)e.scales_w)[n]);
+    } else if (e.c_mode == 2) {
+        v *= e.scales_x[m * e.stride_sx_m];
+    } else if (e.c_mode == 3) {
+        v *= e.scales_x[m * e.stride_sx_m] * TR::to_float(((const uint16_t*)e.scales_w)[n]);
+    }
+    ((uint16_t*)e.out)[m * e.stride_om + n] = TR::from_float(v);
+}
+
 // dequant of an integer code q (as float) for W_group_mode (triton_kernels/utils.py:73-87),
 // evaluated in fp32 on the stored scale / zero
 __device__ __forceinline__ float dequant_f32(float q, float s, float z, int w_mode) {
@@ -222,6 +253,11 @@ __device__ __forceinline__ void group_affine(float s, float z, int w_mode, float
         default: a = 1.0f; b = 0.0f; break;
     }
 }
+
+// Workspace layout: [arrival counters: MAX_SPLITK_COUNTERS x u32 | slabs].  The counters sit at a FIXED
+// place so that slab payload of one shape can never alias the counters of another; kernels leave them zero.
+constexpr int MAX_SPLITK_COUNTERS = 65536;
+constexpr uint64_t COUNTER_BYTES = (uint64_t)MAX_SPLITK_COUNTERS * 4;
 
 // ---------------------------------------------------------------------------------------------
 // split-K hand-off words: write-through (sc1) stores / loads at agent scope
@@ -292,8 +328,8 @@ struct LaunchPlan {
     const char* name;
     dim3 grid, block;
     size_t lds_bytes;
-    uint64_t ws_bytes;    // total workspace needed
-    uint64_t slab_bytes;  // offset of the counters inside the workspace
+    uint64_t ws_bytes;    // total workspace needed (COUNTER_BYTES + slab_bytes when K is split, else 0)
+    uint64_t slab_bytes;
 };
 
 }  // namespace gl
