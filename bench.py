@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-samples", type=int, default=256, help="launches timed individually for roofline")
     ap.add_argument("--tuning", default="", help="development: comma-separated tuning[] override, e.g. 4,8")
+    ap.add_argument("--matmul-type", default="", help="development: force a kernel family (forward_manual)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,9 +132,12 @@ def main():
     N, K, nbits, group, M, dt, layers, bound = WORKLOADS[args.workload]
     mods, x = build_layers(args.workload, device)
 
+    def call(lin):
+        return lin.forward_manual(x, args.matmul_type) if args.matmul_type else lin(x)
+
     def step_eager():
         for lin in mods:
-            lin(x)
+            call(lin)
 
     # warm-up on a side stream (allocates the per-stream split-K workspace), then capture one step
     stream = torch.cuda.Stream(device)
@@ -188,7 +192,7 @@ def main():
         with torch.cuda.stream(stream):
             for i, (a, b) in enumerate(pairs):
                 lib.gemlite_hip_set_profile_events(a, b)
-                mods[i % layers](x)
+                call(mods[i % layers])
         torch.cuda.synchronize()
         durs = np.array([ev.elapsed_ms(a, b) * 1e3 for a, b in pairs])
         durs = durs[np.isfinite(durs) & (durs > 0)]

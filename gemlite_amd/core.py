@@ -206,8 +206,8 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
         # dynamic per-token activation quantisation (core.py:155-175)
         x, scales_x = scale_activations_per_token(x, w_dtype=DTYPE_TO_TORCH[in_code])
     x2 = x.view(-1, x.shape[-1])
-    if matmul_type < 0:
-        matmul_type = GEMLITE_MATMUL_TYPES_MAPPING[get_matmul_type(x2.shape[0], W_nbits, False)]
+    # matmul_type < 0 (auto) is resolved inside the library: the HIP kernel families have their own M
+    # thresholds (GEMV <= 4 rows, streaming MFMA above), unlike the Triton ones of get_matmul_type()
     out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type).view(out_shape)
     if bias is not None:
         out += bias

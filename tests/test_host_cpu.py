@@ -73,12 +73,13 @@ def test_struct_abi_and_validation():
 
 
 @pytest.mark.parametrize("kw,kernel", [
-    (dict(M=1), "gemv_wn_kernel<narrow16>"),          # cfgA: 256 tiles of 16 columns, no split-K
-    (dict(M=1, in_dt=2), "gemv_wn_kernel<narrow16>"),
-    (dict(M=8), "gemv_wn_kernel<narrow16>"),
-    (dict(M=1, nbits=2), "gemv_wn_kernel<narrow16>"),
-    (dict(M=1, N=1024), "gemv_wn_kernel<wide64>"),    # too few columns: 64-column tiles + split-K
-    (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<narrow16>"),
+    (dict(M=1), "gemv_wn_kernel<tile32>"),            # cfgA: 128 tiles of 32 columns (128-byte row segments)
+    (dict(M=1, in_dt=2), "gemv_wn_kernel<tile32>"),
+    (dict(M=4), "gemv_wn_kernel<tile32>"),
+    (dict(M=8), "gemm_wn_stream_kernel"),             # M >= 5: MFMA streaming kernel
+    (dict(M=1, nbits=2), "gemv_wn_kernel<tile32>"),
+    (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
+    (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile32>"),
     (dict(M=16), "gemm_wn_stream_kernel"),
     (dict(M=1, mt=4), "gemm_wn_stream_kernel"),      # manual GEMM family at M=1 -> an MFMA kernel
     (dict(M=4, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK
@@ -97,12 +98,13 @@ def test_kernel_selection(kw, kernel):
 
 def test_workspace_sizing_cfgA():
     lib = _hip.load()
-    a = _args(M=1)  # 4096x4096 W4 -> narrow tiles, K not split: no workspace at all
-    assert lib.gemlite_hip_workspace_bytes(C.byref(a)) == 0
-    a.tuning[0] = 4  # force the wide variant: 64 column tiles x split-K 8 slabs of 64 fp32 behind the counters
+    a = _args(M=1)
+    a.tuning[0], a.tuning[1] = 4, 8  # 64-column tiles x split-K 8: slabs of 64 fp32 behind the fixed counter block
     assert lib.gemlite_hip_workspace_bytes(C.byref(a)) == 65536 * 4 + 64 * 8 * 64 * 4
-    a.tuning[1] = 1  # forced split-K 1
+    a.tuning[0], a.tuning[1] = 2, 0  # 16-column tiles never split K at this shape: no workspace at all
     assert lib.gemlite_hip_workspace_bytes(C.byref(a)) == 0
+    a.tuning[0], a.tuning[1] = 4, 3  # 3 does not divide the K steps -> falls through to another kernel family
+    assert lib.gemlite_hip_kernel_name(C.byref(a)).decode() != "gemv_wn_kernel<tile64>"
 
 
 # ------------------------------------------------------------------------------ bit packing (host)
