@@ -120,7 +120,7 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         p.stride_meta_g = per_group_meta ? a.stride_meta_g : 0;
         const int mt = a.matmul_type;
         const bool want_gemv = (mt == GEMLITE_MATMUL_GEMV || mt == GEMLITE_MATMUL_GEMV_REVSPLITK ||
-                                mt == GEMLITE_MATMUL_GEMV_SPLITK || (mt == GEMLITE_MATMUL_AUTO && a.M <= 4));
+                                mt == GEMLITE_MATMUL_GEMV_SPLITK || (mt == GEMLITE_MATMUL_AUTO && a.M <= 1));
         LaunchPlan lp{};
         if (want_gemv && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }
         if (!want_gemv) {

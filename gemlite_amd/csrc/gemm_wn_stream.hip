@@ -215,9 +215,17 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void gemm_wn_stream_kernel(
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // all A fragments of the piece are requested up front (LDS latency overlaps the unpack VALU work)
+        u32x4 afr[U][NF][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    afr[u][f][t] = *(const u32x4*)(xs + (t * 16 + c) * XPITCH + (wave * ROWS_WP + 4 * u + g) * HALF + 4 * f);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int row_p = wave * ROWS_WP + 4 * u + g;  // packed row inside the piece
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const int ks = u * NF + f;  // MFMA k-step 0..3 inside the wave's 128-k span
@@ -232,11 +240,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void gemm_wn_stream_kernel(
                         bfrag[j][dd] = h;
                     }
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const u32x4 afrag = *(const u32x4*)(xs + (t * 16 + c) * XPITCH + row_p * HALF + 4 * f);
+                for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[t][j] = mfma16<Tag>(afrag, bfrag[j], acc[t][j]);
-                }
+                    for (int j = 0; j < 4; ++j) acc[t][j] = mfma16<Tag>(afr[u][f][t], bfrag[j], acc[t][j]);
                 if ((ks + 1) % SPG == 0) {  // end of a quantisation group: fold scale / zero into the totals
                     const int q = ks / SPG;
                     f32x4 s = unpack4(pc.s[q]), z = unpack4(pc.z[q]);
@@ -283,10 +289,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void gemm_wn_stream_kernel(
     if (npieces > 1) load_piece(B, 1);
     put_x(X, 0);
     __syncthreads();
-    if (npieces == 1) {
-        compute(A, 0);
-    } else if constexpr (DBUF) {
-        for (int pc = 0; pc < npieces; pc += 2) {  // npieces even; the tail re-requests the last piece (unused)
+    if constexpr (DBUF) {
+        int pc = 0;
+        for (; pc + 2 <= npieces; pc += 2) {  // the tail re-requests the last piece (harmless)
             fetch_x(X, pc + 1);
             compute(A, 0);
             load_piece(A, pc + 2 < npieces ? pc + 2 : npieces - 1);
@@ -298,8 +303,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void gemm_wn_stream_kernel(
             put_x(X, 0);
             __syncthreads();
         }
+        if (npieces & 1) compute(A, 0);
     } else {
-        for (int pc = 0; pc < npieces; pc += 2) {
+        int pc = 0;
+        for (; pc + 2 <= npieces; pc += 2) {
             fetch_x(X, pc + 1);
             compute(A, 0);
             load_piece(A, pc + 2 < npieces ? pc + 2 : npieces - 1);
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void gemm_wn_stream_kernel(
             put_x(X, 0);
             __syncthreads();
         }
+        if (npieces & 1) compute(A, 0);
     }
 
     // ---- combine the 4 waves (disjoint K) through LDS ------------------------------------------------------
@@ -422,11 +430,7 @@ bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     if (!fn) return false;
     const int tiles = (int)(a.N / 64), mtiles = (int)((a.M + bm - 1) / bm);
     const int units = rows / piece_rows;
-    auto ok = [&](int sk) {
-        if (sk < 1 || units % sk != 0) return false;
-        const int steps = units / sk;
-        return steps == 1 || steps % 2 == 0;
-    };
+    auto ok = [&](int sk) { return sk >= 1 && units % sk == 0; };
     int splitk = 0;
     if (a.tuning[1] > 0) {
         if (!ok(a.tuning[1])) return false;

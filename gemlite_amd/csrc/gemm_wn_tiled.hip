@@ -1,7 +1,307 @@
-// gemm_wn_tiled.hip — large-M tiled MFMA GEMM for packed weights (placeholder until the tiled kernel lands;
-// the dispatcher falls through to the streaming MFMA kernel when this planner declines).
+// gemm_wn_tiled.hip — fused unpack + dequant + tiled MFMA GEMM for packed low-bit weights, large M (prefill).
+// Replaces gemm_INT_kernel (gemlite/triton_kernels/gemm_kernels.py:248-413).
+//
+// Why this shape (CDNA4, measured costs in DESIGN.md): every VALU instruction costs ~4 cycles per wave and
+// v_mfma_f32_32x32x16 32 cycles per SIMD, so a weight must be dequantised ONCE per block and reused by many
+// MFMAs.  Block = 4 waves, tile 128 (M) x 128 (N); wave w owns all 128 rows x columns [32w, 32w+32):
+//   * B: lane (col = lane&31, kb = lane>>5) of a 32x32x16 MFMA holds 8 consecutive k of ONE column = one packed
+//     int32 word (4-bit).  The wave therefore loads its B fragments straight from HBM/L2 with one dword per lane
+//     (2 packed rows x 128 contiguous bytes per instruction), dequantises them in registers exactly like the
+//     reference (q exact -> fma / sub / mul in fp16, triton_kernels/utils.py:73-87; bf16: one fp32 fma rounded
+//     once) and feeds 4 MFMAs (the 4 row blocks) with each fragment: no LDS traffic and no redundancy for B.
+//   * A (x): 128 x 64 tile per K step through LDS, double buffered, stored pair-permuted (the k order the AND/OR
+//     unpack produces) and XOR-swizzled on 16-byte slots so that ds_read_b128 of 32 rows is conflict-free.
+//   * K is optionally split over gridDim.y (128-column tiles alone rarely fill 256 CUs at M = 256); slices are
+//     combined with the write-through slab + ticket protocol (gl_common.h).
 #include "gl_common.h"
 
 namespace gl {
-bool plan_gemm_wn_tiled(const gemlite_hip_forward_args&, WnParams&, LaunchPlan&) { return false; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename Tag>
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 mfma32<half_tag>(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 mfma32<bf16_tag>(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
+}
+
+// two dequantised weights (packed 16-bit floats) from one magic-number pair
+template <typename Tag>
+struct Deq2;
+template <>
+struct Deq2<half_tag> {
+    // branch-free form of triton_kernels/utils.py:73-87:  w = fma(q - zsub, s, zadd)  with
+    //   mode 0: (0, 1, 0) | 1: (z, 1, 0) | 2: (0, s, 0) | 3: (z, s, 0) | 4: (0, s, z')
+    // q - 0 and t * 1 + 0 are exact, so every mode rounds exactly where the reference rounds.
+    h2_t zsub2, s2, zadd2;
+    __device__ __forceinline__ void set(float s, float z, int w_mode) {
+        const float zs = (w_mode == 1 || w_mode == 3) ? z : 0.f;
+        const float sc = w_mode >= 2 ? s : 1.f;
+        const float za = w_mode == 4 ? z : 0.f;
+        zsub2 = (h2_t){(_Float16)zs, (_Float16)zs};
+        s2 = (h2_t){(_Float16)sc, (_Float16)sc};
+        zadd2 = (h2_t){(_Float16)za, (_Float16)za};
+    }
+    __device__ __forceinline__ uint32_t apply(uint32_t h, int) const {
+        h2_t q = __builtin_bit_cast(h2_t, h) - (h2_t){(_Float16)1024.0f, (_Float16)1024.0f};  // exact integer
+        q = __builtin_elementwise_fma(q - zsub2, s2, zadd2);
+        return __builtin_bit_cast(uint32_t, q);
+    }
+};
+template <>
+struct Deq2<bf16_tag> {
+    float A, B;  // w = fma(128 + q, A, B), the 128 offset folded into B
+    __device__ __forceinline__ void set(float s, float z, int w_mode) {
+        switch (w_mode) {
+            case 1: A = 1.0f; B = -(z + 128.0f); break;
+            case 2: A = s; B = -128.0f * s; break;
+            case 3: A = s; B = -(z + 128.0f) * s; break;
+            case 4: A = s; B = __builtin_fmaf(-128.0f, s, z); break;
+            default: A = 1.0f; B = -128.0f; break;
+        }
+    }
+    __device__ __forceinline__ uint32_t apply(uint32_t h, int) const {
+        const float lo = __builtin_bit_cast(float, h << 16);
+        const float hi = __builtin_bit_cast(float, h & 0xFFFF0000u);
+        const b2_t r = {(__bf16)__builtin_fmaf(lo, A, B), (__bf16)__builtin_fmaf(hi, A, B)};
+        return __builtin_bit_cast(uint32_t, r);
+    }
+};
+
+constexpr int TBM = 128, TBN = 128, TBK = 64;
+constexpr int A_BUF_BYTES = TBM * TBK * 2;  // 16 KiB
+constexpr int C_PITCH = TBN + 4;            // floats per row of the epilogue tile (16-byte aligned, conflict-free)
+
+// byte offset of the 16-byte slot (row r, slot s of 8) inside an A buffer: XOR swizzle on (r >> 1)
+__device__ __forceinline__ int a_slot(int r, int s) { return r * (TBK * 2) + ((s ^ ((r >> 1) & 7)) << 4); }
+
+template <typename Tag>
+__global__ __launch_bounds__(256, 2) void gemm_w4_tiled_kernel(const WnParams p) {
+    using TR = F16Traits<Tag>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][A_BUF_BYTES], later the C tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, kb = lane >> 5;
+    const int ntile_n = p.N / TBN;
+    // tile order: consecutive blocks share the same column tile (B reuse in L2), M tiles fastest
+    const int mtiles = (p.M + TBM - 1) / TBM;
+    const int bid = blockIdx.x;
+    const int mt = bid % mtiles, nt = bid / mtiles;
+    const int slice = blockIdx.y;
+    const int m0 = mt * TBM;
+    const int n = nt * TBN + wave * 32 + col;  // this lane's column
+    (void)ntile_n;
+
+    const int ksteps = p.rows_per_slice / (TBK / 8);       // K steps of 64 in this slice (rows_per_slice packed rows)
+    const int row_s0 = slice * p.rows_per_slice;           // first packed row of the slice
+    const int64_t k_s0 = (int64_t)row_s0 * 8;
+
+    const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
+    const uint16_t* sp = need_s ? (const uint16_t*)p.scales : (const uint16_t*)p.w;
+    const uint16_t* zp = need_z ? (const uint16_t*)p.zeros : (const uint16_t*)p.w;
+    const int64_t mstride = (need_s || need_z) ? p.stride_meta_g : 0;
+    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
+
+    // ---- B stream: 8 packed rows per K step; this lane needs rows 2*ks + kb (ks = 0..3) of its column ----------
+    const uint32_t* wbase = p.w + (int64_t)(row_s0 + kb) * p.stride_wk + n;
+    const int sw = (int)p.stride_wk, gsz = p.group_size, ms = (int)mstride;  // 32-bit index math in the loop
+    const int kbase = (int)k_s0;
+    struct BStep { uint32_t w[4]; uint16_t s, z; };
+    auto load_b = [&](BStep& b, int step) {
+        const uint32_t* wp = wbase + step * 8 * sw;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b.w[ks] = wp[2 * ks * sw];
+        const int grp = (kbase + step * TBK) / gsz;
+        b.s = sp[grp * ms + n];
+        b.z = zp[grp * ms + n];
+    };
+    // ---- A stream: 128 rows x 64 k per step = 1024 16-byte slots, 4 per thread ---------------------------------
+    const uint16_t* xg = (const uint16_t*)p.x;
+    struct AStep { u32x4 v[4]; };
+    const uint16_t* xrow[4];  // this thread's 4 staging rows (clamped: rows >= M are zeroed after the load)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = tid + 256 * i, r = u >> 3, s = u & 7;
+        const int rr = m0 + r < p.M ? m0 + r : p.M - 1;
+        xrow[i] = xg + (int64_t)rr * p.stride_xm + k_s0 + s * 8;
+    }
+    auto load_a = [&](AStep& a, int step) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a.v[i] = *(const u32x4*)(xrow[i] + step * TBK);
+            if (m0 + ((tid + 256 * i) >> 3) >= p.M) a.v[i] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto put_a = [&](const AStep& a, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = tid + 256 * i, r = u >> 3, s = u & 7;
+            // 8 halfs x0..x7 -> pairs (x0,x4)(x1,x5)(x2,x6)(x3,x7): the k order of the unpacked B fragment
+            const uint32_t d0 = a.v[i][0], d1 = a.v[i][1], d2 = a.v[i][2], d3 = a.v[i][3];
+            u32x4 o;
+            o[0] = (d0 & 0xFFFFu) | (d2 << 16);
+            o[1] = (d0 >> 16) | (d2 & 0xFFFF0000u);
+            o[2] = (d1 & 0xFFFFu) | (d3 << 16);
+            o[3] = (d1 >> 16) | (d3 & 0xFFFF0000u);
+            *(u32x4*)(smem + buf * A_BUF_BYTES + a_slot(r, s)) = o;
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    Deq2<Tag> dq;
+    // A-fragment offsets: row = mi*32 + col, slot = ks*2 + kb; the swizzle term depends on col only
+    int a_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a_off[ks] = a_slot(col, ks * 2 + kb);
+    auto compute = [&](const BStep& b, int buf) {
+        const unsigned char* abase = smem + buf * A_BUF_BYTES;
+        // all 16 A fragments of the K step are requested up front: their LDS latency overlaps the dequant VALU work
+        u32x4 af[4][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[ks][mi] = *(const u32x4*)(abase + mi * 32 * (TBK * 2) + a_off[ks]);
+        float s = need_s ? TR::to_float(b.s) : 1.f;
+        float z = need_z ? TR::to_float(b.z) : scalar_zero;
+        dq.set(s, z, p.w_mode);
+        u32x4 bfrag[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const uint32_t h = ((b.w[ks] >> (4 * dd)) & 0x000F000Fu) | TR::MAGIC2;
+                bfrag[ks][dd] = dq.apply(h, p.w_mode);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma32<Tag>(af[ks][mi], bfrag[ks], acc[mi]);
+    };
+
+    BStep B0, B1;
+    AStep A0;
+    load_a(A0, 0);
+    load_b(B0, 0);
+    if (ksteps > 1) load_b(B1, 1);
+    put_a(A0, 0);
+    __syncthreads();
+    {
+        int st = 0;
+        for (; st + 2 <= ksteps; st += 2) {
+            load_a(A0, st + 1);
+            compute(B0, 0);
+            load_b(B0, st + 2 < ksteps ? st + 2 : ksteps - 1);
+            put_a(A0, 1);
+            __syncthreads();
+            load_a(A0, st + 2 < ksteps ? st + 2 : ksteps - 1);
+            compute(B1, 1);
+            load_b(B1, st + 3 < ksteps ? st + 3 : ksteps - 1);
+            put_a(A0, 0);
+            __syncthreads();
+        }
+        if (ksteps & 1) compute(B0, 0);
+    }
+
+    // ---- epilogue.  C fragment of a 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+    // The tile is transposed through LDS so that slabs and the output move as 16-byte row segments (4-byte
+    // write-through stores are ~6x slower per byte: MI355X_MICROARCH.md "stores of each flavour").
+    __syncthreads();  // all waves are done with the A buffers
+    float* ct = (float*)smem;  // [TBM][C_PITCH]
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kb;
+            ct[r * C_PITCH + wave * 32 + col] = acc[mi][e];
+        }
+    __syncthreads();
+    const int tile_lin = bid;
+    constexpr int UNITS = TBM * TBN / 4 / 256;  // float4 units per thread
+    const int64_t ncol0 = (int64_t)nt * TBN;
+    if (p.splitk == 1) {
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 256 * i, r = u >> 5, c4 = (u & 31) * 4;
+            if (m0 + r < p.M) store_out4_t<Tag>(p.epi, *(const f32x4*)(ct + r * C_PITCH + c4), m0 + r, ncol0 + c4);
+        }
+        return;
+    }
+    constexpr int NOUT = TBM * TBN;
+    float* slab = p.slabs + ((int64_t)tile_lin * p.splitk) * NOUT;  // wave-uniform base of this tile's slabs
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+        const int u = tid + 256 * i, r = u >> 5, c4 = (u & 31) * 4;
+        if (m0 + r < p.M) {
+            const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (slice * NOUT + r * TBN + c4) * 4, 0, 16);  // sc1
+        }
+    }
+    unsigned* flag = (unsigned*)(smem + TBM * C_PITCH * 4);
+    if (!splitk_arrive_is_last(p.counters + tile_lin, p.splitk, flag)) return;
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+        const int u = tid + 256 * i, r = u >> 5, c4 = (u & 31) * 4;
+        if (m0 + r < p.M) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.splitk; ++s)
+                v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (s * NOUT + r * TBN + c4) * 4, 0, 16));
+            store_out4_t<Tag>(p.epi, v, m0 + r, ncol0 + c4);
+        }
+    }
+    if (tid == 0) splitk_reset(p.counters + tile_lin);
+}
+
+// tuning[1]: 0 auto | n force split-K n
+bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
+    if (a.W_nbits != 4) return false;  // 2-/1-bit words span more than one MFMA fragment: streaming kernel
+    if (a.N % TBN != 0 || a.K % TBK != 0) return false;
+    if (a.output_dtype != a.input_dtype) return false;
+    const bool uses_s = a.W_group_mode >= 2 || a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
+    if (uses_s && a.meta_dtype != a.input_dtype) return false;
+    if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
+    if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
+    if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;
+    if (p.group_size % TBK != 0) return false;  // one (scale, zero) pair per column and K step
+    const int rows = (int)(a.K / 8), step_rows = TBK / 8;
+    const int units = rows / step_rows;
+    const int64_t tiles = (int64_t)(a.N / TBN) * ((a.M + TBM - 1) / TBM);
+    auto ok = [&](int sk) { return sk >= 1 && units % sk == 0; };
+    int splitk = 0;
+    if (a.tuning[1] > 0) {
+        if (!ok(a.tuning[1])) return false;
+        splitk = a.tuning[1];
+    } else {
+        for (int sk = 1; sk <= units && sk <= 16; sk *= 2) {
+            if (!ok(sk)) continue;
+            splitk = sk;
+            if (tiles * sk >= 256) break;
+        }
+        if (!splitk) return false;
+    }
+    if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
+    p.splitk = splitk;
+    p.rows_per_slice = rows / splitk;
+    lp.fn = a.input_dtype == GEMLITE_DT_FP16 ? (const void*)gemm_w4_tiled_kernel<half_tag>
+                                              : (const void*)gemm_w4_tiled_kernel<bf16_tag>;
+    lp.name = "gemm_w4_tiled_kernel";
+    lp.grid = dim3((unsigned)tiles, splitk, 1);
+    lp.block = dim3(256, 1, 1);
+    lp.lds_bytes = (size_t)TBM * C_PITCH * 4 + 16;  // the epilogue tile (66 KiB) is larger than the two A buffers
+    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * TBM * TBN * 4 : 0;
+    lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
+    return true;
+}
+
 }  // namespace gl

@@ -29,41 +29,39 @@
 
 namespace gl {
 
-// Unpack geometry.  One AND/OR turns packed bits into two 16-bit floats (OFF + q * 2^(NBITS*i)) where i is
-// the position of the element inside a WINDOW of consecutive bit fields that still fits the mantissa; the
-// matching x pair is stored pre-scaled by 2^-(NBITS*i) (exact power of two), so only one shift per window
-// (not per element) is needed:  fp16 (10-bit mantissa): 2 x 4-bit / 4 x 2-bit / 8 x 1-bit fields per window;
-// bf16 (7-bit): 1 x 4-bit / 2 x 2-bit / 4 x 1-bit.
+// Unpack geometry.  One AND turns packed bits into two 16-bit floats q * 2^(NBITS*i) (i = position of the
+// element inside a WINDOW of consecutive bit fields that still fits the mantissa); the matching x pair is stored
+// pre-scaled by 2^-(NBITS*i) (an exact power of two), so only one shift per window (not per element) is needed.
+//   fp16 (10-bit mantissa): the masked bits are used as fp16 SUBNORMALS (value * 2^-24, exact; v_dot2c keeps
+//         subnormals — scripts/ubench/probe_dot2.hip); windows hold 2 x 4-bit / 4 x 2-bit / 8 x 1-bit fields;
+//   bf16 (7-bit mantissa, no usable subnormal range): (bits | 0x4300) = 128 + value, and the 128 * sum(x) term
+//         is removed per run of rows; windows hold 1 x 4-bit / 2 x 2-bit / 4 x 1-bit fields.
 template <typename Tag, int NBITS>
 struct Window {
-    static constexpr int MANT = F16Traits<Tag>::DT == GEMLITE_DT_FP16 ? 10 : 7;
+    static constexpr bool SUBN = F16Traits<Tag>::DT == GEMLITE_DT_FP16;
+    static constexpr int MANT = SUBN ? 10 : 7;
     static constexpr int HALF = 16 / NBITS;
     static constexpr int fit() {
         int wp = 1;
         while (wp * 2 <= HALF && (((1 << NBITS) - 1) << (NBITS * (wp * 2 - 1))) < (1 << MANT)) wp *= 2;
         return wp;
     }
-    static constexpr int WP = fit();            // pairs per window
-    static constexpr int NWIN = HALF / WP;      // windows (= shifts + 1) per packed word
+    static constexpr int WP = fit();  // pairs per window
 };
-
-__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t magic) {
-    // plain C on purpose: an inline-asm v_and_or_b32 (one op instead of two) made hipcc's scheduler hoist all
-    // unpacks ahead of their uses: 256 VGPRs + scratch spills instead of ~110 VGPRs
-    return (a & mask) | magic;
-}
 
 template <typename Tag, int NBITS, int MB, int R, int CQ>
 __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1 : 2)) void gemv_wn_kernel(const WnParams p) {
     using TR = F16Traits<Tag>;
     using WN = Window<Tag, NBITS>;
+    constexpr bool SUBN = WN::SUBN;
     constexpr int E = 32 / NBITS;    // elements per packed word
     constexpr int HALF = E / 2;      // (k, k+HALF) pairs per word == LDS dwords per packed row
     constexpr int WP = WN::WP;
     constexpr int G = 64 >> CQ;      // row sub-groups per wave
     constexpr int CHUNK = G * R;     // packed rows one wave consumes per step
     constexpr int TC = 4 << CQ;      // tile columns
-    static_assert(NBITS <= TR::MAX_QBITS, "q + OFF must be exact in the 16-bit float type");
+    constexpr int RUN_SPANS = R * E / 32;  // 32-k spans of x covered by a lane's run of R rows
+    static_assert(R * E % 32 == 0, "a run of rows must cover whole 32-k spans of x");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,48 +82,13 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     const int row_s0 = slice * rows_slice;            // first packed row of the slice
     const int row_w0 = wave * rows_wave;              // wave start, relative to the slice
     const int pairs = rows_slice * HALF;              // LDS dwords per x row
+    const int nspans = rows_slice * E / 32;           // 32-k spans per x row
 
-    uint32_t* xs = (uint32_t*)smem;                               // [MB][pairs]
-    float* red = (float*)(smem + (size_t)MB * pairs * 4);          // [4][MB][TC]
+    uint32_t* xs = (uint32_t*)smem;                                   // [MB][pairs]  pair-permuted, pre-scaled x
+    float* xsum_t = (float*)(smem + (size_t)MB * pairs * 4);           // [MB][nspans] sum of x over each span
+    float* xsum_s = xsum_t + MB * nspans;                              // [MB][nspans] sum of x as stored (bf16 path)
+    float* red = xsum_s + MB * nspans;                                 // [4][MB][TC]
     unsigned* flag = (unsigned*)(red + 4 * MB * TC);
-
-    // ---- x[k-slice]: global -> registers (pair-permuted, window-prescaled), issued AHEAD of the weights -----
-    constexpr int XPT = 4;  // LDS dwords staged per thread per pass
-    const uint16_t* xg = (const uint16_t*)p.x;
-    const int64_t k0 = (int64_t)row_s0 * E;
-    const int xtotal = MB * pairs;
-    const int npass = (xtotal + 256 * XPT - 1) / (256 * XPT);
-    auto fetch_x = [&](uint32_t (&v)[XPT], int pass) {
-#pragma unroll
-        for (int t = 0; t < XPT; ++t) {
-            const int idx = (pass * XPT + t) * 256 + tid;
-            v[t] = 0;
-            if (idx < xtotal) {
-                const int m = idx / pairs, pi = idx - m * pairs;
-                const int word = pi / HALF, d = pi - word * HALF;
-                if (m < p.M) {
-                    const int64_t k = k0 + (int64_t)word * E + d;
-                    v[t] = (uint32_t)xg[m * p.stride_xm + k] | ((uint32_t)xg[m * p.stride_xm + k + HALF] << 16);
-                }
-            }
-        }
-    };
-    auto put_x = [&](const uint32_t (&v)[XPT], int pass) {
-#pragma unroll
-        for (int t = 0; t < XPT; ++t) {
-            const int idx = (pass * XPT + t) * 256 + tid;
-            if (idx < xtotal) {
-                uint32_t val = v[t];
-                if constexpr (WP > 1) {  // pre-scale the pair by 2^-(NBITS * position-in-window): exact
-                    const int i = (idx % HALF) % WP;
-                    const float sc = __builtin_bit_cast(float, (uint32_t)(127 - NBITS * i) << 23);
-                    const float lo = TR::to_float((uint16_t)(val & 0xFFFFu)) * sc, hi = TR::to_float((uint16_t)(val >> 16)) * sc;
-                    val = (uint32_t)TR::from_float(lo) | ((uint32_t)TR::from_float(hi) << 16);
-                }
-                xs[idx] = val;
-            }
-        }
-    };
 
     // ---- weight + metadata stream: everything a chunk needs is requested together, one chunk ahead --------
     const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
@@ -145,16 +108,74 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
         ck.z = *(const u32x2*)(zp + grp * mstride + n0);
     };
 
+    // ---- x[k-slice] -> LDS.  task = (row m, 32-k span): 64 bytes in, 16 pair-permuted / pre-scaled dwords and
+    //      the span sums out.  The first task's loads are issued AHEAD of the weight stream. ---------------------
+    const uint16_t* xg = (const uint16_t*)p.x;
+    const int64_t k0 = (int64_t)row_s0 * E;
+    const int ntasks = MB * nspans;
+    auto fetch_x = [&](u32x4 (&v)[4], int task) {
+        if (task < ntasks) {
+            const int m = task / nspans, spn = task - m * nspans;
+            if (m < p.M) {
+                const uint16_t* src = xg + (int64_t)m * p.stride_xm + k0 + (int64_t)spn * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = *(const u32x4*)(src + 8 * q);
+            }
+        }
+    };
+    auto put_x = [&](const u32x4 (&vin)[4], int task) {
+        if (task >= ntasks) return;
+        constexpr int WPS = 32 / E;  // packed words per span (E <= 32)
+        const int m = task / nspans, spn = task - m * nspans;
+        uint32_t outv[16];
+        float sum_t = 0.f, sum_s = 0.f;
+        if (m < p.M) {
+            uint16_t v[32];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    v[8 * q + 2 * z] = (uint16_t)(vin[q][z] & 0xFFFFu);
+                    v[8 * q + 2 * z + 1] = (uint16_t)(vin[q][z] >> 16);
+                }
+#pragma unroll
+            for (int wdi = 0; wdi < WPS; ++wdi)
+#pragma unroll
+                for (int d = 0; d < HALF; ++d) {
+                    const float lo = TR::to_float(v[wdi * E + d]), hi = TR::to_float(v[wdi * E + d + HALF]);
+                    sum_t += lo + hi;
+                    if constexpr (WP > 1) {  // pre-scale by 2^-(NBITS * position-in-window): exact
+                        const float sc = __builtin_bit_cast(float, (uint32_t)(127 - NBITS * (d % WP)) << 23);
+                        const uint16_t slo = TR::from_float(lo * sc), shi = TR::from_float(hi * sc);
+                        sum_s += TR::to_float(slo) + TR::to_float(shi);
+                        outv[wdi * HALF + d] = (uint32_t)slo | ((uint32_t)shi << 16);
+                    } else {
+                        outv[wdi * HALF + d] = (uint32_t)v[wdi * E + d] | ((uint32_t)v[wdi * E + d + HALF] << 16);
+                    }
+                }
+            if constexpr (WP == 1) sum_s = sum_t;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) outv[d] = 0u;
+        }
+        uint32_t* dst = xs + m * pairs + spn * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(u32x4*)(dst + 4 * q) = (u32x4){outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
+        xsum_t[task] = sum_t;
+        xsum_s[task] = sum_s;
+    };
+
     Chunk A, B;
     {
-        uint32_t xv[XPT];
-        fetch_x(xv, 0);
+        u32x4 xv[4];
+        fetch_x(xv, tid);
         load_chunk(A, 0);
         if (nchunks > 1) load_chunk(B, 1);
-        put_x(xv, 0);
-        for (int pass = 1; pass < npass; ++pass) {  // large K * MB only
-            fetch_x(xv, pass);
-            put_x(xv, pass);
+        put_x(xv, tid);
+        for (int task = tid + 256; task < ntasks; task += 256) {  // large K * MB only
+            fetch_x(xv, task);
+            put_x(xv, task);
         }
     }
     __syncthreads();
@@ -170,8 +191,8 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     // b = bz * z * (mode 3 ? s : 1) with bz = -1 (modes 1, 3), +1 (mode 4), 0 otherwise
     const float bz = (p.w_mode == 1 || p.w_mode == 3) ? -1.f : (p.w_mode == 4 ? 1.f : 0.f);
     const bool b_times_s = p.w_mode == 3;
-    const uint32_t magic = TR::MAGIC2;
-    uint32_t wmask[WP];  // wave-uniform masks (SGPRs): field i of a window, both halves
+    constexpr float QSCALE = SUBN ? 16777216.0f : 1.0f;  // 2^24: undo the subnormal interpretation
+    uint32_t wmask[WP];  // field i of a window, both 16-bit halves
 #pragma unroll
     for (int i = 0; i < WP; ++i) wmask[i] = (((1u << NBITS) - 1u) * 0x00010001u) << (NBITS * i);
 
@@ -185,21 +206,16 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
 
     auto compute = [&](const Chunk& ck, int chunk) {
         const int row_rel = row_w0 + chunk * CHUNK + g * R;  // first of this lane's R rows (slice-relative)
-        float acc[MB][4], accx[MB][WP];  // accx[m][i]: sum of the STORED (pre-scaled) x of window position i
+        float acc[MB][4];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-#pragma unroll
-            for (int i = 0; i < WP; ++i) accx[m][i] = 0.f;
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
-        }
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             constexpr int XW = HALF >= 4 ? 4 : HALF;  // x dwords fetched per LDS read
 #pragma unroll
             for (int q = 0; q < HALF / XW; ++q) {
-                // keep hipcc from hoisting every row's LDS reads + unpacks to the top (VGPR blow-up / spills)
-                __builtin_amdgcn_sched_barrier(0);
                 uint32_t xr[MB][XW];
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
@@ -214,14 +230,12 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
                 }
 #pragma unroll
                 for (int dd = 0; dd < XW; ++dd) {
-                    const int d = q * XW + dd;          // pair index inside the word
+                    const int d = q * XW + dd;            // pair index inside the word
                     const int win = d / WP, wi = d % WP;  // window, position in window
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) accx[m][wi] = TR::dot2(xr[m][dd], TR::ONES2, accx[m][wi]);
-#pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        // two 16-bit floats  OFF + q_d * 2^(NBITS*wi),  OFF + q_{d+HALF} * 2^(NBITS*wi)
-                        const uint32_t h = and_or(ck.w[i][j] >> (NBITS * WP * win), wmask[wi], magic);
+                        uint32_t h = (ck.w[i][j] >> (NBITS * WP * win)) & wmask[wi];
+                        if constexpr (!SUBN) h |= TR::MAGIC2;
 #pragma unroll
                         for (int m = 0; m < MB; ++m) acc[m][j] = TR::dot2(h, xr[m][dd], acc[m][j]);
                     }
@@ -231,32 +245,35 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
         f32x4 s = unpack4(ck.s), z = unpack4(ck.z);
         if (!need_s) s = (f32x4){1.f, 1.f, 1.f, 1.f};
         if (!need_z) z = (f32x4){scalar_zero, scalar_zero, scalar_zero, scalar_zero};
+        const int span0 = (row_rel * E) / 32;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            float xs_stored = 0.f, xs_true = 0.f;  // sum of stored x (for the OFF term), sum of real x
+            float xt = 0.f, xst = 0.f;  // sum of x over the run; sum of x as stored (magic-offset removal)
 #pragma unroll
-            for (int i = 0; i < WP; ++i) {
-                xs_stored += accx[m][i];
-                xs_true += accx[m][i] * (float)(1u << (NBITS * i));
+            for (int e2 = 0; e2 < RUN_SPANS; ++e2) {
+                xt += xsum_t[m * nspans + span0 + e2];
+                if constexpr (!SUBN) xst += xsum_s[m * nspans + span0 + e2];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float a = s[j];
+                const float a = s[j] * QSCALE;
                 const float b = bz * z[j] * (b_times_s ? s[j] : 1.f);
-                tot[m][j] += a * (acc[m][j] - TR::OFF * xs_stored) + b * xs_true;
+                float v = acc[m][j];
+                if constexpr (!SUBN) v -= TR::OFF * xst;
+                tot[m][j] += a * v + b * xt;
             }
         }
     };
 
-    if (nchunks == 1) {
-        compute(A, 0);
-    } else {
-        for (int ch = 0; ch < nchunks; ch += 2) {  // nchunks is even; the tail re-requests the last chunk (unused)
+    {
+        int ch = 0;
+        for (; ch + 2 <= nchunks; ch += 2) {  // the tail re-requests the last chunk (harmless, keeps the body uniform)
             compute(A, ch);
             load_chunk(A, ch + 2 < nchunks ? ch + 2 : nchunks - 1);
             compute(B, ch + 1);
             load_chunk(B, ch + 3 < nchunks ? ch + 3 : nchunks - 1);
         }
+        if (nchunks & 1) compute(A, nchunks - 1);
     }
 
     // ---- reduce over the G row sub-groups of the wave (lane bits CQ..5) --------------------------------
@@ -323,32 +340,34 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
 // ---------------------------------------------------------------------------------------------
 // host-side planning
 // ---------------------------------------------------------------------------------------------
+template <typename Tag, int NBITS, int MB, int R, int CQ>
+static const void* inst() {
+    // only the (bits, rows, tile) combinations the planner can pick are instantiated
+    constexpr bool used = (CQ == 2 && R == 4 && (NBITS == 4 || NBITS == 2)) ||
+                          (CQ == 3 && ((R == 4 && (NBITS == 4 || NBITS == 2)) || (R == 2 && NBITS == 2))) ||
+                          (CQ == 4 && ((R == 8 && NBITS == 8) || (R == 4 && (NBITS == 4 || NBITS == 2)) ||
+                                       (R == 2 && NBITS == 2) || (R == 1 && NBITS == 1)));
+    if constexpr (used && (R * (32 / NBITS)) % 32 == 0 && NBITS <= F16Traits<Tag>::MAX_QBITS) {
+        return (const void*)gemv_wn_kernel<Tag, NBITS, MB, R, CQ>;
+    } else {
+        return nullptr;
+    }
+}
 template <typename Tag, int NBITS, int MB>
 static const void* pick_shape(int cq, int r) {
-    if (cq == 2) {
-        if constexpr (NBITS == 4 || NBITS == 2) {
-            if (r == 8) return (const void*)gemv_wn_kernel<Tag, NBITS, MB, 8, 2>;
-        }
-        return nullptr;
+    if (cq == 2) return r == 4 ? inst<Tag, NBITS, MB, 4, 2>() : nullptr;
+    if (cq == 3) return r == 4 ? inst<Tag, NBITS, MB, 4, 3>() : (r == 2 ? inst<Tag, NBITS, MB, 2, 3>() : nullptr);
+    switch (r) {
+        case 8: return inst<Tag, NBITS, MB, 8, 4>();
+        case 4: return inst<Tag, NBITS, MB, 4, 4>();
+        case 2: return inst<Tag, NBITS, MB, 2, 4>();
+        case 1: return inst<Tag, NBITS, MB, 1, 4>();
+        default: return nullptr;
     }
-    if (cq == 3) {
-        if constexpr (NBITS == 4 || NBITS == 2) {
-            if (r == 4) return (const void*)gemv_wn_kernel<Tag, NBITS, MB, 4, 3>;
-            if (r == 2) return (const void*)gemv_wn_kernel<Tag, NBITS, MB, 2, 3>;
-        }
-        return nullptr;
-    }
-    if (r == 4) return (const void*)gemv_wn_kernel<Tag, NBITS, MB, 4, 4>;
-    if (r == 1) return (const void*)gemv_wn_kernel<Tag, NBITS, MB, 1, 4>;
-    return nullptr;
 }
 template <typename Tag, int NBITS>
 static const void* pick_mb(int mb, int cq, int r) {
-    switch (mb) {
-        case 1: return pick_shape<Tag, NBITS, 1>(cq, r);
-        case 2: return pick_shape<Tag, NBITS, 2>(cq, r);
-        default: return pick_shape<Tag, NBITS, 4>(cq, r);
-    }
+    return mb == 1 ? pick_shape<Tag, NBITS, 1>(cq, r) : nullptr;  // M >= 2 runs on the MFMA streaming kernel
 }
 template <typename Tag>
 static const void* pick_bits(int nbits, int mb, int cq, int r) {
@@ -356,9 +375,7 @@ static const void* pick_bits(int nbits, int mb, int cq, int r) {
         case 1: return pick_mb<Tag, 1>(mb, cq, r);
         case 2: return pick_mb<Tag, 2>(mb, cq, r);
         case 4: return pick_mb<Tag, 4>(mb, cq, r);
-        case 8:
-            if constexpr (F16Traits<Tag>::MAX_QBITS >= 8) return pick_mb<Tag, 8>(mb, cq, r);
-            return nullptr;
+        case 8: return pick_mb<Tag, 8>(mb, cq, r);
         default: return nullptr;
     }
 }
@@ -368,13 +385,14 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
     const int nbits = a.W_nbits;
     if (nbits != 1 && nbits != 2 && nbits != 4 && nbits != 8) return false;
     const int e = 32 / nbits;
-    if (a.M > 4 || a.K % e != 0) return false;  // M >= 5 goes to the MFMA streaming kernel (16-row tiles)
+    if (a.M > 1 || a.K % e != 0) return false;  // M >= 2 goes to the MFMA streaming kernel (16-row tiles)
     if (a.output_dtype != a.input_dtype) return false;  // typed epilogue
     const bool uses_s = a.W_group_mode >= 2 || a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
     const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
     if (uses_s && a.meta_dtype != a.input_dtype) return false;
     if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
     if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
+    if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0 || a.K % 32 != 0) return false;  // 16-byte x loads
     const int rows = (int)(a.K / e);
     const int64_t gs = p.group_size;
     if (gs % e != 0) return false;
@@ -384,16 +402,19 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
     auto try_plan = [&](int cq, int want_splitk) -> bool {
         const int tc = 4 << cq, G = 64 >> cq;
         if (a.N % tc != 0) return false;
-        int r;
-        if (cq == 2) {
-            r = 8;
-        } else if (cq == 3) {
-            r = (rpg % 4 == 0 && rows % (4 * G * 4) == 0) ? 4 : 2;
-        } else {
-            r = (rpg % 4 == 0 && rows % (4 * G * 4) == 0) ? 4 : 1;
-            if (nbits == 1) r = 1;  // register budget (16 x-dwords per packed row)
+        // rows per lane and step: must divide a group, cover whole 32-k spans of x, and fit the register budget
+        int r = 0;
+        const int cand[4] = {8, 4, 2, 1};
+        for (int ci = 0; ci < 4 && !r; ++ci) {
+            const int rr = cand[ci];
+            if (cq == 2 && rr != 4) continue;
+            if (cq == 3 && rr != 4 && rr != 2) continue;
+            if (rr == 8 && cq == 4 && nbits != 8) continue;       // 8 rows in flight only where they are needed
+            if (nbits == 1 && rr != 1) continue;                   // 16 x-dwords per packed row
+            if ((rr * e) % 32 != 0 || rpg % rr != 0 || rows % (4 * G * rr) != 0) continue;
+            r = rr;
         }
-        if (rpg % r != 0) return false;
+        if (!r) return false;
         const int block_rows = 4 * G * r;  // packed rows per block step
         if (rows % block_rows != 0) return false;
         const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r)
@@ -401,10 +422,8 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         if (!fn) return false;
         const int tiles = (int)(a.N / tc);
         const int units = rows / block_rows;  // max number of K slices
-        auto ok = [&](int sk) {  // slices must divide the steps, leave 1 or an even number of steps per wave,
-            if (sk < 1 || units % sk != 0) return false;  // and keep the LDS copy of x within 64 KiB
-            const int steps = units / sk;
-            if (!(steps == 1 || steps % 2 == 0)) return false;
+        auto ok = [&](int sk) {  // slices must divide the steps and keep the LDS copy of x within 64 KiB
+            if (sk < 1 || units % sk != 0) return false;
             return (int64_t)mb * (rows / sk) * e * 2 <= 65536;
         };
         int splitk = 0;
@@ -412,7 +431,7 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
             if (!ok(want_splitk)) return false;
             splitk = want_splitk;
         } else {
-            const int target = cq == 2 ? 1 : 384;  // narrow tiles exist to avoid the split
+            const int target = 256;  // >= one block per CU; beyond that the in-launch combine costs more than it buys
             for (int sk = 1; sk <= units; sk *= 2) {
                 if (!ok(sk)) continue;
                 splitk = sk;
@@ -427,7 +446,8 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         lp.name = cq == 2 ? "gemv_wn_kernel<tile16>" : (cq == 3 ? "gemv_wn_kernel<tile32>" : "gemv_wn_kernel<tile64>");
         lp.grid = dim3(tiles, splitk, 1);
         lp.block = dim3(256, 1, 1);
-        lp.lds_bytes = (size_t)mb * p.rows_per_slice * (e / 2) * 4 + (size_t)4 * mb * tc * 4 + 16;
+        lp.lds_bytes = (size_t)mb * p.rows_per_slice * (e / 2) * 4 + (size_t)2 * mb * (p.rows_per_slice * e / 32) * 4 +
+                       (size_t)4 * mb * tc * 4 + 16;
         lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * mb * tc * 4 : 0;
         lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
         return true;
@@ -436,8 +456,11 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
     // tuning[0]: 0 auto | 2 / 3 / 4 force 16- / 32- / 64-column tiles;  tuning[1]: 0 auto | n force split-K n
     const int force = a.tuning[0], sk = a.tuning[1];
     if (force >= 2 && force <= 4) return try_plan(force, sk);
-    // auto: 128-byte row segments (32-column tiles) stream best (scripts/ubench/readbw.hip); 64-column tiles when
-    // N is not a multiple of 32 columns... and 16-column tiles only when that is what makes the shape fit
+    // auto (measured, profiles/r01_*): the widest tile that still gives >= 256 blocks WITHOUT splitting K wins —
+    // 256-byte row segments stream best, 64-byte ones worst, but any in-launch split-K combine costs ~3 us.
+    if (a.N % 64 == 0 && a.N / 64 >= 256 && try_plan(4, sk > 0 ? sk : 1)) return true;
+    if (a.N % 32 == 0 && a.N / 32 >= 256 && try_plan(3, sk > 0 ? sk : 1)) return true;
+    if (a.N % 16 == 0 && a.N / 16 >= 256 && try_plan(2, sk > 0 ? sk : 1)) return true;
     if (try_plan(3, sk)) return true;
     if (try_plan(4, sk)) return true;
     return try_plan(2, sk);

@@ -231,6 +231,24 @@ __device__ __forceinline__ void store_out_t(const Epilogue& e, float v, int64_t 
     ((uint16_t*)e.out)[m * e.stride_om + n] = TR::from_float(v);
 }
 
+// 4 consecutive outputs of one row: channel scaling, cast, one 8-byte store (n0 multiple of 4)
+template <typename Tag>
+__device__ __forceinline__ void store_out4_t(const Epilogue& e, f32x4 v, int64_t m, int64_t n0) {
+    using TR = F16Traits<Tag>;
+    if (e.c_mode == 1 || e.c_mode == 3) {
+        const f32x4 sw = load4_t<Tag>(e.scales_w, n0);
+        v *= sw;
+    }
+    if (e.c_mode == 2 || e.c_mode == 3) {
+        const float sx = e.scales_x[m * e.stride_sx_m];
+        v *= (f32x4){sx, sx, sx, sx};
+    }
+    u32x2 o;
+    o[0] = (uint32_t)TR::from_float(v[0]) | ((uint32_t)TR::from_float(v[1]) << 16);
+    o[1] = (uint32_t)TR::from_float(v[2]) | ((uint32_t)TR::from_float(v[3]) << 16);
+    *(u32x2*)((uint16_t*)e.out + m * e.stride_om + n0) = o;
+}
+
 // dequant of an integer code q (as float) for W_group_mode (triton_kernels/utils.py:73-87),
 // evaluated in fp32 on the stored scale / zero
 __device__ __forceinline__ float dequant_f32(float q, float s, float z, int w_mode) {

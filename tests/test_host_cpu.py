@@ -73,15 +73,20 @@ def test_struct_abi_and_validation():
 
 
 @pytest.mark.parametrize("kw,kernel", [
-    (dict(M=1), "gemv_wn_kernel<tile32>"),            # cfgA: 128 tiles of 32 columns (128-byte row segments)
-    (dict(M=1, in_dt=2), "gemv_wn_kernel<tile32>"),
-    (dict(M=4), "gemv_wn_kernel<tile32>"),
-    (dict(M=8), "gemm_wn_stream_kernel"),             # M >= 5: MFMA streaming kernel
-    (dict(M=1, nbits=2), "gemv_wn_kernel<tile32>"),
+    (dict(M=1), "gemv_wn_kernel<tile16>"),            # cfgA: 256 tiles of 16 columns, K not split
+    (dict(M=1, in_dt=2), "gemv_wn_kernel<tile16>"),
+    (dict(M=1, N=8192, K=8192), "gemv_wn_kernel<tile32>"),
+    (dict(M=1, N=16384, K=16384), "gemv_wn_kernel<tile64>"),
+    (dict(M=2), "gemm_wn_stream_kernel"),             # M >= 2: MFMA streaming kernel
+    (dict(M=8), "gemm_wn_stream_kernel"),
+    (dict(M=1, nbits=2), "gemv_wn_kernel<tile16>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
-    (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile32>"),
+    (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64>"),
     (dict(M=16), "gemm_wn_stream_kernel"),
-    (dict(M=1, mt=4), "gemm_wn_stream_kernel"),      # manual GEMM family at M=1 -> an MFMA kernel
+    (dict(M=1, mt=4), "gemm_w4_tiled_kernel"),       # manual GEMM family at M=1 -> the tiled MFMA kernel
+    (dict(M=256), "gemm_w4_tiled_kernel"),
+    (dict(M=256, N=8192, K=8192, in_dt=2), "gemm_w4_tiled_kernel"),
+    (dict(M=256, nbits=2), "gemm_wn_stream_kernel"),  # 2-bit: streaming kernel with row tiles
     (dict(M=4, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
     (dict(M=1, N=1000), "generic_matmul_kernel"),    # N not a multiple of 64
