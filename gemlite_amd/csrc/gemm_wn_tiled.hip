@@ -73,21 +73,24 @@ struct Deq2<bf16_tag> {
     }
 };
 
-constexpr int TBM = 128, TBN = 128, TBK = 64;
-constexpr int A_BUF_BYTES = TBM * TBK * 2;  // 16 KiB
-constexpr int C_PITCH = TBN + 4;            // floats per row of the epilogue tile (16-byte aligned, conflict-free)
+constexpr int TBN = 128, TBK = 64;
+constexpr int C_ROWS = 128;                 // rows of the epilogue staging tile (processed per 128-row half)
+constexpr int C_PITCH = TBN + 4;            // floats per row of that tile (16-byte aligned, conflict-free)
 
 // byte offset of the 16-byte slot (row r, slot s of 8) inside an A buffer: XOR swizzle on (r >> 1)
 __device__ __forceinline__ int a_slot(int r, int s) { return r * (TBK * 2) + ((s ^ ((r >> 1) & 7)) << 4); }
 
-template <typename Tag>
-__global__ __launch_bounds__(256, 2) void gemm_w4_tiled_kernel(const WnParams p) {
+// MI = 32-row blocks per wave: tile = (32*MI) x 128, 4 waves, wave w owns all rows x columns [32w, 32w+32)
+template <typename Tag, int MI>
+__global__ __launch_bounds__(256, (MI <= 4 ? 2 : 1)) void gemm_w4_tiled_kernel(const WnParams p) {
     using TR = F16Traits<Tag>;
+    constexpr int TBM = 32 * MI;
+    constexpr int A_BUF_BYTES = TBM * TBK * 2;
+    constexpr int SLOTS = TBM * 8 / 256;  // 16-byte A slots staged per thread and K step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][A_BUF_BYTES], later the C tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, kb = lane >> 5;
-    const int ntile_n = p.N / TBN;
     // tile order: consecutive blocks share the same column tile (B reuse in L2), M tiles fastest
     const int mtiles = (p.M + TBM - 1) / TBM;
     const int bid = blockIdx.x;
@@ -95,7 +98,6 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_tiled_kernel(const WnParams p)
     const int slice = blockIdx.y;
     const int m0 = mt * TBM;
     const int n = nt * TBN + wave * 32 + col;  // this lane's column
-    (void)ntile_n;
 
     const int ksteps = p.rows_per_slice / (TBK / 8);       // K steps of 64 in this slice (rows_per_slice packed rows)
     const int row_s0 = slice * p.rows_per_slice;           // first packed row of the slice
@@ -120,41 +122,41 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_tiled_kernel(const WnParams p)
         b.s = sp[grp * ms + n];
         b.z = zp[grp * ms + n];
     };
-    // ---- A stream: 128 rows x 64 k per step = 1024 16-byte slots, 4 per thread ---------------------------------
+    // ---- A stream: TBM rows x 64 k per step = TBM*8 16-byte slots, SLOTS per thread ---------------------------
     const uint16_t* xg = (const uint16_t*)p.x;
-    struct AStep { u32x4 v[4]; };
-    const uint16_t* xrow[4];  // this thread's 4 staging rows (clamped: rows >= M are zeroed after the load)
+    struct AStep { u32x4 v[SLOTS]; };
+    const uint16_t* xrow[SLOTS];  // this thread's staging rows (clamped: rows >= M are zeroed after the load)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < SLOTS; ++i) {
         const int u = tid + 256 * i, r = u >> 3, s = u & 7;
         const int rr = m0 + r < p.M ? m0 + r : p.M - 1;
         xrow[i] = xg + (int64_t)rr * p.stride_xm + k_s0 + s * 8;
     }
     auto load_a = [&](AStep& a, int step) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < SLOTS; ++i) {
             a.v[i] = *(const u32x4*)(xrow[i] + step * TBK);
             if (m0 + ((tid + 256 * i) >> 3) >= p.M) a.v[i] = (u32x4){0u, 0u, 0u, 0u};
         }
     };
     auto put_a = [&](const AStep& a, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < SLOTS; ++i) {
             const int u = tid + 256 * i, r = u >> 3, s = u & 7;
             // 8 halfs x0..x7 -> pairs (x0,x4)(x1,x5)(x2,x6)(x3,x7): the k order of the unpacked B fragment
             const uint32_t d0 = a.v[i][0], d1 = a.v[i][1], d2 = a.v[i][2], d3 = a.v[i][3];
             u32x4 o;
-            o[0] = (d0 & 0xFFFFu) | (d2 << 16);
-            o[1] = (d0 >> 16) | (d2 & 0xFFFF0000u);
-            o[2] = (d1 & 0xFFFFu) | (d3 << 16);
-            o[3] = (d1 >> 16) | (d3 & 0xFFFF0000u);
+            o[0] = __builtin_amdgcn_perm(d2, d0, 0x05040100u);  // (x0, x4)
+            o[1] = __builtin_amdgcn_perm(d2, d0, 0x07060302u);  // (x1, x5)
+            o[2] = __builtin_amdgcn_perm(d3, d1, 0x05040100u);  // (x2, x6)
+            o[3] = __builtin_amdgcn_perm(d3, d1, 0x07060302u);  // (x3, x7)
             *(u32x4*)(smem + buf * A_BUF_BYTES + a_slot(r, s)) = o;
         }
     };
 
-    f32x16 acc[4];
+    f32x16 acc[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
@@ -165,12 +167,11 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_tiled_kernel(const WnParams p)
     for (int ks = 0; ks < 4; ++ks) a_off[ks] = a_slot(col, ks * 2 + kb);
     auto compute = [&](const BStep& b, int buf) {
         const unsigned char* abase = smem + buf * A_BUF_BYTES;
-        // all 16 A fragments of the K step are requested up front: their LDS latency overlaps the dequant VALU work
-        u32x4 af[4][4];
+        // the A fragments of k-step pair (0,1) are requested before the dequant VALU work, pair (2,3) before the
+        // first MFMAs: LDS latency hides behind VALU / MFMA instead of stalling each MFMA
+        u32x4 af[2][MI];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[ks][mi] = *(const u32x4*)(abase + mi * 32 * (TBK * 2) + a_off[ks]);
+        for (int mi = 0; mi < MI; ++mi) af[0][mi] = *(const u32x4*)(abase + mi * 32 * (TBK * 2) + a_off[0]);
         float s = need_s ? TR::to_float(b.s) : 1.f;
         float z = need_z ? TR::to_float(b.z) : scalar_zero;
         dq.set(s, z, p.w_mode);
@@ -183,9 +184,15 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_tiled_kernel(const WnParams p)
                 bfrag[ks][dd] = dq.apply(h, p.w_mode);
             }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma32<Tag>(af[ks][mi], bfrag[ks], acc[mi]);
+                for (int mi = 0; mi < MI; ++mi)
+                    af[(ks + 1) & 1][mi] = *(const u32x4*)(abase + mi * 32 * (TBK * 2) + a_off[ks + 1]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma32<Tag>(af[ks & 1][mi], bfrag[ks], acc[mi]);
+        }
     };
 
     BStep B0, B1;
@@ -213,50 +220,62 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_tiled_kernel(const WnParams p)
     }
 
     // ---- epilogue.  C fragment of a 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
-    // The tile is transposed through LDS so that slabs and the output move as 16-byte row segments (4-byte
-    // write-through stores are ~6x slower per byte: MI355X_MICROARCH.md "stores of each flavour").
-    __syncthreads();  // all waves are done with the A buffers
-    float* ct = (float*)smem;  // [TBM][C_PITCH]
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kb;
-            ct[r * C_PITCH + wave * 32 + col] = acc[mi][e];
-        }
-    __syncthreads();
+    // The tile is transposed through LDS (128 rows at a time) so that slabs and the output move as 16-byte row
+    // segments (4-byte write-through stores are ~10x slower: MI355X_MICROARCH.md "stores of each flavour").
+    float* ct = (float*)smem;  // [C_ROWS][C_PITCH]
+    unsigned* flag = (unsigned*)(smem + C_ROWS * C_PITCH * 4);
     const int tile_lin = bid;
-    constexpr int UNITS = TBM * TBN / 4 / 256;  // float4 units per thread
-    const int64_t ncol0 = (int64_t)nt * TBN;
-    if (p.splitk == 1) {
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            const int u = tid + 256 * i, r = u >> 5, c4 = (u & 31) * 4;
-            if (m0 + r < p.M) store_out4_t<Tag>(p.epi, *(const f32x4*)(ct + r * C_PITCH + c4), m0 + r, ncol0 + c4);
-        }
-        return;
-    }
+    constexpr int UNITS = C_ROWS * TBN / 4 / 256;  // float4 units per thread and 128-row half
     constexpr int NOUT = TBM * TBN;
+    const int64_t ncol0 = (int64_t)nt * TBN;
     float* slab = p.slabs + ((int64_t)tile_lin * p.splitk) * NOUT;  // wave-uniform base of this tile's slabs
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < UNITS; ++i) {
-        const int u = tid + 256 * i, r = u >> 5, c4 = (u & 31) * 4;
-        if (m0 + r < p.M) {
-            const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (slice * NOUT + r * TBN + c4) * 4, 0, 16);  // sc1
+    for (int half = 0; half < MI / 4; ++half) {
+        __syncthreads();  // A buffers (or the previous half) are no longer read
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kb;
+                ct[r * C_PITCH + wave * 32 + col] = acc[half * 4 + mi][e];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 256 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + half * C_ROWS + r;
+            if (m < p.M) {
+                const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
+                if (p.splitk == 1) store_out4_t<Tag>(p.epi, v, m, ncol0 + c4);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                            (slice * NOUT + (half * C_ROWS + r) * TBN + c4) * 4, 0, 16);  // sc1
+            }
         }
     }
-    unsigned* flag = (unsigned*)(smem + TBM * C_PITCH * 4);
+    if (p.splitk == 1) return;
+    __syncthreads();
     if (!splitk_arrive_is_last(p.counters + tile_lin, p.splitk, flag)) return;
+    // last arriver: slices outer, units inner -> every slice's 16-byte loads are in flight together
+    for (int half = 0; half < MI / 4; ++half) {
+        f32x4 sum[UNITS];
 #pragma unroll
-    for (int i = 0; i < UNITS; ++i) {
-        const int u = tid + 256 * i, r = u >> 5, c4 = (u & 31) * 4;
-        if (m0 + r < p.M) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < p.splitk; ++s)
-                v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (s * NOUT + r * TBN + c4) * 4, 0, 16));
-            store_out4_t<Tag>(p.epi, v, m0 + r, ncol0 + c4);
+        for (int i = 0; i < UNITS; ++i) sum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.splitk; ++s) {
+            u32x4 t[UNITS];
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) {
+                const int u = tid + 256 * i, r = u >> 5, c4 = (u & 31) * 4;
+                t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (s * NOUT + (half * C_ROWS + r) * TBN + c4) * 4, 0, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) sum[i] += __builtin_bit_cast(f32x4, t[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 256 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + half * C_ROWS + r;
+            if (m < p.M) store_out4_t<Tag>(p.epi, sum[i], m, ncol0 + c4);
         }
     }
     if (tid == 0) splitk_reset(p.counters + tile_lin);
@@ -276,7 +295,12 @@ bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPl
     if (p.group_size % TBK != 0) return false;  // one (scale, zero) pair per column and K step
     const int rows = (int)(a.K / 8), step_rows = TBK / 8;
     const int units = rows / step_rows;
-    const int64_t tiles = (int64_t)(a.N / TBN) * ((a.M + TBM - 1) / TBM);
+    // tuning[2]: 0 auto | 4 / 8 = 32-row blocks per wave (128- / 256-row tiles).  256-row tiles halve the dequant and
+    // staging work per flop but run at one wave per SIMD; measured slower than two 128-row blocks per CU
+    // (profiles/r01_run12_bench_sweep.jsonl), so 128-row tiles are the default.
+    int mi = a.tuning[2] == 8 ? 8 : 4;
+    const int tbm = 32 * mi;
+    const int64_t tiles = (int64_t)(a.N / TBN) * ((a.M + tbm - 1) / tbm);
     auto ok = [&](int sk) { return sk >= 1 && units % sk == 0; };
     int splitk = 0;
     if (a.tuning[1] > 0) {
@@ -286,20 +310,23 @@ bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPl
         for (int sk = 1; sk <= units && sk <= 16; sk *= 2) {
             if (!ok(sk)) continue;
             splitk = sk;
-            if (tiles * sk >= 256) break;
+            if (tiles * sk >= 512) break;  // two blocks per CU: one wave's VALU overlaps the other's MFMAs
         }
         if (!splitk) return false;
     }
     if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
+    if ((uint64_t)splitk * tbm * TBN * 4 >= (1ull << 31)) return false;  // buffer descriptor range
     p.splitk = splitk;
     p.rows_per_slice = rows / splitk;
-    lp.fn = a.input_dtype == GEMLITE_DT_FP16 ? (const void*)gemm_w4_tiled_kernel<half_tag>
-                                              : (const void*)gemm_w4_tiled_kernel<bf16_tag>;
+    const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
+    lp.fn = mi == 8 ? (f16 ? (const void*)gemm_w4_tiled_kernel<half_tag, 8> : (const void*)gemm_w4_tiled_kernel<bf16_tag, 8>)
+                    : (f16 ? (const void*)gemm_w4_tiled_kernel<half_tag, 4> : (const void*)gemm_w4_tiled_kernel<bf16_tag, 4>);
     lp.name = "gemm_w4_tiled_kernel";
     lp.grid = dim3((unsigned)tiles, splitk, 1);
     lp.block = dim3(256, 1, 1);
-    lp.lds_bytes = (size_t)TBM * C_PITCH * 4 + 16;  // the epilogue tile (66 KiB) is larger than the two A buffers
-    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * TBM * TBN * 4 : 0;
+    const size_t a_b = (size_t)2 * tbm * TBK * 2, c_b = (size_t)C_ROWS * C_PITCH * 4 + 16;
+    lp.lds_bytes = a_b > c_b ? a_b : c_b;
+    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * tbm * TBN * 4 : 0;
     lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
     return true;
 }
