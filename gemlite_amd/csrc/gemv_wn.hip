@@ -49,7 +49,11 @@ struct Window {
     static constexpr int WP = fit();  // pairs per window
 };
 
-template <typename Tag, int NBITS, int MB, int R, int CQ>
+// XD ("x direct", 4-bit only): x is not staged in LDS; every lane loads the 16 bytes of x that belong to each of
+// its packed rows straight from global memory (L1/L2 hits, requested together with the weights) and pairs /
+// pre-scales them in registers (4 v_perm + 2 v_pk_mul + 4 v_dot2 per row).  This removes the x -> LDS -> barrier
+// prologue from the critical path of short K slices (decode shapes such as 4096 x 4096).
+template <typename Tag, int NBITS, int MB, int R, int CQ, bool XD = false>
 __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1 : 2)) void gemv_wn_kernel(const WnParams p) {
     using TR = F16Traits<Tag>;
     using WN = Window<Tag, NBITS>;
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     constexpr int TC = 4 << CQ;      // tile columns
     constexpr int RUN_SPANS = R * E / 32;  // 32-k spans of x covered by a lane's run of R rows
     static_assert(R * E % 32 == 0, "a run of rows must cover whole 32-k spans of x");
+    static_assert(!XD || (NBITS == 4 && MB == 1), "direct x loads: one 16-byte x chunk per packed row");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,10 +103,15 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     const int64_t mstride = (need_s || need_z) ? p.stride_meta_g : 0;
     const uint32_t* wbase = p.w + (int64_t)(row_s0 + row_w0 + g * R) * p.stride_wk + n0;
     const int nchunks = rows_wave / CHUNK;  // 1, or even (planner)
-    struct Chunk { u32x4 w[R]; u32x2 s, z; };
+    struct Chunk { u32x4 w[R]; u32x2 s, z; u32x4 x[XD ? R : 1]; };
+    const uint16_t* xg = (const uint16_t*)p.x;
     auto load_chunk = [&](Chunk& ck, int chunk) {
         const int row = row_s0 + row_w0 + chunk * CHUNK + g * R;
         const int64_t grp = ((int64_t)row * E) / p.group_size;
+        if constexpr (XD) {  // x first: it is the cheaper (cached) request and is needed together with w
+#pragma unroll
+            for (int i = 0; i < R; ++i) ck.x[i] = *(const u32x4*)(xg + (int64_t)(row + i) * E);
+        }
 #pragma unroll
         for (int i = 0; i < R; ++i) ck.w[i] = *(const u32x4*)(wbase + (int64_t)(chunk * CHUNK + i) * p.stride_wk);
         ck.s = *(const u32x2*)(sp + grp * mstride + n0);
@@ -110,7 +120,6 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
 
     // ---- x[k-slice] -> LDS.  task = (row m, 32-k span): 64 bytes in, 16 pair-permuted / pre-scaled dwords and
     //      the span sums out.  The first task's loads are issued AHEAD of the weight stream. ---------------------
-    const uint16_t* xg = (const uint16_t*)p.x;
     const int64_t k0 = (int64_t)row_s0 * E;
     const int ntasks = MB * nspans;
     auto fetch_x = [&](u32x4 (&v)[4], int task) {
@@ -167,7 +176,10 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     };
 
     Chunk A, B;
-    {
+    if constexpr (XD) {
+        load_chunk(A, 0);
+        if (nchunks > 1) load_chunk(B, 1);
+    } else {
         u32x4 xv[4];
         fetch_x(xv, tid);
         load_chunk(A, 0);
@@ -177,8 +189,8 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
             fetch_x(xv, task);
             put_x(xv, task);
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     float tot[MB][4];
 #pragma unroll
@@ -207,6 +219,7 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     auto compute = [&](const Chunk& ck, int chunk) {
         const int row_rel = row_w0 + chunk * CHUNK + g * R;  // first of this lane's R rows (slice-relative)
         float acc[MB][4];
+        float xd_sum = 0.f;  // XD: sum of the run's true x
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -217,6 +230,26 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
 #pragma unroll
             for (int q = 0; q < HALF / XW; ++q) {
                 uint32_t xr[MB][XW];
+                if constexpr (XD) {
+                    // natural (x0x1)(x2x3)(x4x5)(x6x7) -> pairs (x0,x4)(x1,x5)(x2,x6)(x3,x7); run sums on the TRUE x,
+                    // then the window pre-scale (fp16: odd pairs * 2^-4, exact)
+                    const uint32_t d0 = ck.x[i][0], d1 = ck.x[i][1], d2 = ck.x[i][2], d3 = ck.x[i][3];
+                    xr[0][0] = __builtin_amdgcn_perm(d2, d0, 0x05040100u);
+                    xr[0][1] = __builtin_amdgcn_perm(d2, d0, 0x07060302u);
+                    xr[0][2] = __builtin_amdgcn_perm(d3, d1, 0x05040100u);
+                    xr[0][3] = __builtin_amdgcn_perm(d3, d1, 0x07060302u);
+#pragma unroll
+                    for (int dd = 0; dd < 4; ++dd) xd_sum = TR::dot2(xr[0][dd], TR::ONES2, xd_sum);
+                    if constexpr (WP > 1) {
+#pragma unroll
+                        for (int dd = 0; dd < 4; ++dd)
+                            if (dd % WP) {
+                                const h2_t v = __builtin_bit_cast(h2_t, xr[0][dd]) *
+                                               (h2_t){(_Float16)(1.0f / (1 << (NBITS * (dd % WP)))), (_Float16)(1.0f / (1 << (NBITS * (dd % WP))))};
+                                xr[0][dd] = __builtin_bit_cast(uint32_t, v);
+                            }
+                    }
+                } else
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
                     const uint32_t* src = xs + m * pairs + (row_rel + i) * HALF + q * XW;
@@ -249,10 +282,15 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             float xt = 0.f, xst = 0.f;  // sum of x over the run; sum of x as stored (magic-offset removal)
+            if constexpr (XD) {
+                xt = xd_sum;
+                xst = xd_sum;  // bf16 has one 4-bit field per window: stored x == x
+            } else {
 #pragma unroll
-            for (int e2 = 0; e2 < RUN_SPANS; ++e2) {
-                xt += xsum_t[m * nspans + span0 + e2];
-                if constexpr (!SUBN) xst += xsum_s[m * nspans + span0 + e2];
+                for (int e2 = 0; e2 < RUN_SPANS; ++e2) {
+                    xt += xsum_t[m * nspans + span0 + e2];
+                    if constexpr (!SUBN) xst += xsum_s[m * nspans + span0 + e2];
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -340,7 +378,7 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
 // ---------------------------------------------------------------------------------------------
 // host-side planning
 // ---------------------------------------------------------------------------------------------
-template <typename Tag, int NBITS, int MB, int R, int CQ>
+template <typename Tag, int NBITS, int MB, int R, int CQ, bool XD = false>
 static const void* inst() {
     // only the (bits, rows, tile) combinations the planner can pick are instantiated
     constexpr bool used = (CQ == 2 && R == 4 && (NBITS == 4 || NBITS == 2)) ||
@@ -348,13 +386,21 @@ static const void* inst() {
                           (CQ == 4 && ((R == 8 && NBITS == 8) || (R == 4 && (NBITS == 4 || NBITS == 2)) ||
                                        (R == 2 && NBITS == 2) || (R == 1 && NBITS == 1)));
     if constexpr (used && (R * (32 / NBITS)) % 32 == 0 && NBITS <= F16Traits<Tag>::MAX_QBITS) {
-        return (const void*)gemv_wn_kernel<Tag, NBITS, MB, R, CQ>;
+        return (const void*)gemv_wn_kernel<Tag, NBITS, MB, R, CQ, XD>;
     } else {
         return nullptr;
     }
 }
 template <typename Tag, int NBITS, int MB>
-static const void* pick_shape(int cq, int r) {
+static const void* pick_shape(int cq, int r, bool xd) {
+    if (xd) {  // direct-x variants exist for 4-bit, 4 rows per lane
+        if constexpr (NBITS == 4 && MB == 1) {
+            if (r != 4) return nullptr;
+            return cq == 2 ? inst<Tag, 4, 1, 4, 2, true>() : (cq == 3 ? inst<Tag, 4, 1, 4, 3, true>() : inst<Tag, 4, 1, 4, 4, true>());
+        } else {
+            return nullptr;
+        }
+    }
     if (cq == 2) return r == 4 ? inst<Tag, NBITS, MB, 4, 2>() : nullptr;
     if (cq == 3) return r == 4 ? inst<Tag, NBITS, MB, 4, 3>() : (r == 2 ? inst<Tag, NBITS, MB, 2, 3>() : nullptr);
     switch (r) {
@@ -366,16 +412,16 @@ static const void* pick_shape(int cq, int r) {
     }
 }
 template <typename Tag, int NBITS>
-static const void* pick_mb(int mb, int cq, int r) {
-    return mb == 1 ? pick_shape<Tag, NBITS, 1>(cq, r) : nullptr;  // M >= 2 runs on the MFMA streaming kernel
+static const void* pick_mb(int mb, int cq, int r, bool xd) {
+    return mb == 1 ? pick_shape<Tag, NBITS, 1>(cq, r, xd) : nullptr;  // M >= 2 runs on the MFMA streaming kernel
 }
 template <typename Tag>
-static const void* pick_bits(int nbits, int mb, int cq, int r) {
+static const void* pick_bits(int nbits, int mb, int cq, int r, bool xd) {
     switch (nbits) {
-        case 1: return pick_mb<Tag, 1>(mb, cq, r);
-        case 2: return pick_mb<Tag, 2>(mb, cq, r);
-        case 4: return pick_mb<Tag, 4>(mb, cq, r);
-        case 8: return pick_mb<Tag, 8>(mb, cq, r);
+        case 1: return pick_mb<Tag, 1>(mb, cq, r, xd);
+        case 2: return pick_mb<Tag, 2>(mb, cq, r, xd);
+        case 4: return pick_mb<Tag, 4>(mb, cq, r, xd);
+        case 8: return pick_mb<Tag, 8>(mb, cq, r, xd);
         default: return nullptr;
     }
 }
@@ -417,9 +463,6 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         if (!r) return false;
         const int block_rows = 4 * G * r;  // packed rows per block step
         if (rows % block_rows != 0) return false;
-        const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r)
-                                                           : pick_bits<bf16_tag>(nbits, mb, cq, r);
-        if (!fn) return false;
         const int tiles = (int)(a.N / tc);
         const int units = rows / block_rows;  // max number of K slices
         auto ok = [&](int sk) {  // slices must divide the steps and keep the LDS copy of x within 64 KiB
@@ -440,10 +483,22 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
             if (!splitk) return false;
         }
         if (tiles > MAX_SPLITK_COUNTERS && splitk > 1) return false;
+        // tuning[3]: 0 auto | 1 stage x in LDS | 2 load x directly.  Direct x pays when a wave has <= 2 steps.
+        const int steps = units / splitk;
+        bool xd = nbits == 4 && mb == 1 && r == 4 && (a.tuning[3] == 2 || (a.tuning[3] == 0 && steps <= 2));
+        const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, xd)
+                                                           : pick_bits<bf16_tag>(nbits, mb, cq, r, xd);
+        if (!fn && xd) {
+            xd = false;
+            fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, false)
+                                                  : pick_bits<bf16_tag>(nbits, mb, cq, r, false);
+        }
+        if (!fn) return false;
         p.splitk = splitk;
         p.rows_per_slice = rows / splitk;
         lp.fn = fn;
-        lp.name = cq == 2 ? "gemv_wn_kernel<tile16>" : (cq == 3 ? "gemv_wn_kernel<tile32>" : "gemv_wn_kernel<tile64>");
+        lp.name = xd ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect>" : (cq == 3 ? "gemv_wn_kernel<tile32,xdirect>" : "gemv_wn_kernel<tile64,xdirect>"))
+                     : (cq == 2 ? "gemv_wn_kernel<tile16>" : (cq == 3 ? "gemv_wn_kernel<tile32>" : "gemv_wn_kernel<tile64>"));
         lp.grid = dim3(tiles, splitk, 1);
         lp.block = dim3(256, 1, 1);
         lp.lds_bytes = (size_t)mb * p.rows_per_slice * (e / 2) * 4 + (size_t)2 * mb * (p.rows_per_slice * e / 32) * 4 +

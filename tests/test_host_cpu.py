@@ -73,8 +73,8 @@ def test_struct_abi_and_validation():
 
 
 @pytest.mark.parametrize("kw,kernel", [
-    (dict(M=1), "gemv_wn_kernel<tile16>"),            # cfgA: 256 tiles of 16 columns, K not split
-    (dict(M=1, in_dt=2), "gemv_wn_kernel<tile16>"),
+    (dict(M=1), "gemv_wn_kernel<tile16,xdirect>"),    # cfgA: 256 tiles of 16 columns, K not split, x from L2
+    (dict(M=1, in_dt=2), "gemv_wn_kernel<tile16,xdirect>"),
     (dict(M=1, N=8192, K=8192), "gemv_wn_kernel<tile32>"),
     (dict(M=1, N=16384, K=16384), "gemv_wn_kernel<tile64>"),
     (dict(M=2), "gemm_wn_stream_kernel"),             # M >= 2: MFMA streaming kernel
