@@ -111,16 +111,12 @@ def main():
     ap.add_argument("--matmul-type", default="", help="development: force a kernel family (forward_manual)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    from gemlite_amd.bench_utils import ReplicaGroup, timed_steps, whole_job_rate
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL; used only for the timing barrier / max-reduce
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    group = ReplicaGroup("nccl")  # RCCL; used only for the timing barrier / max-reduce (replicas, no data exchange)
+    world, rank = group.world, group.rank
 
     from gemlite_amd import _hip
     lib = _hip.load()  # fails loudly if the HIP library is missing
@@ -159,25 +155,7 @@ def main():
             with torch.cuda.stream(stream):
                 step_eager()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        run_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(group, run_step, args.steps, args.warmup, device_sync=torch.cuda.synchronize, device=device)
 
     launches = args.steps * layers
     bytes_per_launch = algorithmic_bytes(M, N, K, nbits, group)
@@ -207,13 +185,13 @@ def main():
     gap_us = elapsed / launches * 1e6
     if bound == "hbm":
         unit, peak = "GB/s", HBM_PEAK_GBS
-        value = world * launches * bytes_per_launch / elapsed / 1e9
+        value = whole_job_rate(layers * bytes_per_launch, args.steps, world, elapsed) / 1e9
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9 if kernel_us == kernel_us else bytes_per_launch / (gap_us * 1e-6) / 1e9
         gap_incl = bytes_per_launch / (gap_us * 1e-6) / 1e9
         metric = "HBM GB/s (algorithmic bytes) vs roofline, A16W4 gs=128 4096x4096 M=1"
     else:
         unit, peak = "TFLOP/s", MFMA_PEAK_TFLOPS
-        value = world * launches * flops_per_launch / elapsed / 1e12
+        value = whole_job_rate(layers * flops_per_launch, args.steps, world, elapsed) / 1e12
         achieved = flops_per_launch / (kernel_us * 1e-6) / 1e12 if kernel_us == kernel_us else flops_per_launch / (gap_us * 1e-6) / 1e12
         gap_incl = flops_per_launch / (gap_us * 1e-6) / 1e12
         metric = "TFLOP/s vs bf16 MFMA roofline, A16W4 gs=128 M=256"
@@ -251,8 +229,7 @@ def main():
                                           f"M={M}, {sec * 1e3:.2f} ms/call"}
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":
