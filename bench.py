@@ -115,8 +115,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    group = ReplicaGroup("nccl")  # RCCL; used only for the timing barrier / max-reduce (replicas, no data exchange)
-    world, rank = group.world, group.rank
+    rgroup = ReplicaGroup("nccl")  # RCCL; used only for the timing barrier / max-reduce (replicas, no data exchange)
+    world, rank = rgroup.world, rgroup.rank
 
     from gemlite_amd import _hip
     lib = _hip.load()  # fails loudly if the HIP library is missing
@@ -155,7 +155,7 @@ def main():
             with torch.cuda.stream(stream):
                 step_eager()
 
-    elapsed = timed_steps(group, run_step, args.steps, args.warmup, device_sync=torch.cuda.synchronize, device=device)
+    elapsed = timed_steps(rgroup, run_step, args.steps, args.warmup, device_sync=torch.cuda.synchronize, device=device)
 
     launches = args.steps * layers
     bytes_per_launch = algorithmic_bytes(M, N, K, nbits, group)
@@ -229,7 +229,7 @@ def main():
                                           f"M={M}, {sec * 1e3:.2f} ms/call"}
     if rank == 0:
         print(json.dumps(line), flush=True)
-    group.close()
+    rgroup.close()
 
 
 if __name__ == "__main__":

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     const uint16_t* xg = (const uint16_t*)p.x;
     auto load_chunk = [&](Chunk& ck, int chunk) {
         const int row = row_s0 + row_w0 + chunk * CHUNK + g * R;
-        const int64_t grp = ((int64_t)row * E) / p.group_size;
+        const int64_t grp = group_of(row * E, p.group_size, p.gs_shift);
         if constexpr (XD) {  // x first: it is the cheaper (cached) request and is needed together with w
 #pragma unroll
             for (int i = 0; i < R; ++i) ck.x[i] = *(const u32x4*)(xg + (int64_t)(row + i) * E);
@@ -175,6 +175,13 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
         xsum_s[task] = sum_s;
     };
 
+    // opt-in timeline (tuning[3] & 4, needs a workspace): lane 0 of every wave of block (0,0) stores s_memtime stamps
+    const bool probe = (p.flags & 4) && p.counters && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0;
+    unsigned long long* stamps = (unsigned long long*)(p.counters + 4096) + wave * 16;
+    auto stamp = [&](int i) {
+        if (probe) stamps[i] = __builtin_readcyclecounter();
+    };
+    stamp(0);
     Chunk A, B;
     if constexpr (XD) {
         load_chunk(A, 0);
@@ -192,6 +199,7 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
         __syncthreads();
     }
 
+    stamp(1);  // loads issued (and, without XD, x staged + barrier passed)
     float tot[MB][4];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -307,12 +315,14 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
         int ch = 0;
         for (; ch + 2 <= nchunks; ch += 2) {  // the tail re-requests the last chunk (harmless, keeps the body uniform)
             compute(A, ch);
+            if (ch == 0) stamp(2);  // first chunk consumed (its data had arrived)
             load_chunk(A, ch + 2 < nchunks ? ch + 2 : nchunks - 1);
             compute(B, ch + 1);
             load_chunk(B, ch + 3 < nchunks ? ch + 3 : nchunks - 1);
         }
         if (nchunks & 1) compute(A, nchunks - 1);
     }
+    stamp(3);  // all chunks consumed
 
     // ---- reduce over the G row sub-groups of the wave (lane bits CQ..5) --------------------------------
 #pragma unroll
@@ -324,6 +334,7 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
             for (int off = 1 << CQ; off < 64; off <<= 1) v += __shfl_xor(v, off);
             tot[m][j] = v;
         }
+    stamp(4);  // wave-level shuffles done
     if (g == 0) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
         }
     }
     __syncthreads();
+    stamp(5);  // block barrier passed
 
     // ---- across the 4 waves; output o = m*TC + col, o < MB*TC, strided over the 256 threads ------------
     constexpr int NOUT = MB * TC;
@@ -354,6 +366,7 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
             const int o = tid + it * 256;
             if (o < NOUT && (o / TC) < p.M) store_out_t<Tag>(p.epi, part[it], o / TC, (int64_t)tile * TC + (o % TC));
         }
+        stamp(6);
         return;
     }
     float* slab = p.slabs + ((int64_t)tile * p.splitk) * NOUT;

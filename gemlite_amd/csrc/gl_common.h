@@ -322,7 +322,13 @@ struct WnParams {
     int splitk;          // K slices (gridDim.y)
     int rows_per_slice;  // packed rows per K slice
     int64_t stride_xm, stride_xk, stride_wk, stride_meta_g;
+    int flags;           // experiment switches forwarded from tuning[3] (kernel-specific)
+    int gs_shift;        // log2(group_size) when it is a power of two, else -1 (64-bit division is ~100 VALU ops)
 };
+
+__device__ __forceinline__ int group_of(int k, int group_size, int gs_shift) {
+    return gs_shift >= 0 ? (k >> gs_shift) : (k / group_size);
+}
 
 // parameter block of the coverage kernels (generic.hip)
 struct GenericParams {

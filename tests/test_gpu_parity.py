@@ -365,3 +365,64 @@ def test_unsupported_raises_not_falls_back():
         lin(torch.randn(1, 2048).half())  # CPU tensor
     with pytest.raises(ValueError):
         lin(torch.randn(1, 1024).half().to(DEV))  # wrong K
+
+
+# --------------------------------------------------------------- odd shapes / kernel-boundary cases
+@pytest.mark.parametrize("N,K,gs", [(4160, 4096, 128), (1000, 2048, 128), (4096, 4224, 64), (2048, 14336, 128),
+                                      (14336, 4096, 128), (6144, 4096, 128), (128, 512, 32), (64, 64, 64)])
+@pytest.mark.parametrize("M", [1, 2, 7, 17, 65, 129])
+def test_odd_shapes(N, K, gs, M):
+    """Shapes off the tuned grid: every one must land on SOME native kernel and match the oracle."""
+    tdt = torch.float16
+    lin = _make_layer(N, K, 4, gs, tdt, seed=N % 97 + K % 89)
+    x = torch.from_numpy(O.gen_x(M, K, seed=M + 3).astype(np.float32)).to(tdt).to(DEV)
+    y = lin(x)
+    torch.cuda.synchronize()
+    _compare(f"odd/{N}x{K}g{gs}/M{M}", y, _oracle_from_layer(lin, x), 1, extra=dict(kernel=_kernel_name(lin, x)))
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("nbits", [2, 1])
+@pytest.mark.parametrize("M", [1, 16, 48, 200])
+def test_low_bits_all_kernel_families(nbits, M, tdt):
+    lin = _make_layer(2048, 4096, nbits, 128, tdt, seed=nbits)
+    x = torch.from_numpy(O.gen_x(M, 4096, seed=M).astype(np.float32)).to(tdt).to(DEV)
+    for mt in (None, "GEMM_SPLITK", "GEMM"):
+        y = lin(x) if mt is None else lin.forward_manual(x, mt)
+        torch.cuda.synchronize()
+        _compare(f"lowbits/w{nbits}/{str(tdt)[6:]}/M{M}/{mt}", y, _oracle_from_layer(lin, x), lin.output_dtype.value,
+                 extra=dict(kernel=_kernel_name(lin, x, -1 if mt is None else gemlite_amd.core.GEMLITE_MATMUL_TYPES_MAPPING[mt])))
+
+
+@pytest.mark.parametrize("zeros_kind,fma,scales_kind", [("tensor", False, "group"), ("none", True, "group"),
+                                                         ("int", True, "group"), ("int", True, "channel"),
+                                                         ("tensor", True, "channel")])
+def test_tiled_kernel_all_modes_m256(zeros_kind, fma, scales_kind):
+    tdt = torch.bfloat16
+    lin = _make_layer(2048, 4096, 4, 128 if scales_kind == "group" else 4096, tdt, seed=7, zeros_kind=zeros_kind, fma=fma,
+                      scales_kind=scales_kind)
+    x = torch.from_numpy(O.gen_x(256, 4096, seed=5).astype(np.float32)).to(tdt).to(DEV)
+    bias = torch.randn(2048).to(tdt).to(DEV)
+    lin.bias = torch.nn.Parameter(bias, requires_grad=False)
+    y = lin(x)
+    torch.cuda.synchronize()
+    y_or = _oracle_from_layer(lin, x) + O.to_f64(bias).reshape(1, -1)
+    assert _kernel_name(lin, x).startswith("gemm_w4_tiled")
+    # |y| ~ 0.8 because of the bias: the absolute gate of the bias-free fixtures does not apply, the relative one does
+    _compare(f"tiled-modes/{zeros_kind}-{fma}-{scales_kind}", y, y_or, 2, abs_gate=None, extra=dict(kernel="gemm_w4_tiled_kernel"))
+
+
+def test_split_k_variants_agree_bitwise_independent_of_run_order():
+    """Forced split-K factors: each is deterministic and all agree with the oracle."""
+    lin = _make_layer(4096, 4096, 4, 128, torch.float16, seed=11)
+    from gemlite_amd.core import _hip_matmul
+    for M, mt, tunings in ((1, 1, [(4, 1, 0, 0), (4, 2, 0, 0), (4, 8, 0, 0), (3, 4, 0, 0), (2, 1, 0, 1)]),
+                           (16, 3, [(0, 1, 0, 0), (0, 2, 0, 0), (0, 8, 0, 0)]),
+                           (256, 4, [(0, 1, 4, 0), (0, 4, 4, 0), (0, 16, 4, 0), (0, 2, 8, 0)])):
+        x = torch.from_numpy(O.gen_x(M, 4096, seed=M)).to(DEV)
+        y_or = _oracle_from_layer(lin, x)
+        for t in tunings:
+            ys = [_hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), mt, t).clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), (M, t)
+            _compare(f"splitk/M{M}/{t}", ys[0], y_or, 1)
