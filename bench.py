@@ -211,7 +211,9 @@ def main():
         "dtype": dt, "data": "synthetic (seeded random W_q/scales/zeros/x, random-init)",
         "config": {"workload": f"A16W{nbits} gs={group} {N}x{K} M={M} {dt}; step = {layers} distinct layers "
                                f"(cache-cold rotation), {'hipGraph replay' if graph is not None else 'eager'}",
-                   "layers_per_step": layers, "launches_per_step": layers, "parallelism": f"replicas x{world}"},
+                   "layers_per_step": layers, "launches_per_step": layers, "parallelism": f"replicas x{world}",
+                   **({"tuning": args.tuning} if args.tuning else {}),
+                   **({"matmul_type": args.matmul_type} if args.matmul_type else {})},
         "roofline": {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
                      "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": kernel_name,
                      "kernel_us": None if kernel_us != kernel_us else round(kernel_us, 3),

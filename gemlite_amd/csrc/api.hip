@@ -15,6 +15,7 @@ namespace gl {
 // planners (defined next to their kernels)
 bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
@@ -119,15 +120,19 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         p.stride_xm = a.stride_xm; p.stride_xk = a.stride_xk; p.stride_wk = a.stride_wk;
         p.stride_meta_g = per_group_meta ? a.stride_meta_g : 0;
         p.flags = a.tuning[3];
-        p.gs_shift = (eff_group > 0 && (eff_group & (eff_group - 1)) == 0) ? __builtin_ctz((unsigned)eff_group) : -1;
+        p.gs_shift = eff_group >= a.K ? 31
+                     : ((eff_group > 0 && (eff_group & (eff_group - 1)) == 0) ? __builtin_ctz((unsigned)eff_group) : -1);
         const int mt = a.matmul_type;
         const bool want_gemv = (mt == GEMLITE_MATMUL_GEMV || mt == GEMLITE_MATMUL_GEMV_REVSPLITK ||
                                 mt == GEMLITE_MATMUL_GEMV_SPLITK || (mt == GEMLITE_MATMUL_AUTO && a.M <= 1));
         LaunchPlan lp{};
+        if (p.gs_shift < 0) goto coverage;  // group size not a power of two
         if (want_gemv && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }
         if (!want_gemv) {
             const bool want_tiled = (mt == GEMLITE_MATMUL_GEMM || (mt == GEMLITE_MATMUL_AUTO && a.M > 64));
             if (want_tiled && a.tuning[0] != 1 && plan_gemm_wn_tiled(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
+            // few rows: registers-only MFMA path (tuning[2] == 1 keeps the LDS-staged streaming kernel)
+            if (a.M <= 32 && a.tuning[2] != 1 && plan_gemm_wn_direct(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
             if (plan_gemm_wn_stream(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
         }
         // AUTO with small M that the GEMV planner rejected may still fit the streaming kernel
@@ -136,6 +141,7 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         }
     }
 
+coverage:
     // ---- coverage kernels ---------------------------------------------------------------------------
     GenericParams g{};
     g.x = a.x; g.w = a.w_q; g.scales = a.scales; g.zeros = a.zeros;
@@ -201,7 +207,7 @@ extern "C" {
 int gemlite_hip_abi_version(void) { return GEMLITE_HIP_ABI_VERSION; }
 
 const char* gemlite_hip_build_info(void) {
-    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_stream, gemm_wn_tiled, kmajor, generic, "
+    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_direct, gemm_wn_stream, gemm_wn_tiled, kmajor, generic, "
            "act_quant_per_token, pack/unpack_over_cols";
 }
 

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void gemm_wn_stream_kernel(
         const int k_w = (row_s0 + piece * 4 * ROWS_WP + wave * ROWS_WP) * E;  // first k of the span
 #pragma unroll
         for (int q = 0; q < NGRP; ++q) {
-            const int64_t grp = group_of(k_w + q * 32 * SPG, p.group_size, p.gs_shift);
+            const int64_t grp = group_of(k_w + q * 32 * SPG, p.gs_shift);
             pc.s[q] = *(const u32x2*)(sp + grp * mstride + n0);
             pc.z[q] = *(const u32x2*)(zp + grp * mstride + n0);
         }

@@ -53,8 +53,10 @@ struct Window {
 // its packed rows straight from global memory (L1/L2 hits, requested together with the weights) and pairs /
 // pre-scales them in registers (4 v_perm + 2 v_pk_mul + 4 v_dot2 per row).  This removes the x -> LDS -> barrier
 // prologue from the critical path of short K slices (decode shapes such as 4096 x 4096).
-template <typename Tag, int NBITS, int MB, int R, int CQ, bool XD = false>
-__global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1 : 2)) void gemv_wn_kernel(const WnParams p) {
+// NW = waves per block (4; 8 for the short-K direct-x variant: with one chunk per wave the only way to overlap the
+// unpack arithmetic of one part of K with the weight stream of another is a second wave on the same SIMD).
+template <typename Tag, int NBITS, int MB, int R, int CQ, bool XD = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 || NW > 4) ? 1 : 2)) void gemv_wn_kernel(const WnParams p) {
     using TR = F16Traits<Tag>;
     using WN = Window<Tag, NBITS>;
     constexpr bool SUBN = WN::SUBN;
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     constexpr int CHUNK = G * R;     // packed rows one wave consumes per step
     constexpr int TC = 4 << CQ;      // tile columns
     constexpr int RUN_SPANS = R * E / 32;  // 32-k spans of x covered by a lane's run of R rows
-    static_assert(R * E % 32 == 0, "a run of rows must cover whole 32-k spans of x");
+    constexpr int NT = NW * 64;           // threads per block
+    static_assert(XD || R * E % 32 == 0, "a run of rows must cover whole 32-k spans of x");
     static_assert(!XD || (NBITS == 4 && MB == 1), "direct x loads: one 16-byte x chunk per packed row");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -82,8 +85,8 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     const int slice = blockIdx.y;
     const int n0 = tile * TC + c * 4;
 
-    const int rows_slice = p.rows_per_slice;          // multiple of 4*CHUNK
-    const int rows_wave = rows_slice >> 2;            // each wave takes a contiguous quarter
+    const int rows_slice = p.rows_per_slice;          // multiple of NW*CHUNK
+    const int rows_wave = rows_slice / NW;            // each wave takes a contiguous part
     const int row_s0 = slice * rows_slice;            // first packed row of the slice
     const int row_w0 = wave * rows_wave;              // wave start, relative to the slice
     const int pairs = rows_slice * HALF;              // LDS dwords per x row
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     uint32_t* xs = (uint32_t*)smem;                                   // [MB][pairs]  pair-permuted, pre-scaled x
     float* xsum_t = (float*)(smem + (size_t)MB * pairs * 4);           // [MB][nspans] sum of x over each span
     float* xsum_s = xsum_t + MB * nspans;                              // [MB][nspans] sum of x as stored (bf16 path)
-    float* red = xsum_s + MB * nspans;                                 // [4][MB][TC]
-    unsigned* flag = (unsigned*)(red + 4 * MB * TC);
+    float* red = xsum_s + MB * nspans;                                 // [NW][MB][TC]
+    unsigned* flag = (unsigned*)(red + NW * MB * TC);
 
     // ---- weight + metadata stream: everything a chunk needs is requested together, one chunk ahead --------
     const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     const uint16_t* xg = (const uint16_t*)p.x;
     auto load_chunk = [&](Chunk& ck, int chunk) {
         const int row = row_s0 + row_w0 + chunk * CHUNK + g * R;
-        const int64_t grp = group_of(row * E, p.group_size, p.gs_shift);
+        const int64_t grp = group_of(row * E, p.gs_shift);
         if constexpr (XD) {  // x first: it is the cheaper (cached) request and is needed together with w
 #pragma unroll
             for (int i = 0; i < R; ++i) ck.x[i] = *(const u32x4*)(xg + (int64_t)(row + i) * E);
@@ -184,15 +187,13 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     stamp(0);
     Chunk A, B;
     if constexpr (XD) {
-        load_chunk(A, 0);
-        if (nchunks > 1) load_chunk(B, 1);
+        pipeline2_prime(nchunks, A, B, load_chunk);
     } else {
         u32x4 xv[4];
         fetch_x(xv, tid);
-        load_chunk(A, 0);
-        if (nchunks > 1) load_chunk(B, 1);
+        pipeline2_prime(nchunks, A, B, load_chunk);
         put_x(xv, tid);
-        for (int task = tid + 256; task < ntasks; task += 256) {  // large K * MB only
+        for (int task = tid + NT; task < ntasks; task += NT) {  // large K * MB only
             fetch_x(xv, task);
             put_x(xv, task);
         }
@@ -311,17 +312,10 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
         }
     };
 
-    {
-        int ch = 0;
-        for (; ch + 2 <= nchunks; ch += 2) {  // the tail re-requests the last chunk (harmless, keeps the body uniform)
-            compute(A, ch);
-            if (ch == 0) stamp(2);  // first chunk consumed (its data had arrived)
-            load_chunk(A, ch + 2 < nchunks ? ch + 2 : nchunks - 1);
-            compute(B, ch + 1);
-            load_chunk(B, ch + 3 < nchunks ? ch + 3 : nchunks - 1);
-        }
-        if (nchunks & 1) compute(A, nchunks - 1);
-    }
+    pipeline2_run(nchunks, A, B, load_chunk, [&](const Chunk& ck, int ch) {
+        compute(ck, ch);
+        if (ch == 0) stamp(2);  // first chunk consumed (its data had arrived)
+    });
     stamp(3);  // all chunks consumed
 
     // ---- reduce over the G row sub-groups of the wave (lane bits CQ..5) --------------------------------
@@ -345,25 +339,25 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     __syncthreads();
     stamp(5);  // block barrier passed
 
-    // ---- across the 4 waves; output o = m*TC + col, o < MB*TC, strided over the 256 threads ------------
+    // ---- across the waves; output o = m*TC + col, o < MB*TC, strided over the threads ---------------------
     constexpr int NOUT = MB * TC;
-    constexpr int OPT = (NOUT + 255) / 256;  // outputs per thread
+    constexpr int OPT = (NOUT + NT - 1) / NT;  // outputs per thread
     float part[OPT];
 #pragma unroll
     for (int it = 0; it < OPT; ++it) {
-        const int o = tid + it * 256;
+        const int o = tid + it * NT;
         float v = 0.f;
         if (o < NOUT) {
             const int m = o / TC, col = o % TC;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[(w * MB + m) * TC + col];
+            for (int w = 0; w < NW; ++w) v += red[(w * MB + m) * TC + col];
         }
         part[it] = v;
     }
     if (p.splitk == 1) {
 #pragma unroll
         for (int it = 0; it < OPT; ++it) {
-            const int o = tid + it * 256;
+            const int o = tid + it * NT;
             if (o < NOUT && (o / TC) < p.M) store_out_t<Tag>(p.epi, part[it], o / TC, (int64_t)tile * TC + (o % TC));
         }
         stamp(6);
@@ -372,13 +366,13 @@ __global__ __launch_bounds__(256, ((MB * (16 / NBITS) >= 32 || R * MB >= 32) ? 1
     float* slab = p.slabs + ((int64_t)tile * p.splitk) * NOUT;
 #pragma unroll
     for (int it = 0; it < OPT; ++it) {
-        const int o = tid + it * 256;
+        const int o = tid + it * NT;
         if (o < NOUT) slab_store(slab + (int64_t)slice * NOUT + o, part[it]);
     }
     if (!splitk_arrive_is_last(p.counters + tile, p.splitk, flag)) return;
 #pragma unroll
     for (int it = 0; it < OPT; ++it) {
-        const int o = tid + it * 256;
+        const int o = tid + it * NT;
         if (o < NOUT) {
             float v = 0.f;
             for (int s = 0; s < p.splitk; ++s) v += slab_load(slab + (int64_t)s * NOUT + o);
@@ -405,10 +399,13 @@ static const void* inst() {
     }
 }
 template <typename Tag, int NBITS, int MB>
-static const void* pick_shape(int cq, int r, bool xd) {
+static const void* pick_shape(int cq, int r, bool xd, int nw) {
     if (xd) {  // direct-x variants exist for 4-bit, 4 rows per lane
         if constexpr (NBITS == 4 && MB == 1) {
+            if (nw == 8 && r == 2) return cq == 2 ? (const void*)gemv_wn_kernel<Tag, 4, 1, 2, 2, true, 8> : nullptr;
+            if (nw == 16 && r == 2) return cq == 2 ? (const void*)gemv_wn_kernel<Tag, 4, 1, 2, 2, true, 16> : nullptr;
             if (r != 4) return nullptr;
+            if (nw == 8) return cq == 2 ? (const void*)gemv_wn_kernel<Tag, 4, 1, 4, 2, true, 8> : (cq == 3 ? (const void*)gemv_wn_kernel<Tag, 4, 1, 4, 3, true, 8> : nullptr);
             return cq == 2 ? inst<Tag, 4, 1, 4, 2, true>() : (cq == 3 ? inst<Tag, 4, 1, 4, 3, true>() : inst<Tag, 4, 1, 4, 4, true>());
         } else {
             return nullptr;
@@ -425,16 +422,16 @@ static const void* pick_shape(int cq, int r, bool xd) {
     }
 }
 template <typename Tag, int NBITS>
-static const void* pick_mb(int mb, int cq, int r, bool xd) {
-    return mb == 1 ? pick_shape<Tag, NBITS, 1>(cq, r, xd) : nullptr;  // M >= 2 runs on the MFMA streaming kernel
+static const void* pick_mb(int mb, int cq, int r, bool xd, int nw) {
+    return mb == 1 ? pick_shape<Tag, NBITS, 1>(cq, r, xd, nw) : nullptr;  // M >= 2 runs on the MFMA streaming kernel
 }
 template <typename Tag>
-static const void* pick_bits(int nbits, int mb, int cq, int r, bool xd) {
+static const void* pick_bits(int nbits, int mb, int cq, int r, bool xd, int nw = 4) {
     switch (nbits) {
-        case 1: return pick_mb<Tag, 1>(mb, cq, r, xd);
-        case 2: return pick_mb<Tag, 2>(mb, cq, r, xd);
-        case 4: return pick_mb<Tag, 4>(mb, cq, r, xd);
-        case 8: return pick_mb<Tag, 8>(mb, cq, r, xd);
+        case 1: return pick_mb<Tag, 1>(mb, cq, r, xd, nw);
+        case 2: return pick_mb<Tag, 2>(mb, cq, r, xd, nw);
+        case 4: return pick_mb<Tag, 4>(mb, cq, r, xd, nw);
+        case 8: return pick_mb<Tag, 8>(mb, cq, r, xd, nw);
         default: return nullptr;
     }
 }
@@ -498,9 +495,25 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         if (tiles > MAX_SPLITK_COUNTERS && splitk > 1) return false;
         // tuning[3]: 0 auto | 1 stage x in LDS | 2 load x directly.  Direct x pays when a wave has <= 2 steps.
         const int steps = units / splitk;
-        bool xd = nbits == 4 && mb == 1 && r == 4 && (a.tuning[3] == 2 || (a.tuning[3] == 0 && steps <= 2));
-        const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, xd)
-                                                           : pick_bits<bf16_tag>(nbits, mb, cq, r, xd);
+        const int xmode = a.tuning[3] & 3;
+        bool xd = nbits == 4 && mb == 1 && r == 4 && (xmode == 2 || (xmode == 0 && steps <= 2));
+        // tuning[2]: 0 auto | 4 | 8 waves per block.  8 waves: one chunk per wave, two waves per SIMD (short K only)
+        int nw = 4;
+        if (xd && cq <= 3 && splitk == 1) {
+            const int want = a.tuning[2];
+            // measured at 4096 x 4096 (profiles/r01_run21): 4 waves 5.28 us, 8 waves 4.69-4.80 us, 16 waves 4.48 us
+            const int opt_nw[3] = {16, 8, 8}, opt_r[3] = {2, 4, 2}, opt_key[3] = {16, 8, 82};
+            for (int oi = 0; oi < 3; ++oi) {
+                if (!(want == opt_key[oi] || (want == 0 && oi < 2))) continue;
+                const int br = opt_nw[oi] * G * opt_r[oi];
+                if (rows % br != 0 || rows / br > 2 || rpg % opt_r[oi] != 0) continue;
+                nw = opt_nw[oi];
+                r = opt_r[oi];
+                break;
+            }
+        }
+        const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, xd, nw)
+                                                           : pick_bits<bf16_tag>(nbits, mb, cq, r, xd, nw);
         if (!fn && xd) {
             xd = false;
             fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, false)
@@ -510,12 +523,14 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         p.splitk = splitk;
         p.rows_per_slice = rows / splitk;
         lp.fn = fn;
-        lp.name = xd ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect>" : (cq == 3 ? "gemv_wn_kernel<tile32,xdirect>" : "gemv_wn_kernel<tile64,xdirect>"))
+        lp.name = (xd && nw == 16) ? "gemv_wn_kernel<tile16,xdirect,16w>"
+                  : (xd && nw == 8) ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect,8w>" : "gemv_wn_kernel<tile32,xdirect,8w>")
+                  : xd ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect>" : (cq == 3 ? "gemv_wn_kernel<tile32,xdirect>" : "gemv_wn_kernel<tile64,xdirect>"))
                      : (cq == 2 ? "gemv_wn_kernel<tile16>" : (cq == 3 ? "gemv_wn_kernel<tile32>" : "gemv_wn_kernel<tile64>"));
         lp.grid = dim3(tiles, splitk, 1);
-        lp.block = dim3(256, 1, 1);
+        lp.block = dim3(64 * nw, 1, 1);
         lp.lds_bytes = (size_t)mb * p.rows_per_slice * (e / 2) * 4 + (size_t)2 * mb * (p.rows_per_slice * e / 32) * 4 +
-                       (size_t)4 * mb * tc * 4 + 16;
+                       (size_t)nw * mb * tc * 4 + 16;
         lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * mb * tc * 4 : 0;
         lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
         return true;

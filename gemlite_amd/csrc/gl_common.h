@@ -323,11 +323,39 @@ struct WnParams {
     int rows_per_slice;  // packed rows per K slice
     int64_t stride_xm, stride_xk, stride_wk, stride_meta_g;
     int flags;           // experiment switches forwarded from tuning[3] (kernel-specific)
-    int gs_shift;        // log2(group_size) when it is a power of two, else -1 (64-bit division is ~100 VALU ops)
+    int gs_shift;        // log2(group_size); 31 when one metadata row spans all of K; -1 (not a power of two)
+                         // sends the problem to the coverage kernel — an integer division per metadata load costs
+                         // ~50 VALU instructions and a branch in kernels that have ~300 per chunk
 };
 
-__device__ __forceinline__ int group_of(int k, int group_size, int gs_shift) {
-    return gs_shift >= 0 ? (k >> gs_shift) : (k / group_size);
+__device__ __forceinline__ int group_of(int k, int gs_shift) { return k >> gs_shift; }
+
+// Two-buffer software pipeline over n >= 1 units (chunks / pieces of K): unit i + 2 is requested as soon as unit i
+// has been consumed, and nothing is requested twice — a clamped "re-request the last unit" tail would stream the
+// whole weight matrix through L2 -> L1 up to three times when n == 2, which is the case for the 4096 x 4096 decode
+// shape.  The steady-state loop has unconditional loads so the compiler's vmcnt bookkeeping stays exact; the
+// last (up to three) units are peeled.
+template <typename Buf, typename Load>
+__device__ __forceinline__ void pipeline2_prime(int n, Buf& A, Buf& B, Load&& load) {
+    load(A, 0);
+    if (n > 1) load(B, 1);
+}
+template <typename Buf, typename Load, typename Compute>
+__device__ __forceinline__ void pipeline2_run(int n, Buf& A, Buf& B, Load&& load, Compute&& compute) {
+    int i = 0;
+    for (; i + 4 <= n; i += 2) {
+        compute(A, i);
+        load(A, i + 2);
+        compute(B, i + 1);
+        load(B, i + 3);
+    }
+    const int rem = n - i;  // 1, 2 or 3
+    compute(A, i);
+    if (rem >= 2) {
+        if (rem == 3) load(A, i + 2);
+        compute(B, i + 1);
+        if (rem == 3) compute(A, i + 2);
+    }
 }
 
 // parameter block of the coverage kernels (generic.hip)

@@ -8,8 +8,8 @@ from gemlite_amd.core import _hip_matmul
 from oracle import gemlite_oracle as O
 dev = "cuda:0"
 out = {}
-for name, (N, K, tun) in {"cfgA_tile16_xd": (4096, 4096, (2, 1, 0, 4 | 2)), "cfgA_tile16_lds": (4096, 4096, (2, 1, 0, 4 | 1)),
-                          "cfgA_tile32_sk1": (4096, 4096, (3, 1, 0, 4 | 2)), "8192_tile32": (8192, 8192, (3, 1, 0, 4 | 1))}.items():
+for name, (N, K, tun) in {"cfgA_tile16_xd_4w": (4096, 4096, (2, 1, 4, 4 | 2)), "cfgA_tile16_xd_8w": (4096, 4096, (2, 1, 8, 4 | 2)),
+                          "8192_tile32": (8192, 8192, (3, 1, 0, 4 | 1))}.items():
     layers = []
     for i in range(24 if N == 4096 else 8):
         W_q, s, z = O.gen_data(N, K, 4, 128, seed=i)
@@ -23,7 +23,8 @@ for name, (N, K, tun) in {"cfgA_tile16_xd": (4096, 4096, (2, 1, 0, 4 | 2)), "cfg
             y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 1, tun)
             torch.cuda.synchronize()
             ws = list(_hip._workspaces.values())[0]
-            st = ws[4096 * 4: 4096 * 4 + 4 * 16 * 8].view(torch.int64).cpu().numpy().reshape(4, 16)
+            nw = 8 if tun[2] == 8 else 4
+            st = ws[4096 * 4: 4096 * 4 + nw * 16 * 8].view(torch.int64).cpu().numpy().reshape(nw, 16)
             recs.append(st[:, :7].copy())
     r = np.stack(recs[len(layers):])            # drop the first (warm-up) rotation
     t0 = r[:, :, 0].min(axis=1, keepdims=True)[:, :, None]

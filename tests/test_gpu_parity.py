@@ -48,6 +48,8 @@ def _kernel_name(lin, x, mt=-1):
     if lin.channel_scale_mode in (2, 3):
         a.scales_x = 0x1000
     a.input_dtype = lin.input_dtype.value
+    for i in range(4):
+        a.tuning[i] = 0  # the cached struct keeps whatever the last forward() used
     return _hip.load().gemlite_hip_kernel_name(_hip.C.byref(a)).decode()
 
 
@@ -416,9 +418,10 @@ def test_split_k_variants_agree_bitwise_independent_of_run_order():
     """Forced split-K factors: each is deterministic and all agree with the oracle."""
     lin = _make_layer(4096, 4096, 4, 128, torch.float16, seed=11)
     from gemlite_amd.core import _hip_matmul
-    for M, mt, tunings in ((1, 1, [(4, 1, 0, 0), (4, 2, 0, 0), (4, 8, 0, 0), (3, 4, 0, 0), (2, 1, 0, 1)]),
-                           (16, 3, [(0, 1, 0, 0), (0, 2, 0, 0), (0, 8, 0, 0)]),
-                           (256, 4, [(0, 1, 4, 0), (0, 4, 4, 0), (0, 16, 4, 0), (0, 2, 8, 0)])):
+    for M, mt, tunings in ((1, 1, [(4, 1, 0, 0), (4, 2, 0, 0), (4, 8, 0, 0), (3, 4, 0, 0), (2, 1, 0, 1),
+                                   (2, 1, 4, 0), (2, 1, 8, 0), (2, 1, 16, 0), (2, 1, 82, 0)]),  # waves per block
+                           (16, 3, [(0, 1, 1, 0), (0, 2, 1, 0), (0, 8, 1, 0), (1, 1, 0, 0), (2, 2, 0, 0), (4, 4, 0, 0)]),
+                           (256, 4, [(0, 1, 0, 0), (0, 4, 0, 0), (0, 16, 0, 0), (0, 32, 0, 0), (0, 2, 4, 0)])):
         x = torch.from_numpy(O.gen_x(M, 4096, seed=M)).to(DEV)
         y_or = _oracle_from_layer(lin, x)
         for t in tunings:
@@ -426,3 +429,39 @@ def test_split_k_variants_agree_bitwise_independent_of_run_order():
             torch.cuda.synchronize()
             assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), (M, t)
             _compare(f"splitk/M{M}/{t}", ys[0], y_or, 1)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("nbits,N,K", [(4, 4096, 4096), (2, 2048, 4096), (4, 1024, 8192)])
+def test_direct_mfma_kernel_tiles_and_splits(nbits, N, K, tdt):
+    """Registers-only MFMA kernel for few rows: every tile width, forced split-K, both row-tile counts, and the
+    LDS-staged streaming kernel (tuning[2] = 1) as a cross-check — all against the oracle."""
+    from gemlite_amd.core import _hip_matmul
+    lin = _make_layer(N, K, nbits, 128, tdt, seed=21 + nbits)
+    for M in (1, 2, 13, 16, 17, 32):
+        x = torch.from_numpy(O.gen_x(M, K, seed=M + 3).astype(np.float32)).to(tdt).to(DEV)
+        y_or = _oracle_from_layer(lin, x)
+        for tuning in ((1, 0, 0, 0), (2, 0, 0, 0), (4, 0, 0, 0), (1, 2, 0, 0), (4, 2, 0, 0), (0, 0, 0, 0), (0, 0, 1, 0)):
+            if tuning[0] == 1 and M > 16:
+                continue  # the 16-column tile exists for one row tile only
+            y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 3, tuning)
+            torch.cuda.synchronize()
+            _compare(f"direct/w{nbits}/{N}x{K}/{str(tdt)[6:]}/M{M}/{tuning}", y, y_or, lin.output_dtype.value)
+    x = torch.from_numpy(O.gen_x(8, K, seed=1).astype(np.float32)).to(tdt).to(DEV)
+    assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel"), _kernel_name(lin, x)
+
+
+@pytest.mark.parametrize("zeros_kind,fma,scales_kind", [("tensor", False, "group"), ("none", True, "group"),
+                                                         ("int", True, "group"), ("int", True, "channel"),
+                                                         ("tensor", True, "channel"), ("none", True, "channel")])
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_direct_mfma_kernel_all_modes(zeros_kind, fma, scales_kind, tdt):
+    lin = _make_layer(2048, 4096, 4, 128 if scales_kind == "group" else 4096, tdt, seed=5, zeros_kind=zeros_kind, fma=fma,
+                      scales_kind=scales_kind)
+    for M in (3, 24):
+        x = torch.from_numpy(O.gen_x(M, 4096, seed=M).astype(np.float32)).to(tdt).to(DEV)
+        y = lin(x)
+        torch.cuda.synchronize()
+        assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel"), _kernel_name(lin, x)
+        _compare(f"direct-modes/{zeros_kind}-{fma}-{scales_kind}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x),
+                 lin.output_dtype.value)

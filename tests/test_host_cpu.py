@@ -47,6 +47,8 @@ def _args(M=1, N=4096, K=4096, nbits=4, gs=128, in_dt=1, w_mode=4, c_mode=0, e=N
     a.stride_wk, a.stride_wn = (N, 1) if e > 1 else (1, K)
     a.stride_om, a.stride_on = N, 1
     a.stride_meta_g, a.stride_meta_n = N, 1
+    for i, t in enumerate(kw.get("tuning", ())):
+        a.tuning[i] = t
     return a
 
 
@@ -73,21 +75,30 @@ def test_struct_abi_and_validation():
 
 
 @pytest.mark.parametrize("kw,kernel", [
-    (dict(M=1), "gemv_wn_kernel<tile16,xdirect>"),    # cfgA: 256 tiles of 16 columns, K not split, x from L2
-    (dict(M=1, in_dt=2), "gemv_wn_kernel<tile16,xdirect>"),
+    (dict(M=1), "gemv_wn_kernel<tile16,xdirect,16w>"),  # cfgA: 256 tiles of 16 columns, K not split, x from L2,
+    (dict(M=1, in_dt=2), "gemv_wn_kernel<tile16,xdirect,16w>"),  # 16 waves x one chunk each
+    (dict(M=1, tuning=(0, 0, 4, 0)), "gemv_wn_kernel<tile16,xdirect>"),
     (dict(M=1, N=8192, K=8192), "gemv_wn_kernel<tile32>"),
     (dict(M=1, N=16384, K=16384), "gemv_wn_kernel<tile64>"),
-    (dict(M=2), "gemm_wn_stream_kernel"),             # M >= 2: MFMA streaming kernel
-    (dict(M=8), "gemm_wn_stream_kernel"),
+    (dict(M=2), "gemm_wn_direct_kernel<tile16>"),     # 2 <= M <= 32: registers-only MFMA kernel, K not split
+    (dict(M=4), "gemm_wn_direct_kernel<tile16>"),
+    (dict(M=8), "gemm_wn_direct_kernel<tile32>"),     # >= 8 rows: 32-column tiles x split-K 2 (less x traffic)
+    (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile32>"),
+    (dict(M=24, N=16384, K=16384), "gemm_wn_direct_kernel<tile64>"),
+    (dict(M=8, tuning=(0, 0, 1, 0)), "gemm_wn_stream_kernel"),  # tuning[2] = 1: LDS-staged streaming kernel
+    (dict(M=48), "gemm_wn_stream_kernel"),            # 33..64 rows: streaming kernel with 64-row tiles
     (dict(M=1, nbits=2), "gemv_wn_kernel<tile16>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64>"),
-    (dict(M=16), "gemm_wn_stream_kernel"),
-    (dict(M=1, mt=4), "gemm_w4_tiled_kernel"),       # manual GEMM family at M=1 -> the tiled MFMA kernel
-    (dict(M=256), "gemm_w4_tiled_kernel"),
-    (dict(M=256, N=8192, K=8192, in_dt=2), "gemm_w4_tiled_kernel"),
+    (dict(M=16), "gemm_wn_direct_kernel<tile32>"),
+    (dict(M=1, mt=4), "gemm_w4_tiled_kernel<128x128>"),   # manual GEMM family at M=1 -> the tiled MFMA kernel
+    (dict(M=128), "gemm_w4_tiled_kernel<128x128>"),
+    (dict(M=256), "gemm_w4_tiled_kernel<128x128>"),
+    (dict(M=256, N=8192, K=8192, in_dt=2), "gemm_w4_tiled_kernel<128x128>"),
+    (dict(M=256, tuning=(0, 0, 8, 0)), "gemm_w4_tiled_kernel<256x128>"),   # opt-in: 256-row tiles, one block per CU
+    (dict(M=256, tuning=(0, 0, 4, 0)), "gemm_w4_tiled_kernel<legacy>"),
     (dict(M=256, nbits=2), "gemm_wn_stream_kernel"),  # 2-bit: streaming kernel with row tiles
-    (dict(M=4, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK
+    (dict(M=4, mt=3), "gemm_wn_direct_kernel<tile16>"),  # manual GEMM_SPLITK
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
     (dict(M=1, N=1000), "generic_matmul_kernel"),    # N not a multiple of 64
     (dict(M=1, in_dt=4, w_mode=1, c_mode=1, out_dt=0), "generic_matmul_kernel"),  # int8 x W4
