@@ -46,7 +46,12 @@ WORKLOADS = {
     "a16w4_8192_m1": (8192, 8192, 4, 128, 1, "fp16", 8, "hbm"),
     "a16w2_16384_m1": (16384, 16384, 2, 128, 1, "fp16", 4, "hbm"),
     "a16w4_16384_m1": (16384, 16384, 4, 128, 1, "fp16", 2, "hbm"),
+    # BASELINE config 4: A8W8 int8 dynamic (x pre-quantised per token outside the timed matmul; group = K: channel-wise)
+    "a8w8_4096_m1": (4096, 4096, 8, 4096, 1, "int8", 16, "hbm"),
+    "a8w8_4096_m16": (4096, 4096, 8, 4096, 16, "int8", 16, "hbm"),
+    "a8w8_4096_m256": (4096, 4096, 8, 4096, 256, "int8", 16, "mfma"),
 }
+INT8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (2x bf16, MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes(M, N, K, nbits, group, esize=2):
@@ -82,6 +87,14 @@ def build_layers(name, device):
     from gemlite_amd.dtypes import TORCH_TO_DTYPE
 
     N, K, nbits, group, M, dt, layers, bound = WORKLOADS[name]
+    if dt == "int8":
+        from gemlite_amd.helper import A8W8_int8_dynamic
+        from gemlite_amd.quant_utils import scale_activations_per_token
+        g = torch.Generator(device="cpu").manual_seed(0)
+        proc = A8W8_int8_dynamic(device=device, dtype=torch.float16)
+        mods = [proc.from_weights((torch.randn(N, K, generator=g) / 30).half()) for _ in range(layers)]
+        x = (torch.randn(M, K, generator=g) / 10).half().to(device)
+        return mods, scale_activations_per_token(x, torch.int8)  # (x_q int8 [M, K], scales_x fp32 [M, 1])
     tdt = torch.float16 if dt == "fp16" else torch.bfloat16
     code = TORCH_TO_DTYPE[tdt]
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -129,6 +142,9 @@ def main():
     mods, x = build_layers(args.workload, device)
 
     def call(lin):
+        if dt == "int8":  # the matmul alone: x was quantised once in build_layers
+            from gemlite_amd.core import _hip_matmul
+            return _hip_matmul(x[0], lin.W_q, lin.scales, lin.zeros, x[1], lin.get_meta_args(), -1)
         return lin.forward_manual(x, args.matmul_type) if args.matmul_type else lin(x)
 
     def step_eager():
@@ -159,6 +175,8 @@ def main():
 
     launches = args.steps * layers
     bytes_per_launch = algorithmic_bytes(M, N, K, nbits, group)
+    if dt == "int8":  # int8 W + fp32 channel scales + int8 x + fp32 token scales + fp16 out
+        bytes_per_launch = K * N + N * 4 + M * K + M * 4 + M * N * 2
     flops_per_launch = 2 * M * N * K
     ms_per_step = elapsed / args.steps * 1e3
 
@@ -190,7 +208,7 @@ def main():
         gap_incl = bytes_per_launch / (gap_us * 1e-6) / 1e9
         metric = "HBM GB/s (algorithmic bytes) vs roofline, A16W4 gs=128 4096x4096 M=1"
     else:
-        unit, peak = "TFLOP/s", MFMA_PEAK_TFLOPS
+        unit, peak = "TFLOP/s", (INT8_MFMA_PEAK_TOPS if dt == "int8" else MFMA_PEAK_TFLOPS)
         value = whole_job_rate(layers * flops_per_launch, args.steps, world, elapsed) / 1e12
         achieved = flops_per_launch / (kernel_us * 1e-6) / 1e12 if kernel_us == kernel_us else flops_per_launch / (gap_us * 1e-6) / 1e12
         gap_incl = flops_per_launch / (gap_us * 1e-6) / 1e12
@@ -209,7 +227,7 @@ def main():
         "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dt, "data": "synthetic (seeded random W_q/scales/zeros/x, random-init)",
-        "config": {"workload": f"A16W{nbits} gs={group} {N}x{K} M={M} {dt}; step = {layers} distinct layers "
+        "config": {"workload": f"A{8 if dt == 'int8' else 16}W{nbits} gs={group} {N}x{K} M={M} {dt}; step = {layers} distinct layers "
                                f"(cache-cold rotation), {'hipGraph replay' if graph is not None else 'eager'}",
                    "layers_per_step": layers, "launches_per_step": layers, "parallelism": f"replicas x{world}",
                    **({"tuning": args.tuning} if args.tuning else {}),

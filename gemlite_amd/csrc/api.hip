@@ -16,6 +16,7 @@ namespace gl {
 bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
@@ -156,6 +157,12 @@ coverage:
     g.stride_meta_g = per_group_meta ? a.stride_meta_g : 0;
     g.stride_meta_n = per_group_meta ? a.stride_meta_n : ((a.W_group_mode == 1 && !a.zero_is_scalar) ? 1 : 0);
     r.gp = g;
+    // A8W8 (int8 / fp8) with enough rows for the matrix core; tuning[0] == 1 keeps the streaming kernel
+    if (!packed && a.tuning[0] != 1 && a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
+        a.matmul_type != GEMLITE_MATMUL_GEMV_REVSPLITK && plan_gemm_a8w8(a, r.lp)) {
+        r.kind = K_KMAJOR;  // same launch path: GenericParams, no workspace
+        return;
+    }
     const int esz = dtype_size(a.w_dtype);
     if (!packed && a.W_group_mode == 0 && a.stride_wk == 1 && a.stride_xk == 1 && a.w_dtype == a.input_dtype &&
         esz > 0 && (a.K % (16 / esz) == 0) && ((a.stride_wn * esz) % 16 == 0) && ((a.stride_xm * esz) % 16 == 0) &&
@@ -207,7 +214,7 @@ extern "C" {
 int gemlite_hip_abi_version(void) { return GEMLITE_HIP_ABI_VERSION; }
 
 const char* gemlite_hip_build_info(void) {
-    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_direct, gemm_wn_stream, gemm_wn_tiled, kmajor, generic, "
+    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_direct, gemm_wn_stream, gemm_wn_tiled, gemm_a8w8, kmajor, generic, "
            "act_quant_per_token, pack/unpack_over_cols";
 }
 

@@ -103,22 +103,32 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
     // unused metadata is still "loaded" (from the weight buffer, always in bounds) so the loop stays branch-free
     const uint16_t* sp = need_s ? (const uint16_t*)p.scales : (const uint16_t*)p.w;
     const uint16_t* zp = need_z ? (const uint16_t*)p.zeros : (const uint16_t*)p.w;
-    const int64_t mstride = (need_s || need_z) ? p.stride_meta_g : 0;
-    const uint32_t* wbase = p.w + (int64_t)(row_s0 + row_w0 + g * R) * p.stride_wk + n0;
+    const uint32_t mstride = (need_s || need_z) ? (uint32_t)p.stride_meta_g : 0u;
+    // Addresses are a kernel-uniform base plus a 32-bit BYTE offset per lane (global_load saddr + voffset): the
+    // 64-bit row * stride products of the straightforward form were a third of the loop's VALU instructions.
+    // (The planner keeps every tensor below 4 GiB.)
+    const uint32_t sw4 = (uint32_t)p.stride_wk * 4u;
+    uint32_t wo[R];  // byte offset of this lane's R rows in chunk 0
+#pragma unroll
+    for (int i = 0; i < R; ++i) wo[i] = (uint32_t)(row_s0 + row_w0 + g * R + i) * sw4 + (uint32_t)n0 * 4u;
+    const uint32_t xo = (uint32_t)(row_s0 + row_w0 + g * R) * (uint32_t)(E * 2);  // XD: byte offset of row 0's x chunk
     const int nchunks = rows_wave / CHUNK;  // 1, or even (planner)
     struct Chunk { u32x4 w[R]; u32x2 s, z; u32x4 x[XD ? R : 1]; };
     const uint16_t* xg = (const uint16_t*)p.x;
+    const char* wb = (const char*)p.w;
     auto load_chunk = [&](Chunk& ck, int chunk) {
         const int row = row_s0 + row_w0 + chunk * CHUNK + g * R;
-        const int64_t grp = group_of(row * E, p.gs_shift);
+        const uint32_t mo = ((uint32_t)group_of(row * E, p.gs_shift) * mstride + (uint32_t)n0) * 2u;
         if constexpr (XD) {  // x first: it is the cheaper (cached) request and is needed together with w
+            const uint32_t xc = xo + (uint32_t)(chunk * CHUNK) * (uint32_t)(E * 2);
 #pragma unroll
-            for (int i = 0; i < R; ++i) ck.x[i] = *(const u32x4*)(xg + (int64_t)(row + i) * E);
+            for (int i = 0; i < R; ++i) ck.x[i] = *(const u32x4*)((const char*)xg + (xc + (uint32_t)(i * E * 2)));
         }
+        const uint32_t co = (uint32_t)(chunk * CHUNK) * sw4;  // uniform
 #pragma unroll
-        for (int i = 0; i < R; ++i) ck.w[i] = *(const u32x4*)(wbase + (int64_t)(chunk * CHUNK + i) * p.stride_wk);
-        ck.s = *(const u32x2*)(sp + grp * mstride + n0);
-        ck.z = *(const u32x2*)(zp + grp * mstride + n0);
+        for (int i = 0; i < R; ++i) ck.w[i] = *(const u32x4*)(wb + (wo[i] + co));
+        ck.s = *(const u32x2*)((const char*)sp + mo);
+        ck.z = *(const u32x2*)((const char*)zp + mo);
     };
 
     // ---- x[k-slice] -> LDS.  task = (row m, 32-k span): 64 bytes in, 16 pair-permuted / pre-scaled dwords and
@@ -452,6 +462,8 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
     const int rows = (int)(a.K / e);
     const int64_t gs = p.group_size;
     if (gs % e != 0) return false;
+    // 32-bit byte offsets in the kernel
+    if ((int64_t)rows * a.stride_wk * 4 >= (1ll << 32) || (int64_t)(a.K / gs) * p.stride_meta_g * 2 + a.N * 2 >= (1ll << 32)) return false;
     const int rpg = (int)(gs / e);  // packed rows per group
     const int mb = a.M <= 1 ? 1 : (a.M <= 2 ? 2 : 4);
 

@@ -240,7 +240,7 @@ def test_config5_a16w2_16384_m1():
 
 
 # ----------------------------------------------------------------------- A8W8 / FP8 (config 4 path)
-@pytest.mark.parametrize("M", [1, 16, 256])
+@pytest.mark.parametrize("M", [1, 16, 100, 256])
 def test_a8w8_int8_dynamic_is_exact(M):
     torch.manual_seed(M)
     W = (torch.randn(4096, 4096) / 30).half()
@@ -259,7 +259,7 @@ def test_a8w8_int8_dynamic_is_exact(M):
     assert np.array_equal(xq_g.cpu().numpy().astype(np.float64), xq) and np.array_equal(sx_g.cpu().numpy(), sx)
 
 
-@pytest.mark.parametrize("M", [1, 16])
+@pytest.mark.parametrize("M", [1, 16, 200])
 def test_fp8_fp8_dynamic(M):
     torch.manual_seed(M + 5)
     W = (torch.randn(2048, 4096) / 30).half()
@@ -465,3 +465,20 @@ def test_direct_mfma_kernel_all_modes(zeros_kind, fma, scales_kind, tdt):
         assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel"), _kernel_name(lin, x)
         _compare(f"direct-modes/{zeros_kind}-{fma}-{scales_kind}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x),
                  lin.output_dtype.value)
+
+
+def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
+    """int8 x int8: the MFMA kernel and the sdot4 streaming kernel accumulate exactly, so they agree bit for bit."""
+    torch.manual_seed(3)
+    W = (torch.randn(2048, 4096) / 30).half()
+    lin = gemlite_amd.helper.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights(W)
+    x = (torch.randn(77, 4096) / 10).half().to(DEV)
+    assert _kernel_name(lin, torch.empty(77, 4096, dtype=torch.int8)).startswith("gemm_a8w8_kernel"), _kernel_name(lin, x)
+    y = lin(x)
+    gemlite_amd.core.TUNING_OVERRIDE = (1, 0, 0, 0)
+    try:
+        y2 = lin(x)
+    finally:
+        gemlite_amd.core.TUNING_OVERRIDE = None
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
