@@ -482,3 +482,17 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
         gemlite_amd.core.TUNING_OVERRIDE = None
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("M", [1, 64])
+def test_fp8_e5m2_dynamic(M):
+    """e5m2 x e5m2 (FP8e5, dtype code 8): streaming kernel at M = 1, v_mfma_f32_32x32x16_bf8_bf8 at M = 64."""
+    torch.manual_seed(M + 9)
+    W = (torch.randn(1024, 2048) / 30).half()
+    lin = gemlite_amd.helper.A8W8_dynamic(device=DEV, dtype=torch.float16, fp8=torch.float8_e5m2).from_weights(W)
+    x = (torch.randn(M, 2048) / 10).half().to(DEV)
+    y = lin(x)
+    torch.cuda.synchronize()
+    xq, sx = O.scale_activations_per_token(x, O.FP8E5)
+    y_or = (xq @ O.to_f64(lin.W_q.data)) * (sx.astype(np.float64) * O.to_f64(lin.scales.data).reshape(1, -1))
+    _compare(f"a8w8/fp8e5/M{M}", y, y_or, 1, abs_gate=5e-3)
