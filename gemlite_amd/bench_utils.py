@@ -61,3 +61,53 @@ def timed_steps(group: ReplicaGroup, run_step, steps: int, warmup: int, device_s
 def whole_job_rate(units_per_step_per_rank: float, steps: int, world: int, elapsed_max: float) -> float:
     """Weak scaling: every rank does the same work; the job rate is the sum of the units over the slowest time."""
     return world * steps * units_per_step_per_rank / elapsed_max
+
+
+class HipEvents:
+    """Minimal hipEvent access through libamdhip64 (the runtime torch already loaded): start / stop events that
+    `gemlite_hip_set_profile_events` attaches to ONE kernel launch (hipExtLaunchKernel), i.e. device time of the
+    kernel itself, without launch gaps or host overhead."""
+
+    def __init__(self):
+        import ctypes
+        self._c = ctypes
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    def create(self):
+        e = self._c.c_void_p()
+        assert self.hip.hipEventCreate(self._c.byref(e)) == 0
+        return e
+
+    def destroy(self, e):
+        self.hip.hipEventDestroy(e)
+
+    def elapsed_ms(self, a, b):
+        self.hip.hipEventSynchronize(b)
+        ms = self._c.c_float()
+        rc = self.hip.hipEventElapsedTime(self._c.byref(ms), a, b)
+        return ms.value if rc == 0 else float("nan")
+
+
+def kernel_device_us(launch, iters: int = 30, warmup: int = 3) -> float:
+    """Mean device duration (us) of the library kernel that `launch()` starts, from per-launch HIP events."""
+    import torch
+    from . import _hip
+    lib = _hip.load()
+    for _ in range(warmup):
+        launch()
+    ev = HipEvents()
+    pairs = [(ev.create(), ev.create()) for _ in range(iters)]
+    for a, b in pairs:
+        lib.gemlite_hip_set_profile_events(a, b)
+        launch()
+    torch.cuda.synchronize()
+    durs = [ev.elapsed_ms(a, b) * 1e3 for a, b in pairs]
+    for a, b in pairs:
+        ev.destroy(a)
+        ev.destroy(b)
+    durs = [d for d in durs if d == d and d > 0]
+    return sum(durs) / len(durs) if durs else float("nan")

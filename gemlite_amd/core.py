@@ -152,6 +152,32 @@ def _static_args(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> _hip.
     return a
 
 
+def config_key(M: int, N: int, K: int, group_size: int, elements_per_sample: int, type_id: int) -> str:
+    """Key of the tuning table, the reference's autotune key (core.py:141-145, triton_kernels `key=[...]`):
+    (M bucket, N, K, group_size, elements_per_sample, type_id)."""
+    return str((get_closest_m(int(M)), int(N), int(K), int(group_size), int(elements_per_sample), int(type_id)))
+
+
+def config_family(matmul_type: int, M: int, W_nbits: int) -> str:
+    """Family name a table entry is filed under: the forced family, or what the reference would pick for M."""
+    return GEMLITE_MATMUL_TYPES[matmul_type] if matmul_type >= 0 else get_matmul_type(M, W_nbits)
+
+
+def lookup_tuning(matmul_type: int, M: int, a) -> Optional[tuple]:
+    """tuning[4] for this launch from GEMLITE_HIP_CONFIG_CACHE (filled by load_config() or helper.autotune_layer()),
+    or None: the library's own planner decides.  Entries look like {"tuning": [t0, t1, t2, t3], "us": 4.5}."""
+    if not GEMLITE_HIP_CONFIG_CACHE:
+        return None
+    fam = GEMLITE_HIP_CONFIG_CACHE.get(config_family(matmul_type, M, a.W_nbits))
+    if not fam:
+        return None
+    entry = fam.get(config_key(M, a.N, a.K, a.group_size, a.elements_per_sample, a.type_id))
+    if not entry or "tuning" not in entry:
+        return None
+    t = tuple(int(v) for v in entry["tuning"])
+    return (t + (0, 0, 0, 0))[:4]
+
+
 def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x: Optional[Tensor], meta_args,
                 matmul_type: int, tuning=None) -> Tensor:
     """out[M, N] = epilogue(x[M, K] @ dequant(W_q)) — the seam the reference fills with
@@ -175,6 +201,8 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
         a.scales_x, a.stride_sx_m = None, 0
     if tuning is None:
         tuning = TUNING_OVERRIDE
+    if tuning is None:
+        tuning = lookup_tuning(matmul_type, M, a)
     for i in range(4):
         a.tuning[i] = 0 if tuning is None else int(tuning[i])
     stream = _hip.current_stream_handle(x.device)

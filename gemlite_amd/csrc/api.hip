@@ -130,7 +130,9 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         if (p.gs_shift < 0) goto coverage;  // group size not a power of two
         if (want_gemv && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }
         if (!want_gemv) {
-            const bool want_tiled = (mt == GEMLITE_MATMUL_GEMM || (mt == GEMLITE_MATMUL_AUTO && a.M > 64));
+            // AUTO: the tiled kernel from 33 rows (a half-empty 128-row tile still beats the LDS-staged streaming
+            // kernel: 4096^2, M = 64: ~20 us vs 47 us)
+            const bool want_tiled = (mt == GEMLITE_MATMUL_GEMM || (mt == GEMLITE_MATMUL_AUTO && a.M > 32));
             if (want_tiled && a.tuning[0] != 1 && plan_gemm_wn_tiled(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
             // few rows: registers-only MFMA path (tuning[2] == 1 keeps the LDS-staged streaming kernel)
             if (a.M <= 32 && a.tuning[2] != 1 && plan_gemm_wn_direct(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }

@@ -129,5 +129,61 @@ def patch_model(model: torch.nn.Module, processor, skip_modules=(), device="cuda
 
 def warmup(*_a, **_k):
     """The reference pre-runs Triton autotuning per shape (helper.py:1067-1118); HIP kernels are compiled
-    ahead of time, so there is nothing to warm up."""
+    ahead of time, so there is nothing to warm up.  (autotune_layer() below is the optional measured search.)"""
     return None
+
+
+# tuning[] candidates per kernel family of libgemlite_hip (include/gemlite_hip.h: tuning[0..3]); (0,0,0,0) = planner
+_TUNING_CANDIDATES = {
+    "gemv": [(0, 0, 0, 0), (2, 1, 4, 0), (2, 1, 8, 0), (2, 1, 16, 0), (3, 1, 0, 0), (3, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 4, 0, 0)],
+    "few_rows": [(0, 0, 0, 0), (1, 1, 0, 0), (2, 1, 0, 0), (2, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 4, 0, 0), (0, 0, 1, 0)],
+    "tiled": [(0, 0, 0, 0), (0, 1, 0, 0), (0, 2, 0, 0), (0, 4, 0, 0), (0, 8, 0, 0), (0, 4, 8, 0), (0, 8, 8, 0)],
+}
+
+
+def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, candidates=None, verbose: bool = False) -> dict:
+    """Measured search over the library's tuning knobs for one packed layer — the HIP counterpart of the reference's
+    per-shape Triton autotune (core.py:559-654, helper.py:1067-1118).  For each M, every candidate that the
+    library accepts is timed (device time from per-launch HIP events, `iters` launches, weights warm) and the best is
+    stored in GEMLITE_HIP_CONFIG_CACHE under the reference's key; `GemLiteLinear.cache_config(path)` /
+    `load_config(path)` persist and reload the table, and every later launch of that shape uses it.
+    Returns {M: {"tuning": [...], "us": best, "default_us": planner}}."""
+    from . import core as _core
+    from ._hip import GemliteHipError
+    from .bench_utils import kernel_device_us
+
+    dev = layer.W_q.device
+    in_t = _core.DTYPE_TO_TORCH[layer.input_dtype.value if not layer.scaled_activations else layer.output_dtype.value]
+    meta = layer.get_meta_args()
+    out = {}
+    for M in batch_sizes:
+        x = (torch.randn(M, layer.in_features, device=dev) / 10).to(in_t)
+        scales_x = None
+        if layer.scaled_activations:
+            from .quant_utils import scale_activations_per_token
+            x, scales_x = scale_activations_per_token(x, w_dtype=_core.DTYPE_TO_TORCH[layer.input_dtype.value])
+        fam = "gemv" if M == 1 else ("few_rows" if M <= 64 else "tiled")
+        best, default_us = None, None
+        for cand in (candidates or _TUNING_CANDIDATES[fam]):
+            try:  # device time of the kernel itself (per-launch HIP events), not host-bound wall time
+                us = kernel_device_us(lambda: _core._hip_matmul(x, layer.W_q, layer.scales, layer.zeros, scales_x, meta,
+                                                                -1, cand), iters=iters)
+            except (NotImplementedError, GemliteHipError):
+                continue  # this candidate does not apply to the shape
+            if us != us:
+                continue
+            if cand == (0, 0, 0, 0):
+                default_us = us
+            if verbose:
+                print(f"[autotune] M={M} tuning={cand}: {us:.2f} us")
+            if best is None or us < best[1]:
+                best = (cand, us)
+        if best is None:
+            continue
+        a = _core._static_args(layer.W_q, layer.scales, layer.zeros, meta)
+        key = _core.config_key(M, a.N, a.K, a.group_size, a.elements_per_sample, a.type_id)
+        family = _core.config_family(-1, M, layer.W_nbits)
+        entry = {"tuning": list(best[0]), "us": round(best[1], 3)}
+        _core.GEMLITE_HIP_CONFIG_CACHE.setdefault(family, {})[key] = entry
+        out[M] = dict(entry, default_us=None if default_us is None else round(default_us, 3))
+    return out

@@ -496,3 +496,21 @@ def test_fp8_e5m2_dynamic(M):
     xq, sx = O.scale_activations_per_token(x, O.FP8E5)
     y_or = (xq @ O.to_f64(lin.W_q.data)) * (sx.astype(np.float64) * O.to_f64(lin.scales.data).reshape(1, -1))
     _compare(f"a8w8/fp8e5/M{M}", y, y_or, 1, abs_gate=5e-3)
+
+
+def test_autotune_layer_fills_the_tuning_table_and_results_stay_correct():
+    from gemlite_amd import core
+    core.GemLiteLinear.reset_config()
+    lin = _make_layer(2048, 4096, 4, 128, torch.float16, seed=31)
+    res = gemlite_amd.helper.autotune_layer(lin, batch_sizes=(1, 8, 256), iters=5)
+    assert set(res) == {1, 8, 256} and all(len(v["tuning"]) == 4 and v["us"] > 0 for v in res.values())
+    try:
+        for M in (1, 8, 256):
+            x = torch.from_numpy(O.gen_x(M, 4096, seed=M)).to(DEV)
+            a = core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
+            assert core.lookup_tuning(-1, M, a) == tuple(res[M]["tuning"])
+            y = lin(x)
+            torch.cuda.synchronize()
+            _compare(f"autotuned/M{M}/{res[M]['tuning']}", y, _oracle_from_layer(lin, x), 1)
+    finally:
+        core.GemLiteLinear.reset_config()

@@ -86,7 +86,9 @@ def test_struct_abi_and_validation():
     (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile32>"),
     (dict(M=24, N=16384, K=16384), "gemm_wn_direct_kernel<tile64>"),
     (dict(M=8, tuning=(0, 0, 1, 0)), "gemm_wn_stream_kernel"),  # tuning[2] = 1: LDS-staged streaming kernel
-    (dict(M=48), "gemm_wn_stream_kernel"),            # 33..64 rows: streaming kernel with 64-row tiles
+    (dict(M=48), "gemm_w4_tiled_kernel<128x128>"),    # from 33 rows: the tiled kernel (half-empty tile beats streaming)
+    (dict(M=48, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK at 33..64 rows: LDS-staged streaming kernel
+    (dict(M=48, nbits=2), "gemm_wn_stream_kernel"),   # 2-bit has no tiled kernel
     (dict(M=1, nbits=2), "gemv_wn_kernel<tile16>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64>"),
@@ -240,3 +242,26 @@ def test_config_shims(tmp_path):
     assert gemlite_amd.load_config(str(f)) and "GEMM" in gemlite_amd.core.GEMLITE_HIP_CONFIG_CACHE
     assert gemlite_amd.load_config(str(tmp_path / "missing.json"), print_error=False) is False
     gemlite_amd.set_autotune("fast", use_cuda_graph=False)
+
+
+def test_tuning_table_lookup_and_json_round_trip(tmp_path):
+    """GEMLITE_HIP_CONFIG_CACHE: reference-style keys, consulted per launch, persisted by cache_config / load_config."""
+    from gemlite_amd import core
+    core.GemLiteLinear.reset_config()
+    a = _args(M=1)  # cfgA: N = K = 4096, 4-bit, group 128, e = 8, type_id 104
+    a.type_id = 104
+    assert core.lookup_tuning(-1, 1, a) is None
+    key = core.config_key(1, 4096, 4096, 128, 8, 104)
+    assert key == "(1, 4096, 4096, 128, 8, 104)" and core.config_key(100, 1, 2, 3, 4, 5).startswith("(128,")  # M bucket
+    fam = core.config_family(-1, 1, 4)
+    assert fam == "GEMV_REVSPLITK" and core.config_family(3, 1, 4) == "GEMM_SPLITK" and core.config_family(-1, 256, 4) == "GEMM"
+    core.GEMLITE_HIP_CONFIG_CACHE.setdefault(fam, {})[key] = {"tuning": [2, 1, 8], "us": 4.7}
+    assert core.lookup_tuning(-1, 1, a) == (2, 1, 8, 0)
+    assert core.lookup_tuning(-1, 2, a) is None and core.lookup_tuning(4, 1, a) is None  # other bucket / other family
+    path = str(tmp_path / "hints.json")
+    core.GemLiteLinear.cache_config(path)
+    core.GemLiteLinear.reset_config()
+    assert core.lookup_tuning(-1, 1, a) is None
+    assert core.GemLiteLinear.load_config(path) is not False
+    assert core.lookup_tuning(-1, 1, a) == (2, 1, 8, 0)
+    core.GemLiteLinear.reset_config()
