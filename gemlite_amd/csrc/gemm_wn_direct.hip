@@ -284,9 +284,12 @@ __global__ __launch_bounds__(256, 1) void gemm_wn_direct_kernel(const WnParams p
 // ---------------------------------------------------------------------------------------------
 template <typename Tag, int NBITS, int V, int MT>
 static const void* dpick_spg(int spg) {
-    // group sizes below 128 stay with the LDS-staged streaming kernel: two metadata rows per 128 k and piece
-    // push these register-only pieces past the 512-VGPR budget
+    // group size 64 (two metadata rows per 128 k) fits the 512-VGPR budget for one row tile only (M <= 16);
+    // group size 32 and 17..32 rows at group size 64 stay with the LDS-staged streaming kernel
     if (spg == 4) return (const void*)gemm_wn_direct_kernel<Tag, NBITS, V, MT, 4>;
+    if constexpr (MT == 1) {
+        if (spg == 2) return (const void*)gemm_wn_direct_kernel<Tag, NBITS, V, 1, 2>;
+    }
     return nullptr;
 }
 template <typename Tag, int NBITS, int V>
@@ -331,8 +334,11 @@ bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     if ((uses_s && ((uintptr_t)a.scales % 8) != 0) || (has_z && !a.zero_is_scalar && ((uintptr_t)a.zeros % 8) != 0)) return false;
     if (p.stride_meta_g % 4 != 0) return false;
     const int64_t gs = p.group_size;
-    if (gs % 128 != 0) return false;  // scale / zero are folded in every 128 k
-    const int spg = 4;
+    int spg;
+    if (gs % 128 == 0) spg = 4;       // scale / zero folded in every 128 k
+    else if (gs == 64) spg = 2;       // ... every 64 k
+    else return false;
+    if (gs < 4 * e) return false;     // a group must contain whole 4-row wave loads (their k-steps are interleaved)
     const int mt = a.M <= 16 ? 1 : 2;
     const int bm = 16 * mt;
     const int mtiles = (int)((a.M + bm - 1) / bm);

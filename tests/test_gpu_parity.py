@@ -514,3 +514,19 @@ def test_autotune_layer_fills_the_tuning_table_and_results_stay_correct():
             _compare(f"autotuned/M{M}/{res[M]['tuning']}", y, _oracle_from_layer(lin, x), 1)
     finally:
         core.GemLiteLinear.reset_config()
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_direct_mfma_kernel_group_size_64(nbits, tdt):
+    """Group size 64 (hqq's default): scale / zero folded in every 64 k; registers-only kernel for one row tile."""
+    from gemlite_amd.core import _hip_matmul
+    lin = _make_layer(2048, 4096, nbits, 64, tdt, seed=41 + nbits)
+    for M in (2, 9, 16):
+        x = torch.from_numpy(O.gen_x(M, 4096, seed=M + 5).astype(np.float32)).to(tdt).to(DEV)
+        y_or = _oracle_from_layer(lin, x)
+        assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel"), _kernel_name(lin, x)
+        for tuning in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (4, 0, 0, 0), (4, 2, 0, 0), (0, 0, 1, 0)):
+            y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
+            torch.cuda.synchronize()
+            _compare(f"direct-g64/w{nbits}/{str(tdt)[6:]}/M{M}/{tuning}", y, y_or, lin.output_dtype.value)

@@ -86,6 +86,9 @@ def test_struct_abi_and_validation():
     (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile32>"),
     (dict(M=24, N=16384, K=16384), "gemm_wn_direct_kernel<tile64>"),
     (dict(M=8, tuning=(0, 0, 1, 0)), "gemm_wn_stream_kernel"),  # tuning[2] = 1: LDS-staged streaming kernel
+    (dict(M=4, gs=64), "gemm_wn_direct_kernel<tile16>"),   # group size 64: registers-only kernel up to 16 rows
+    (dict(M=24, gs=64), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32
+    (dict(M=4, gs=32), "gemm_wn_stream_kernel"),
     (dict(M=48), "gemm_w4_tiled_kernel<128x128>"),    # from 33 rows: the tiled kernel (half-empty tile beats streaming)
     (dict(M=48, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK at 33..64 rows: LDS-staged streaming kernel
     (dict(M=48, nbits=2), "gemm_wn_stream_kernel"),   # 2-bit has no tiled kernel
