@@ -1,10 +1,10 @@
-// gemv_wn.hip — fused unpack + group-dequant + GEMV for packed low-bit weights, M <= 8 (decode).
+// gemv_wn.hip — fused unpack + group-dequant + GEMV for packed low-bit weights, M = 1 (decode).
 //
 // Replaces the reference's gemv_INT_revsplitK_kernel / gemv_INT_kernel / gemv_INT_splitK_kernel
 // (gemlite/triton_kernels/gemv_revsplitK_kernels.py:226-462, gemv_kernels.py:230-388,
 // gemv_splitK_kernels.py:240-420) for packed int32 weights.  HBM-bound: the only large stream is W_q.
 //
-// Mapping (CDNA4, 64-wide waves, block = 4 waves).  A lane owns 4 adjacent columns (one 16-byte
+// Mapping (CDNA4, 64-wide waves, block = 4 waves; 8 / 16 for the short-K variant, see NW below).  A lane owns 4 adjacent columns (one 16-byte
 // global_load_dwordx4 per packed row = 4 columns x e k-values) and R consecutive packed rows per step:
 //     lane = (g = lane >> CQ, c = lane & (2^CQ - 1));  columns 4c..4c+3 of the tile;
 //     rows  wave_base + step*G*R + g*R + i,  i < R,  G = 64 >> CQ row sub-groups per wave.
