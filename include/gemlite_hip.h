@@ -124,7 +124,17 @@ typedef struct gemlite_hip_forward_args {
     int64_t stride_meta_g, stride_meta_n;
     int64_t stride_sx_m;
 
-    int32_t tuning[4]; /* 0 = library default. [0] kernel variant, [1] split-K, [2..3] reserved */
+    /* Planner overrides (0 = library default everywhere; what helper.autotune_layer() searches and the tuning table
+     * stores — the counterpart of the reference's per-shape Triton autotune configs).  Meaning per kernel family:
+     *   packed GEMV (M = 1)        [0] 2/3/4 = 16-/32-/64-column tiles   [1] K slices   [2] 4/8/16 waves per block
+     *                              (82 = 8 waves, 2 rows per lane)       [3] & 3: 1 = x through LDS, 2 = x direct
+     *   few rows (2..32, MFMA)     [0] 1/2/4 = 16-/32-/64-column tiles   [1] K slices   [2] 1 = LDS-staged streaming kernel
+     *   tiled (M > 32, MFMA)       [0] 1 = streaming kernel instead      [1] K slices   [2] 4 = one-step-ahead kernel,
+     *                              8 = 256-row tiles (one block per CU)
+     *   unpacked 8-bit (A8W8)      [0] 1 = streaming (one wave per column) kernel instead of the MFMA kernel
+     *   [3] & 4: development timeline stamps (needs a workspace).  A value that does not apply to the shape makes the
+     *   planner fall through to its own choice or to another family; it never produces a wrong result. */
+    int32_t tuning[4];
 } gemlite_hip_forward_args;
 
 /* Library / ABI identification (host only, no device access). */
