@@ -9,7 +9,7 @@ from oracle import gemlite_oracle as O
 dev = "cuda:0"
 out = {}
 for name, (N, K, tun) in {"cfgA_tile16_xd_4w": (4096, 4096, (2, 1, 4, 4 | 2)), "cfgA_tile16_xd_8w": (4096, 4096, (2, 1, 8, 4 | 2)),
-                          "8192_tile32": (8192, 8192, (3, 1, 0, 4 | 1))}.items():
+                          "cfgA_tile16_xd_16w": (4096, 4096, (2, 1, 16, 4 | 2))}.items():
     layers = []
     for i in range(24 if N == 4096 else 8):
         W_q, s, z = O.gen_data(N, K, 4, 128, seed=i)
@@ -23,7 +23,7 @@ for name, (N, K, tun) in {"cfgA_tile16_xd_4w": (4096, 4096, (2, 1, 4, 4 | 2)), "
             y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 1, tun)
             torch.cuda.synchronize()
             ws = list(_hip._workspaces.values())[0]
-            nw = 8 if tun[2] == 8 else 4
+            nw = tun[2] if tun[2] in (8, 16) else 4
             st = ws[4096 * 4: 4096 * 4 + nw * 16 * 8].view(torch.int64).cpu().numpy().reshape(nw, 16)
             recs.append(st[:, :7].copy())
     r = np.stack(recs[len(layers):])            # drop the first (warm-up) rotation
