@@ -1,9 +1,11 @@
 """Layer "processors": quantise / wrap weights into a packed GemLiteLinear (reference: gemlite/helper.py).
 
-Round-1 scope: the processors whose kernels are on the north-star path — A16W8 / A16Wn from raw
-(W_q, scales, zeros), A8W8 dynamic (int8 / fp8) — plus ``patch_model`` for ``torch.nn.Linear`` layers.
-HQQ-object inputs (``from_hqqlinear``) need the third-party ``hqq`` package, which is not installed in this
-image; the raw-tensor entry points take exactly what ``HQQLinear.unpack()`` / ``meta`` hold.
+Processors of the reference with the same names, arguments and resulting (W_group_mode, channel_scale_mode):
+A16W8 / A16W8_INT8 / A16W8_FP8, A16Wn and its ``*_HQQ_INT`` family, A8W8 dynamic (int8 / fp8), A8Wn dynamic
+(fp8 activations x n-bit groups), the two BitNet processors, ``patch_model``, ``cleanup_linear``; MXFP / NVFP
+processors are out of scope.  The third-party ``hqq`` package is not part of this build: ``from_hqqlinear`` only
+reads the attributes the reference reads, and the raw-tensor entry points take exactly what
+``HQQLinear.unpack()`` / ``meta`` hold.
 On gfx950 FP8 means OCP e4m3fn (the reference's HIP default e4m3fnuz, helper.py:13-15, is the MI300X format).
 """
 from typing import Optional
@@ -46,21 +48,166 @@ class A16Wn:
         return layer
 
 
-class A16W8(A16Wn):
-    """fp16/bf16 activations x 8-bit symmetric channel-wise weights quantised here (helper.py:88-185)."""
+class A16W8:
+    """fp16/bf16 activations x 8-bit symmetric channel-wise weights, INT8 or FP8, quantised here or passed in
+    pre-quantised with their scales (reference: helper.py:88-171).  `post_scale=False` folds the channel scale into
+    the dequantisation (modes (2, 0)), `True` applies it after the K reduction ((0, 1))."""
 
-    def from_linear(self, linear: torch.nn.Linear) -> GemLiteLinear:
-        W = linear.weight.data.to(device=self.device, dtype=torch.float32)
-        dtype = linear.weight.dtype if self.dtype is None else self.dtype
-        scales = (W.abs().amax(dim=1, keepdim=True) / 127.0).clamp_(min=1e-6)
-        W_q = (W / scales).round_().clamp_(-128, 127).to(torch.int8)
+    def __init__(self, device="cuda:0", dtype: Optional[torch.dtype] = None, fp8=None, fp32_scale=True, post_scale=False):
+        self.device, self.dtype, self.fp8, self.fp32_scale, self.post_scale = device, dtype, fp8, fp32_scale, post_scale
+
+    def from_weights(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                     scales: Optional[torch.Tensor] = None) -> GemLiteLinear:
+        weight = weight.data if isinstance(weight, torch.nn.Parameter) else weight
+        bias = bias.data if isinstance(bias, torch.nn.Parameter) else bias
+        out_features, in_features = weight.shape
+        if scales is None:  # quantise: symmetric, one scale per output channel
+            w_dtype = self.fp8 if self.fp8 else torch.int8
+            info = torch.finfo(w_dtype) if w_dtype.is_floating_point else torch.iinfo(w_dtype)
+            dtype = weight.dtype if self.dtype is None else self.dtype
+            W = weight.to(device=self.device, dtype=torch.float32)
+            scales = (W.abs().amax(dim=1, keepdim=True) / info.max).clamp_(min=1e-6)
+            W_q = (W / scales).clamp_(info.min, info.max)
+            W_q = W_q.to(w_dtype) if w_dtype.is_floating_point else W_q.round_().to(w_dtype)
+        else:  # pre-quantised
+            assert weight.element_size() == 1, f"Invalid weight.dtype, should be 8-bit (INT8 or FP8), got {weight.dtype}"
+            dtype = self.dtype or (scales.dtype if scales.dtype in (torch.float16, torch.bfloat16) else torch.float16)
+            W_q, scales = weight.to(self.device), scales.to(self.device)
         gdt = _gemlite_dtype(dtype)
-        out_features, in_features = W.shape
+        bias = None if bias is None else bias.to(device=self.device, dtype=dtype)
         layer = GemLiteLinear(8, group_size=in_features, in_features=in_features, out_features=out_features,
                               input_dtype=gdt, output_dtype=gdt)
-        bias = None if linear.bias is None else linear.bias.data.to(device=self.device, dtype=dtype)
-        layer.pack(W_q, scales.to(dtype), zeros=None, bias=bias)  # unpacked int8, channel-wise -> (0, 1)
+        layer.pack(W_q, scales.to(dtype), zeros=None, bias=bias)
+        layer.W_group_mode, layer.channel_scale_mode = (0, 1) if self.post_scale else (2, 0)
         return layer
+
+    def from_linear(self, linear: torch.nn.Linear, del_orig: bool = True) -> GemLiteLinear:
+        out = self.from_weights(linear.weight, linear.bias)
+        cleanup_linear(linear, del_orig)
+        return out
+
+
+class A16W8_INT8(A16W8):
+    def __init__(self, device="cuda:0", dtype=None):
+        super().__init__(device=device, dtype=dtype, fp8=None)
+
+
+class A16W8_FP8(A16W8):
+    def __init__(self, device="cuda:0", dtype=None):
+        super().__init__(device=device, dtype=dtype, fp8=default_fp8)
+
+
+class A16Wn_HQQ_INT(A16Wn):
+    """A16Wn fed from an HQQ-quantised layer (reference: helper.py:339-354).  `hqq` itself is a third-party package
+    that is not part of this build: `from_hqqlinear` only relies on the attributes the reference reads
+    (`meta['nbits' | 'group_size' | 'shape' | 'scale' | 'zero' | 'axis']`, `unpack(dtype=)`, `bias`, `in_features`)."""
+
+    W_nbits: Optional[int] = None
+
+    def __init__(self, device="cuda:0", dtype=None, packing_bitwidth=None, post_scale=default_post_scale, W_nbits=None):
+        super().__init__(device=device, dtype=dtype, packing_bitwidth=packing_bitwidth, post_scale=post_scale)
+        if W_nbits is not None:
+            self.W_nbits = W_nbits
+
+    def from_hqqlinear(self, hqq_layer, del_orig: bool = True) -> GemLiteLinear:
+        meta = hqq_layer.meta
+        assert meta["axis"] == 1, "Only axis==1 is supported."
+        self.device = hqq_layer.W_q.device
+        group_size = meta["group_size"] or hqq_layer.in_features
+        W_q = hqq_layer.unpack(dtype=torch.uint8).view(meta["shape"])
+        scales, zeros = meta["scale"].clone(), meta["zero"].clone()
+        bias = None if hqq_layer.bias is None else hqq_layer.bias.clone()
+        cleanup_linear(hqq_layer, del_orig)
+        return self.from_weights(W_q, scales, zeros, meta["nbits"], group_size, bias=bias)
+
+
+class A16W8_HQQ_INT(A16Wn_HQQ_INT):
+    W_nbits = 8
+
+
+class A16W4_HQQ_INT(A16Wn_HQQ_INT):
+    W_nbits = 4
+
+
+class A16W2_HQQ_INT(A16Wn_HQQ_INT):
+    W_nbits = 2
+
+
+class A16W1_HQQ_INT(A16Wn_HQQ_INT):
+    W_nbits = 1
+
+
+class A8Wn_HQQ_INT_dynamic(A16Wn_HQQ_INT):
+    """8-bit (FP8 by default) dynamically quantised activations x n-bit grouped weights: (q - z) * s dequant with the
+    per-token scale applied after the K reduction — modes (3, 2); channel-wise weights move their scale to the
+    epilogue as well ((1, 3) with `post_scale`, else (3, 2)).  Reference: helper.py:502-615."""
+
+    def __init__(self, device="cuda:0", packing_bitwidth=None, dtype=None, post_scale=default_post_scale, fp8=default_fp8,
+                 fp32_scale=False, W_nbits=None):
+        assert W_nbits is not None or self.W_nbits is not None, "W_nbits should be given (8, 4, 2 ...)"
+        super().__init__(device=device, dtype=dtype, packing_bitwidth=packing_bitwidth, post_scale=post_scale, W_nbits=W_nbits)
+        self.fp8, self.fp32_scale = fp8, fp32_scale
+
+    def from_weights(self, W_q, scales, zeros, W_nbits=None, group_size=None, bias=None) -> GemLiteLinear:
+        W_q = W_q.data if isinstance(W_q, torch.nn.Parameter) else W_q
+        W_nbits = self.W_nbits if W_nbits is None else W_nbits
+        group_size = W_q.numel() // scales.numel() if group_size is None else group_size
+        dtype = self.dtype or (scales.dtype if scales.dtype in (torch.float16, torch.bfloat16) else torch.float16)
+        out_features, in_features = W_q.shape
+        layer = GemLiteLinear(W_nbits, group_size=group_size, in_features=in_features, out_features=out_features,
+                              input_dtype=TORCH_TO_DTYPE[self.fp8], output_dtype=_gemlite_dtype(dtype), scaled_activations=True)
+        layer.pack(W_q.to(device=self.device, dtype=torch.uint8),
+                   scales.to(device=self.device, dtype=torch.float32 if self.fp32_scale else dtype),
+                   None if zeros is None else zeros.to(device=self.device, dtype=dtype),
+                   bias=None if bias is None else bias.to(device=self.device, dtype=dtype),
+                   packing_bitwidth=self.packing_bitwidth, fma_mode=False)
+        if group_size == in_features:
+            layer.W_group_mode, layer.channel_scale_mode = (1, 3) if self.post_scale else (3, 2)
+        return layer
+
+
+class A8W4_HQQ_INT_dynamic(A8Wn_HQQ_INT_dynamic):
+    W_nbits = 4
+
+
+class A8W2_HQQ_INT_dynamic(A8Wn_HQQ_INT_dynamic):
+    W_nbits = 2
+
+
+class A16W158_INT:
+    """BitNet b1.58: ternary weights {-1, 0, 1} stored as 2-bit codes {0, 1, 2} with a scalar zero of 1 and one scale
+    for the whole matrix applied per output channel after the K reduction — modes (1, 1).  Reference: helper.py:950-1004."""
+
+    scaled_activations, channel_scale_mode = False, 1
+
+    def __init__(self, device="cuda:0", dtype: Optional[torch.dtype] = None, fp32_scale=True):
+        self.device, self.dtype, self.fp32_scale = device, dtype, fp32_scale
+
+    def from_weights(self, weight: torch.Tensor, weight_scale, bias: Optional[torch.Tensor] = None) -> GemLiteLinear:
+        weight = weight.data if isinstance(weight, torch.nn.Parameter) else weight
+        bias = bias.data if isinstance(bias, torch.nn.Parameter) else bias
+        dtype = weight.dtype if self.dtype is None else self.dtype
+        W_q = (weight.to(device=self.device, dtype=dtype) + 1).to(torch.uint8)
+        out_features, in_features = W_q.shape
+        ws = float(weight_scale.item() if isinstance(weight_scale, torch.Tensor) else weight_scale)
+        scales = torch.full((out_features, 1), ws, dtype=torch.float32 if self.fp32_scale else dtype, device=self.device)
+        layer = GemLiteLinear(2, group_size=in_features, in_features=in_features, out_features=out_features,
+                              input_dtype=DType.INT8 if self.scaled_activations else _gemlite_dtype(dtype),
+                              output_dtype=_gemlite_dtype(dtype), scaled_activations=self.scaled_activations)
+        layer.pack(W_q, scales=scales, zeros=1, bias=None if bias is None else bias.to(device=self.device, dtype=dtype))
+        layer.W_group_mode, layer.channel_scale_mode = 1, self.channel_scale_mode  # shift only + post-scale
+        return layer
+
+    def from_bitlinear(self, linear_layer, del_orig: bool = True) -> GemLiteLinear:
+        out = self.from_weights(linear_layer.weight, linear_layer.weight_scale, linear_layer.bias)
+        cleanup_linear(linear_layer, del_orig)
+        return out
+
+
+class A8W158_INT_dynamic(A16W158_INT):
+    """BitNet with int8 dynamically quantised activations: modes (1, 3).  Reference: helper.py:1006-1062."""
+
+    scaled_activations, channel_scale_mode = True, 3
 
 
 class A8W8_dynamic:
@@ -114,17 +261,40 @@ class A8W8_fp8_dynamic(A8W8_dynamic):
 A8W8_INT8_dynamic, A8W8_FP8_dynamic = A8W8_int8_dynamic, A8W8_fp8_dynamic
 
 
-def patch_model(model: torch.nn.Module, processor, skip_modules=(), device="cuda:0"):
-    """Replace every ``nn.Linear`` (not named in ``skip_modules``) by ``processor.from_linear(layer)``
-    (reference: helper.py:34-85, Linear branch)."""
-    for name, child in list(model.named_children()):
-        if name in skip_modules:
-            continue
-        if isinstance(child, torch.nn.Linear):
-            setattr(model, name, processor.from_linear(child))
-        else:
-            patch_model(child, processor, skip_modules, device)
-    return model
+def cleanup_linear(linear_layer, del_orig: bool = True):
+    """Drop the original tensors of a layer that has been converted (reference: helper.py:25-31)."""
+    if del_orig:
+        for attr in ("weight", "bias", "weight_scale", "W_q", "meta"):
+            val = getattr(linear_layer, attr, None)
+            if val is not None and hasattr(val, "__len__") and len(val) > 0:
+                setattr(linear_layer, attr, None)
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
+def patch_model(model: torch.nn.Module, device, processor=None, skip_modules=("lm_head", "vision", "visual"), group_size=64):
+    """Replace every ``nn.Linear`` whose qualified name contains none of ``skip_modules`` by the processor's layer
+    (reference: helper.py:34-85; same argument order).  HQQ processors (``from_hqqlinear``) would first quantise
+    with the third-party ``hqq`` package, which this build does not ship: they raise NotImplementedError here — feed
+    ``from_weights`` / ``from_hqqlinear`` with already quantised tensors instead."""
+    if processor is None or hasattr(device, "from_linear") or hasattr(device, "from_hqqlinear"):
+        device, processor = (processor if processor is not None else "cuda:0"), device  # (model, processor[, device]) order
+    if not hasattr(processor, "from_linear"):
+        raise NotImplementedError("this processor needs layers quantised by the `hqq` package (not part of this build)")
+
+    def _walk(module, prefix):
+        for name, child in list(module.named_children()):
+            full = f"{prefix}.{name}" if prefix else name
+            if isinstance(child, torch.nn.Linear):
+                if not any(sk in full for sk in skip_modules):
+                    if hasattr(processor, "device"):
+                        processor.device = device
+                    setattr(module, name, processor.from_linear(child.to(device)))
+            else:
+                _walk(child, full)
+
+    _walk(model, "")
+    return model.to(device)
 
 
 def warmup(*_a, **_k):

@@ -216,14 +216,18 @@ def forward(x, W_kn: np.ndarray, *, scales_w_channel=None, scales_x=None, channe
 
 def forward_packed(x, packed, scales_gn, zeros_gn, *, W_nbits, group_size, W_group_mode,
                    channel_scale_mode=0, scales_x=None, zero_is_scalar=False, pack_bits=32,
-                   bias=None, meta_code=None, output_code=None) -> np.ndarray:
-    """End-to-end oracle for packed weights: unpack -> dequantize -> matmul -> epilogue."""
+                   bias=None, meta_code=None, output_code=None, weight_cast_code=None) -> np.ndarray:
+    """End-to-end oracle for packed weights: unpack -> dequantize -> matmul -> epilogue.
+    weight_cast_code: the reference casts the dequantised tile to the INPUT dtype before the dot
+    (`b.to(input_dtype)`, gemm_kernels.py:384) — a real rounding step when the activations are fp8."""
     q_kn = unpack_over_cols(np.asarray(packed), W_nbits, pack_bits).T.astype(np.float64)
     grouped = W_group_mode in (2, 3, 4) or (W_group_mode == 1 and channel_scale_mode not in (1, 3))
     W = dequantize(q_kn, scales_gn if W_group_mode >= 2 else None,
                    zeros_gn if W_group_mode in (1, 3, 4) else None,
                    group_size, W_group_mode, zero_is_scalar, meta_code)
     del grouped
+    if weight_cast_code is not None:
+        W = round_to_dtype(W, weight_cast_code)
     ch = scales_gn if channel_scale_mode in (1, 3) else None
     return forward(x, W, scales_w_channel=ch, scales_x=scales_x, channel_scale_mode=channel_scale_mode,
                    bias=bias, meta_code=meta_code, output_code=output_code)

@@ -530,3 +530,38 @@ def test_direct_mfma_kernel_group_size_64(nbits, tdt):
             y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
             torch.cuda.synchronize()
             _compare(f"direct-g64/w{nbits}/{str(tdt)[6:]}/M{M}/{tuning}", y, y_or, lin.output_dtype.value)
+
+
+@pytest.mark.parametrize("M", [1, 8])
+def test_remaining_helper_processors_against_the_oracle(M):
+    """A16W8 (int8 / fp8 weight-only, pre- and post-scale), A8W4 dynamic (fp8 activations x 4-bit groups) and the two
+    BitNet processors: whatever kernel they land on, the result matches the float64 evaluation of the stored tensors."""
+    H = gemlite_amd.helper
+    torch.manual_seed(11 + M)
+    N, K = 1024, 2048
+    W = (torch.randn(N, K) / 30).half()
+    x = (torch.randn(M, K) / 10).half().to(DEV)
+    for name, lin in (("a16w8-pre", H.A16W8(device=DEV).from_weights(W)),
+                      ("a16w8-post", H.A16W8(device=DEV, post_scale=True).from_weights(W)),
+                      ("a16w8-fp8", H.A16W8_FP8(device=DEV).from_weights(W))):
+        y = lin(x)
+        torch.cuda.synchronize()
+        _compare(f"helpers/{name}/M{M}", y, _oracle_from_layer(lin, x), 1, abs_gate=5e-3, extra=dict(kernel=_kernel_name(lin, x)))
+    W_q, sc, zr = O.gen_data(N, K, 4, 128, seed=3)
+    Wt = torch.randint(-1, 2, (N, K)).half()
+    for name, lin, code in (
+            ("a8w4-dyn", H.A8W4_HQQ_INT_dynamic(device=DEV).from_weights(torch.from_numpy(W_q), torch.from_numpy(sc), torch.from_numpy(zr)), O.FP8E4),
+            ("a8w158-dyn", H.A8W158_INT_dynamic(device=DEV).from_weights(Wt, torch.tensor(0.02)), O.INT8)):
+        y = lin(x)
+        torch.cuda.synchronize()
+        xq, sx = O.scale_activations_per_token(x, code)
+        # fp8 activations: the dequantised weights are rounded to fp8 before the dot, like the reference (gemm_kernels.py:384)
+        y_or = O.forward_packed(xq, lin.W_q.data.cpu().numpy(), O.to_f64(lin.scales.data), O.to_f64(lin.zeros.data).reshape(-1)
+                                if lin.zeros.numel() == 1 else O.to_f64(lin.zeros.data), W_nbits=lin.W_nbits, group_size=lin.group_size,
+                                W_group_mode=lin.W_group_mode, channel_scale_mode=lin.channel_scale_mode, scales_x=sx,
+                                zero_is_scalar=lin.zeros.numel() == 1, weight_cast_code=code if code == O.FP8E4 else None)
+        _compare(f"helpers/{name}/M{M}", y, y_or, 1, abs_gate=5e-3)
+    lin = H.A16W158_INT(device=DEV).from_weights(Wt, torch.tensor(0.02))
+    y = lin(x)
+    torch.cuda.synchronize()
+    _compare(f"helpers/a16w158/M{M}", y, _oracle_from_layer(lin, x), 1, extra=dict(kernel=_kernel_name(lin, x)))

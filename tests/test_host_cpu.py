@@ -268,3 +268,45 @@ def test_tuning_table_lookup_and_json_round_trip(tmp_path):
     assert core.GemLiteLinear.load_config(path) is not False
     assert core.lookup_tuning(-1, 1, a) == (2, 1, 8, 0)
     core.GemLiteLinear.reset_config()
+
+
+def test_helper_processors_select_the_reference_modes():
+    """(W_group_mode, channel_scale_mode) per processor as in the reference's helper.py; host only."""
+    from gemlite_amd import helper as H
+    from gemlite_amd.dtypes import DType
+    torch.manual_seed(0)
+    W = (torch.randn(64, 128) / 30).half()
+    lin = H.A16W8(device="cpu").from_weights(W)
+    assert (lin.W_group_mode, lin.channel_scale_mode, lin.elements_per_sample, lin.W_q.dtype) == (2, 0, 1, torch.int8)
+    assert tuple(lin.W_q.shape) == (128, 64) and lin.W_q.stride() == (1, 128)  # [K, N] view of the [N, K] tensor
+    lin = H.A16W8(device="cpu", post_scale=True).from_weights(W)
+    assert (lin.W_group_mode, lin.channel_scale_mode) == (0, 1)
+    assert H.A16W8_FP8(device="cpu").from_weights(W).W_q.dtype == torch.float8_e4m3fn
+    Wq = torch.randint(0, 16, (64, 128), dtype=torch.uint8)
+    s, z = (torch.rand(128, 1) * 0.01 + 0.001).half(), (torch.rand(128, 1) * 15).half()
+    lin = H.A8W4_HQQ_INT_dynamic(device="cpu").from_weights(Wq, s, z)
+    assert (lin.W_group_mode, lin.channel_scale_mode, lin.group_size, lin.input_dtype, lin.scaled_activations) == (3, 2, 64, DType.FP8, True)
+    lin = H.A8W4_HQQ_INT_dynamic(device="cpu").from_weights(Wq, s[:64], z[:64])  # one group per row: channel-wise
+    assert (lin.W_group_mode, lin.channel_scale_mode) == (1, 3)
+    Wt = torch.randint(-1, 2, (64, 128)).half()
+    lin = H.A16W158_INT(device="cpu").from_weights(Wt, torch.tensor(0.02))
+    assert (lin.W_nbits, lin.W_group_mode, lin.channel_scale_mode, int(lin.zeros.item()), lin.zeros.dtype) == (2, 1, 1, 1, torch.int32)
+    lin = H.A8W158_INT_dynamic(device="cpu").from_weights(Wt, torch.tensor(0.02))
+    assert (lin.W_group_mode, lin.channel_scale_mode, lin.input_dtype) == (1, 3, DType.INT8)
+
+    class FakeHQQ:  # the attributes the reference reads from an HQQLinear
+        def __init__(self):
+            self.W_q, self.bias, self.in_features = torch.zeros(1), None, 128
+            self.meta = dict(axis=1, nbits=4, group_size=64, shape=(64, 128), scale=s.clone(), zero=z.clone())
+
+        def unpack(self, dtype):
+            return Wq.reshape(128, 64).to(dtype)
+
+    lin = H.A16W4_HQQ_INT(device="cpu").from_hqqlinear(FakeHQQ())
+    assert (lin.W_group_mode, lin.channel_scale_mode, tuple(lin.W_q.shape)) == (4, 0, (16, 64))
+    model = torch.nn.Sequential(torch.nn.Linear(128, 64), torch.nn.ReLU(), torch.nn.Linear(64, 32)).half()
+    model.add_module("lm_head", torch.nn.Linear(32, 8).half())
+    H.patch_model(model, "cpu", H.A16W8_INT8(device="cpu"))  # the reference's argument order
+    assert type(model[0]).__name__ == "GemLiteLinearHIP" and isinstance(model.lm_head, torch.nn.Linear)
+    with pytest.raises(NotImplementedError):
+        H.patch_model(torch.nn.Sequential(torch.nn.Linear(8, 8)), "cpu", H.A16W4_HQQ_INT(device="cpu"))
