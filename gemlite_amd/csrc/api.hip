@@ -20,6 +20,7 @@ bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
+const void* kmajor_w8a16_kernel_fn(int mb);
 const void* act_quant_kernel_fn();
 const void* pack_kernel_fn();
 const void* unpack_kernel_fn();
@@ -163,6 +164,19 @@ coverage:
     if (!packed && a.tuning[0] != 1 && a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
         a.matmul_type != GEMLITE_MATMUL_GEMV_REVSPLITK && plan_gemm_a8w8(a, r.lp)) {
         r.kind = K_KMAJOR;  // same launch path: GenericParams, no workspace
+        return;
+    }
+    // A16W8: 8-bit unpacked weights under 16-bit activations, no metadata or one pre-scale per channel
+    if (!packed && (a.W_group_mode == 0 || (a.W_group_mode == 2 && eff_group >= a.K && a.scales)) && a.stride_wk == 1 &&
+        a.stride_xk == 1 && (a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_BF16) &&
+        (a.w_dtype == GEMLITE_DT_INT8 || a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5) &&
+        a.K % 16 == 0 && a.stride_wn % 16 == 0 && (a.stride_xm * 2) % 16 == 0 && (((uintptr_t)a.w_q | (uintptr_t)a.x) % 16 == 0)) {
+        const int mb = a.M == 1 ? 1 : 4;
+        r.kind = K_KMAJOR;
+        r.lp.fn = kmajor_w8a16_kernel_fn(mb);
+        r.lp.name = "kmajor_w8a16_kernel";
+        r.lp.grid = dim3((unsigned)((a.N + 3) / 4), (unsigned)((a.M + mb - 1) / mb), 1);
+        r.lp.block = dim3(256, 1, 1);
         return;
     }
     const int esz = dtype_size(a.w_dtype);

@@ -141,6 +141,56 @@ __global__ __launch_bounds__(256) void kmajor_matmul_kernel(const GenericParams 
     }
 }
 
+// kmajor_w8a16_kernel: 8-bit weight-only (A16W8: int8 / fp8 unpacked K-contiguous weights, fp16 / bf16 activations,
+// helper.py:88-171): same one-wave-per-column streaming as kmajor_matmul_kernel, a lane converts its 16 weights of a
+// 16-byte load to fp32 and multiplies them with the 32 bytes of x that face them; fp32 accumulation.  A channel-wise
+// pre-scale (W_group_mode 2 with one group = K) is a per-column constant, applied once to the sum.
+template <int MB>
+__global__ __launch_bounds__(256) void kmajor_w8a16_kernel(const GenericParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t m0 = (int64_t)blockIdx.y * MB;
+    if (n >= p.N) return;
+    const uint8_t* wcol = (const uint8_t*)p.w + n * p.stride_wn;
+    float acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+    for (int64_t k = (int64_t)lane * 16; k < p.K; k += 64 * 16) {
+        const u32x4 wv = *(const u32x4*)(wcol + k);
+        float wf[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint8_t b = (uint8_t)(wv[e >> 2] >> (8 * (e & 3)));
+            wf[e] = p.w_dt == GEMLITE_DT_INT8 ? (float)(int8_t)b
+                    : (p.w_dt == GEMLITE_DT_FP8E4 ? fp8e4m3_to_float(b) : fp8e5m2_to_float(b));
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            if (m0 + i >= p.M) continue;
+            const uint16_t* xrow = (const uint16_t*)p.x + (m0 + i) * p.stride_xm + k;
+            const u32x4 x0 = *(const u32x4*)xrow, x1 = *(const u32x4*)(xrow + 8);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t d = (e < 8 ? x0 : x1)[(e & 7) >> 1];
+                const uint16_t h = (uint16_t)(d >> (16 * (e & 1)));
+                const float xf = p.x_dt == GEMLITE_DT_FP16 ? F16Traits<half_tag>::to_float(h) : F16Traits<bf16_tag>::to_float(h);
+                acc[i] = __builtin_fmaf(xf, wf[e], acc[i]);
+            }
+        }
+    }
+    const float sc = p.w_mode == 2 ? load_as_float(p.scales, n, p.meta_dt) : 1.f;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && m0 + i < p.M) epilogue_store(p.epi, v * sc, m0 + i, n);
+    }
+}
+const void* kmajor_w8a16_kernel_fn(int mb) {
+    return mb == 1 ? (const void*)kmajor_w8a16_kernel<1> : (const void*)kmajor_w8a16_kernel<4>;
+}
+
 const void* generic_kernel_fn() { return (const void*)generic_matmul_kernel; }
 const void* kmajor_kernel_fn(int mb) {
     return mb == 1 ? (const void*)kmajor_matmul_kernel<1> : (const void*)kmajor_matmul_kernel<4>;

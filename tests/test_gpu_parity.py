@@ -546,6 +546,7 @@ def test_remaining_helper_processors_against_the_oracle(M):
                       ("a16w8-fp8", H.A16W8_FP8(device=DEV).from_weights(W))):
         y = lin(x)
         torch.cuda.synchronize()
+        assert _kernel_name(lin, x) == "kmajor_w8a16_kernel", _kernel_name(lin, x)
         _compare(f"helpers/{name}/M{M}", y, _oracle_from_layer(lin, x), 1, abs_gate=5e-3, extra=dict(kernel=_kernel_name(lin, x)))
     W_q, sc, zr = O.gen_data(N, K, 4, 128, seed=3)
     Wt = torch.randint(-1, 2, (N, K)).half()

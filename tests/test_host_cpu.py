@@ -111,6 +111,8 @@ def test_struct_abi_and_validation():
     (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_kernel<64x128>"),
     (dict(M=4096, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_kernel<128x128>"),
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(1, 0, 0, 0)), "kmajor_matmul_kernel"),
+    (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "kmajor_w8a16_kernel"),   # A16W8 int8, pre-scale
+    (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "kmajor_w8a16_kernel"),  # fp8 W, bf16 x
     (dict(M=1, N=1000), "generic_matmul_kernel"),    # N not a multiple of 64
     (dict(M=1, in_dt=4, w_mode=1, c_mode=1, out_dt=0), "generic_matmul_kernel"),  # int8 x W4
 ])
