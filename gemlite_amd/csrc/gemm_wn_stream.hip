@@ -413,6 +413,11 @@ bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
     if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte x loads
+    // 16-byte weight loads and 8-byte metadata loads: sliced / offset views that break the alignment go to the
+    // coverage kernel instead of faulting
+    if (((uintptr_t)a.w_q % 16) != 0 || (a.stride_wk % 4) != 0) return false;
+    if ((uses_s && ((uintptr_t)a.scales % 8) != 0) || (has_z && !a.zero_is_scalar && ((uintptr_t)a.zeros % 8) != 0)) return false;
+    if (p.stride_meta_g % 4 != 0) return false;
     // a quantisation group must cover whole 32-k MFMA steps and divide or contain the wave's 128-k span
     const int64_t gs = p.group_size;
     int spg;

@@ -459,6 +459,11 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
     if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
     if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0 || a.K % 32 != 0) return false;  // 16-byte x loads
+    // 16-byte weight loads and 8-byte metadata loads: sliced / offset views that break the alignment go to the
+    // coverage kernel instead of faulting
+    if (((uintptr_t)a.w_q % 16) != 0 || (a.stride_wk % 4) != 0) return false;
+    if ((uses_s && ((uintptr_t)a.scales % 8) != 0) || (has_z && !a.zero_is_scalar && ((uintptr_t)a.zeros % 8) != 0)) return false;
+    if (p.stride_meta_g % 4 != 0) return false;
     const int rows = (int)(a.K / e);
     const int64_t gs = p.group_size;
     if (gs % e != 0) return false;
