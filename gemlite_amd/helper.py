@@ -77,7 +77,7 @@ class A16W8:
         bias = None if bias is None else bias.to(device=self.device, dtype=dtype)
         layer = GemLiteLinear(8, group_size=in_features, in_features=in_features, out_features=out_features,
                               input_dtype=gdt, output_dtype=gdt)
-        layer.pack(W_q, scales.to(dtype), zeros=None, bias=bias)
+        layer.pack(W_q, scales, zeros=None, bias=bias)  # scales stay as computed / given (fp32 when quantised here)
         layer.W_group_mode, layer.channel_scale_mode = (0, 1) if self.post_scale else (2, 0)
         return layer
 

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/helpers.npz: what the REFERENCE's layer processors (gemlite/helper.py) produce on seeded inputs.
+
+TEST INFRASTRUCTURE, build container only (needs /root/reference).  The reference is imported on CPU with the same
+process-local device fakes as oracle/gen_golden.py; its processors only run host code (`pack()` on CPU tensors), so
+every output is the reference's own: packed / transposed W_q, scales, zeros, bias, the 12 `meta_args` ints.
+hqq-object entry points are not exercised (the hqq package is not in this image); fp8 processors are given
+`torch.float8_e4m3fn` explicitly because the reference's HIP default is the MI300X format e4m3fnuz.
+
+Usage:  python oracle/gen_golden_helpers.py [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_golden as G  # sets TRITON_INTERPRET and provides the device fakes
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    G._fake_device_and_import()
+    from gemlite import helper as H
+
+    g = torch.Generator().manual_seed(4321)
+    N, K = 48, 256
+    W = (torch.randn(N, K, generator=g) / 30).to(torch.float16)
+    bias = (torch.randn(N, generator=g) / 10).to(torch.float16)
+    W_q4 = torch.randint(0, 16, (N, K), generator=g, dtype=torch.int32).to(torch.uint8)
+    s64 = (torch.rand(N * K // 64, 1, generator=g) * 0.01 + 0.001).to(torch.float16)
+    z64 = (torch.rand(N * K // 64, 1, generator=g) * 15).to(torch.float16)
+    sch = (torch.rand(N, 1, generator=g) * 0.01 + 0.001).to(torch.float16)
+    zch = (torch.rand(N, 1, generator=g) * 15).to(torch.float16)
+    Wt = torch.randint(-1, 2, (N, K), generator=g).to(torch.float16)
+    wscale = torch.tensor(0.0173)
+    fp8 = torch.float8_e4m3fn
+
+    cases = {
+        "a16w8_int8_pre": lambda: H.A16W8(device="cpu").from_weights(W.clone(), bias.clone()),
+        "a16w8_int8_post": lambda: H.A16W8(device="cpu", post_scale=True).from_weights(W.clone()),
+        "a16w8_fp8_pre": lambda: H.A16W8(device="cpu", fp8=fp8).from_weights(W.clone()),
+        "a16wn_g64": lambda: H.A16Wn(device="cpu").from_weights(W_q4.clone(), s64.clone(), z64.clone(), 4, 64, bias.clone()),
+        "a16wn_channel": lambda: H.A16Wn(device="cpu", post_scale=True).from_weights(W_q4.clone(), sch.clone(), zch.clone(), 4, K),
+        "a8w8_int8_dyn": lambda: H.A8W8_dynamic(device="cpu", fp8=False).from_weights(W.clone(), bias.clone()),
+        "a8w8_fp8_dyn": lambda: H.A8W8_dynamic(device="cpu", fp8=fp8).from_weights(W.clone()),
+        "a8w4_dyn_g64": lambda: H.A8Wn_HQQ_INT_dynamic(device="cpu", fp8=fp8, W_nbits=4).from_weights(W_q4.clone(), s64.clone(), z64.clone()),
+        "a8w4_dyn_channel": lambda: H.A8Wn_HQQ_INT_dynamic(device="cpu", fp8=fp8, W_nbits=4, post_scale=True).from_weights(W_q4.clone(), sch.clone(), zch.clone()),
+        "a16w158": lambda: H.A16W158_INT(device="cpu").from_weights(Wt.clone(), wscale, bias.clone()),
+        "a8w158_dyn": lambda: H.A8W158_INT_dynamic(device="cpu").from_weights(Wt.clone(), wscale),
+    }
+    blob = dict(in_W=G._np(W), in_bias=G._np(bias), in_W_q4=G._np(W_q4), in_s64=G._np(s64), in_z64=G._np(z64),
+                in_sch=G._np(sch), in_zch=G._np(zch), in_Wt=G._np(Wt), in_wscale=np.float32(wscale.item()))
+    names = []
+    for name, make in cases.items():
+        lin = make()
+        names.append(name)
+        blob[f"{name}__W_q"] = G._np(lin.W_q.data)
+        blob[f"{name}__W_q_dtype"] = np.array(str(lin.W_q.dtype))
+        blob[f"{name}__W_q_strides"] = np.array(lin.W_q.stride(), np.int64)
+        blob[f"{name}__scales"] = G._np(lin.scales.data.float())
+        blob[f"{name}__scales_dtype"] = np.array(str(lin.scales.dtype))
+        blob[f"{name}__zeros"] = G._np(lin.zeros.data.float())
+        blob[f"{name}__zeros_dtype"] = np.array(str(lin.zeros.dtype))
+        blob[f"{name}__bias"] = G._np(lin.bias.data.float()) if lin.bias is not None else np.zeros(0, np.float32)
+        blob[f"{name}__meta"] = np.array(lin.get_meta_args(), np.int64)
+        blob[f"{name}__modes"] = np.array([lin.W_group_mode, lin.channel_scale_mode], np.int64)
+        print(name, lin.get_meta_args(), (lin.W_group_mode, lin.channel_scale_mode), tuple(lin.W_q.shape), lin.W_q.dtype)
+    blob["names"] = np.array(names)
+    np.savez_compressed(os.path.join(os.path.abspath(args.out), "helpers.npz"), **blob)
+    print("helpers:", len(names), "cases")
+
+
+if __name__ == "__main__":
+    main()

@@ -312,3 +312,49 @@ def test_helper_processors_select_the_reference_modes():
     assert type(model[0]).__name__ == "GemLiteLinearHIP" and isinstance(model.lm_head, torch.nn.Linear)
     with pytest.raises(NotImplementedError):
         H.patch_model(torch.nn.Sequential(torch.nn.Linear(8, 8)), "cpu", H.A16W4_HQQ_INT(device="cpu"))
+
+
+def _bits(t):
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy()
+    if t.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
+        return t.view(torch.uint8).numpy()
+    return t.numpy()
+
+
+def test_helper_processors_match_the_reference_bit_for_bit():
+    """tests/golden/helpers.npz holds what the reference's own processors produced on CPU for seeded inputs
+    (oracle/gen_golden_helpers.py): packed / transposed W_q, scales, zeros, bias, meta_args, modes must be identical."""
+    from gemlite_amd import helper as H
+    z = np.load(os.path.join(GOLDEN, "helpers.npz"))
+    W, bias = torch.from_numpy(z["in_W"]), torch.from_numpy(z["in_bias"])
+    W_q4, s64, z64 = torch.from_numpy(z["in_W_q4"]), torch.from_numpy(z["in_s64"]), torch.from_numpy(z["in_z64"])
+    sch, zch, Wt = torch.from_numpy(z["in_sch"]), torch.from_numpy(z["in_zch"]), torch.from_numpy(z["in_Wt"])
+    wscale, fp8, K = torch.tensor(float(z["in_wscale"])), torch.float8_e4m3fn, W.shape[1]
+    cases = {
+        "a16w8_int8_pre": lambda: H.A16W8(device="cpu").from_weights(W.clone(), bias.clone()),
+        "a16w8_int8_post": lambda: H.A16W8(device="cpu", post_scale=True).from_weights(W.clone()),
+        "a16w8_fp8_pre": lambda: H.A16W8(device="cpu", fp8=fp8).from_weights(W.clone()),
+        "a16wn_g64": lambda: H.A16Wn(device="cpu").from_weights(W_q4.clone(), s64.clone(), z64.clone(), 4, 64, bias.clone()),
+        "a16wn_channel": lambda: H.A16Wn(device="cpu", post_scale=True).from_weights(W_q4.clone(), sch.clone(), zch.clone(), 4, K),
+        "a8w8_int8_dyn": lambda: H.A8W8_dynamic(device="cpu", fp8=False).from_weights(W.clone(), bias.clone()),
+        "a8w8_fp8_dyn": lambda: H.A8W8_dynamic(device="cpu", fp8=fp8).from_weights(W.clone()),
+        "a8w4_dyn_g64": lambda: H.A8Wn_HQQ_INT_dynamic(device="cpu", fp8=fp8, W_nbits=4).from_weights(W_q4.clone(), s64.clone(), z64.clone()),
+        "a8w4_dyn_channel": lambda: H.A8Wn_HQQ_INT_dynamic(device="cpu", fp8=fp8, W_nbits=4, post_scale=True).from_weights(W_q4.clone(), sch.clone(), zch.clone()),
+        "a16w158": lambda: H.A16W158_INT(device="cpu").from_weights(Wt.clone(), wscale, bias.clone()),
+        "a8w158_dyn": lambda: H.A8W158_INT_dynamic(device="cpu").from_weights(Wt.clone(), wscale),
+    }
+    assert sorted(cases) == sorted(str(n) for n in z["names"])
+    for name, make in cases.items():
+        lin = make()
+        assert lin.get_meta_args() == [int(v) for v in z[f"{name}__meta"]], (name, lin.get_meta_args(), z[f"{name}__meta"])
+        assert [lin.W_group_mode, lin.channel_scale_mode] == [int(v) for v in z[f"{name}__modes"]], name
+        assert str(lin.W_q.dtype) == str(z[f"{name}__W_q_dtype"]) and list(lin.W_q.stride()) == [int(v) for v in z[f"{name}__W_q_strides"]], name
+        assert np.array_equal(_bits(lin.W_q.data), z[f"{name}__W_q"]), name
+        assert str(lin.scales.dtype) == str(z[f"{name}__scales_dtype"]), (name, lin.scales.dtype, z[f"{name}__scales_dtype"])
+        assert np.array_equal(lin.scales.data.float().numpy(), z[f"{name}__scales"]), name
+        assert str(lin.zeros.dtype) == str(z[f"{name}__zeros_dtype"]), (name, lin.zeros.dtype)
+        assert np.array_equal(lin.zeros.data.float().numpy(), z[f"{name}__zeros"]), name
+        ref_bias = z[f"{name}__bias"]
+        assert (lin.bias is None and ref_bias.size == 0) or np.array_equal(lin.bias.data.float().numpy(), ref_bias), name
