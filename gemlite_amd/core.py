@@ -54,7 +54,7 @@ def _closest_m_default(M: int) -> int:
     """Round M up to the reference's tuning buckets: powers of two plus the 1/2 and 1/4 interpolations for
     2^i >= 32, capped at 4096 (triton_kernels/utils.py:140-174)."""
     if M <= 0:
-        return 0
+        return 1  # the reference's table maps 0 to its smallest bucket
     if M >= 4096:
         return 4096
     vals = set()

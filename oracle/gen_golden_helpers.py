@@ -77,3 +77,23 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def host_tables(out_dir):
+    """Reference host-side lookup functions on a dense range: get_closest_m (autotune M buckets,
+    triton_kernels/utils.py:136-174), get_matmul_type / get_default_gemv (core.py:100-114)."""
+    G._fake_device_and_import()
+    from gemlite import core as C
+    from gemlite.triton_kernels import utils as U
+    Ms = np.arange(0, 4300, dtype=np.int64)
+    closest = np.array([U.get_closest_m(int(m)) for m in Ms], np.int64)
+    kinds = sorted({C.get_matmul_type(int(m), nb) for m in (1, 2, 64, 65) for nb in (1, 2, 4, 8)})
+    table = {}
+    for nb in (1, 2, 4, 8):
+        table[f"matmul_type_w{nb}"] = np.array([kinds.index(C.get_matmul_type(int(m), nb)) for m in Ms[1:200]], np.int64)
+    np.savez_compressed(os.path.join(out_dir, "host_tables.npz"), Ms=Ms, closest_m=closest, kinds=np.array(kinds), **table)
+    print("host_tables: closest_m for", len(Ms), "values;", kinds)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_HOST_TABLES", "1") == "1":
+    host_tables(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))

@@ -358,3 +358,17 @@ def test_helper_processors_match_the_reference_bit_for_bit():
         assert np.array_equal(lin.zeros.data.float().numpy(), z[f"{name}__zeros"]), name
         ref_bias = z[f"{name}__bias"]
         assert (lin.bias is None and ref_bias.size == 0) or np.array_equal(lin.bias.data.float().numpy(), ref_bias), name
+
+
+def test_host_lookup_tables_match_the_reference():
+    """get_closest_m (autotune M buckets) and get_matmul_type for every M the reference was asked
+    (tests/golden/host_tables.npz from oracle/gen_golden_helpers.py)."""
+    from gemlite_amd import core
+    z = np.load(os.path.join(GOLDEN, "host_tables.npz"))
+    mine = np.array([core.get_closest_m(int(m)) for m in z["Ms"]], np.int64)
+    bad = np.nonzero(mine != z["closest_m"])[0]
+    assert bad.size == 0, (bad[:10], mine[bad[:10]], z["closest_m"][bad[:10]])
+    kinds = [str(k) for k in z["kinds"]]
+    for nb in (1, 2, 4, 8):
+        got = [kinds.index(core.get_matmul_type(int(m), nb)) for m in z["Ms"][1:200]]
+        assert got == [int(v) for v in z[f"matmul_type_w{nb}"]], nb
