@@ -95,5 +95,27 @@ def host_tables(out_dir):
     print("host_tables: closest_m for", len(Ms), "values;", kinds)
 
 
+CTOR_GRID = dict(W_nbits=(1, 2, 3, 4, 8, 16), group_size=(None, 8, 16, 32, 64, 100, 128), in_features=(64, 96, 100, 4096),
+                 dtype=("FP32", "FP16", "BF16", "FP8", "INT8", "FP8e5", "UINT8"))
+
+
+def ctor_grid(out_dir):
+    """Outcome of GemLiteLinear.__init__ (core.py:231-299) over a grid: exception class or the derived attributes."""
+    import itertools
+    G._fake_device_and_import()
+    from gemlite import DType, GemLiteLinear
+    rows = []
+    for nb, gs, k, dt in itertools.product(*CTOR_GRID.values()):
+        try:
+            lin = GemLiteLinear(nb, gs, k, 64, getattr(DType, dt), DType.FP16, scaled_activations=True)
+            rows.append(f"ok|{lin.group_size}|{lin.unpack_mask}|{int(lin.scaled_activations)}|{lin.acc_dtype.value}|{lin.meta_dtype.value}")
+        except Exception as e:  # noqa: BLE001 - the class name is the recorded behaviour
+            rows.append(type(e).__name__)
+    np.savez_compressed(os.path.join(out_dir, "ctor_grid.npz"), rows=np.array(rows))
+    print("ctor_grid:", len(rows), "combinations,", sum(r.startswith("ok") for r in rows), "accepted")
+
+
 if __name__ == "__main__" and os.environ.get("GEN_HOST_TABLES", "1") == "1":
-    host_tables(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))
+    _out = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    host_tables(_out)
+    ctor_grid(_out)

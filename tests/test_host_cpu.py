@@ -372,3 +372,21 @@ def test_host_lookup_tables_match_the_reference():
     for nb in (1, 2, 4, 8):
         got = [kinds.index(core.get_matmul_type(int(m), nb)) for m in z["Ms"][1:200]]
         assert got == [int(v) for v in z[f"matmul_type_w{nb}"]], nb
+
+
+def test_constructor_validation_matches_the_reference_on_a_grid():
+    """GemLiteLinear.__init__ accepts / rejects (and derives group_size, unpack_mask, scaled_activations, acc / meta
+    dtype) exactly like the reference over 1176 argument combinations (tests/golden/ctor_grid.npz)."""
+    import itertools
+    grid = dict(W_nbits=(1, 2, 3, 4, 8, 16), group_size=(None, 8, 16, 32, 64, 100, 128), in_features=(64, 96, 100, 4096),
+                dtype=("FP32", "FP16", "BF16", "FP8", "INT8", "FP8e5", "UINT8"))
+    rows = [str(r) for r in np.load(os.path.join(GOLDEN, "ctor_grid.npz"))["rows"]]
+    combos = list(itertools.product(*grid.values()))
+    assert len(rows) == len(combos)
+    for (nb, gs, k, dt), want in zip(combos, rows):
+        try:
+            lin = GemLiteLinear(nb, gs, k, 64, getattr(DType, dt), DType.FP16, scaled_activations=True)
+            got = f"ok|{lin.group_size}|{lin.unpack_mask}|{int(lin.scaled_activations)}|{lin.acc_dtype.value}|{lin.meta_dtype.value}"
+        except Exception as e:  # noqa: BLE001
+            got = type(e).__name__
+        assert got == want, ((nb, gs, k, dt), got, want)
