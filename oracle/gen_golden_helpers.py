@@ -115,7 +115,46 @@ def ctor_grid(out_dir):
     print("ctor_grid:", len(rows), "combinations,", sum(r.startswith("ok") for r in rows), "accepted")
 
 
+PACK_GRID = dict(nbits=(4, 2, 8), scales=("none", "group", "channel"), zeros=("none", "int", "tensor"), fma=(True, False),
+                 in_dt=("FP16", "BF16", "INT8", "FP8"), scaled=(False, True))
+
+
+def pack_inputs(nbits, scales_kind, zeros_kind, N=16, K=128, gs=64):
+    """Seeded raw inputs of one pack() grid point (shared by the generator and the test)."""
+    g = torch.Generator().manual_seed(1000 + nbits)
+    W_q = torch.randint(0, 2 ** nbits, (N, K), generator=g, dtype=torch.int32).to(torch.uint8)
+    n_groups = {"group": N * K // gs, "channel": N}.get(scales_kind, N * K // gs)
+    scales = None if scales_kind == "none" else (torch.rand(n_groups, 1, generator=g) * 0.01 + 0.001).to(torch.float16)
+    zeros = {"none": None, "int": 2 ** (nbits - 1)}.get(zeros_kind, "t")
+    if zeros == "t":
+        zeros = torch.round(torch.rand(n_groups, 1, generator=g) * (2 ** nbits - 1)).to(torch.float16)
+    return W_q, scales, zeros
+
+
+def pack_grid(out_dir):
+    """What pack() decides (core.py:336-519) over a grid of scale / zero kinds, fma mode, input dtype and activation
+    scaling: modes, meta_args, dtypes and shapes of the stored tensors, or the exception class."""
+    import itertools
+    G._fake_device_and_import()
+    from gemlite import DType, GemLiteLinear
+    rows = []
+    for nb, sk, zk, fma, dt, sa in itertools.product(*PACK_GRID.values()):
+        W_q, scales, zeros = pack_inputs(nb, sk, zk)
+        gs = 128 if sk == "channel" else 64
+        try:
+            lin = GemLiteLinear(nb, gs, 128, 16, getattr(DType, dt), DType.FP16, scaled_activations=sa)
+            lin.pack(W_q, scales, zeros, None, fma_mode=fma)
+            rows.append("|".join(str(v) for v in (
+                "ok", lin.W_group_mode, lin.channel_scale_mode, lin.get_meta_args(), str(lin.scales.dtype), tuple(lin.scales.shape),
+                str(lin.zeros.dtype), tuple(lin.zeros.shape), float(lin.zeros.float().sum()), float(lin.scales.float().sum()))))
+        except Exception as e:  # noqa: BLE001
+            rows.append(type(e).__name__)
+    np.savez_compressed(os.path.join(out_dir, "pack_grid.npz"), rows=np.array(rows))
+    print("pack_grid:", len(rows), "combinations,", sum(r.startswith("ok") for r in rows), "accepted")
+
+
 if __name__ == "__main__" and os.environ.get("GEN_HOST_TABLES", "1") == "1":
     _out = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
     host_tables(_out)
     ctor_grid(_out)
+    pack_grid(_out)
