@@ -427,3 +427,19 @@ def test_pack_decisions_match_the_reference_on_a_grid():
         if got != want:
             bad.append(((nb, sk, zk, fma, dt, sa), got, want))
     assert not bad, (len(bad), bad[:4])
+
+
+def test_c_consumer_links_and_queries(tmp_path):
+    """include/gemlite_hip.h is valid C99 and a plain-C program can link the library and use the host-only entry points."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    _hip.load()
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(_hip.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi", "abi_smoke.c"), "-o", exe, "-L", libdir, "-lgemlite_hip",
+                    f"-Wl,-rpath,{libdir}"], check=True, capture_output=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "gemv_wn_kernel<tile16,xdirect,16w>" in out and "libgemlite_hip gfx950" in out
