@@ -394,8 +394,10 @@ class GemLiteLinearHIP(torch.nn.Module):
         self.meta_dtype = TORCH_TO_DTYPE[self.scales.dtype]
 
         as_param = lambda t: torch.nn.Parameter(t, requires_grad=False)  # noqa: E731
-        self.W_q, self.scales, self.zeros = as_param(self.W_q), as_param(self.scales), as_param(self.zeros)
+        # registration order = key order of state_dict(): W_q, bias, scales, zeros, metadata, orig_shape (core.py:503-517)
+        self.W_q = as_param(self.W_q)
         self.bias = as_param(self.bias) if self.bias is not None else None
+        self.scales, self.zeros = as_param(self.scales), as_param(self.zeros)
         self.metadata = as_param(torch.tensor(self.get_meta_args(), device=self.device, dtype=torch.int32))
         self.orig_shape = as_param(torch.tensor([self.out_features, self.in_features], device=self.device,
                                                 dtype=torch.int32))

@@ -153,8 +153,37 @@ def pack_grid(out_dir):
     print("pack_grid:", len(rows), "combinations,", sum(r.startswith("ok") for r in rows), "accepted")
 
 
+def dtype_table_and_state_dicts(out_dir):
+    """DType members (dtypes.py:8-29) and the state_dict() of three packed reference layers (core.py:301-333, 503-517)."""
+    G._fake_device_and_import()
+    from gemlite import DType, GemLiteLinear
+    from gemlite import helper as H
+    blob = {"dtype_names": np.array([d.name for d in DType]), "dtype_values": np.array([d.value for d in DType], np.int64)}
+    g = torch.Generator().manual_seed(77)
+    W_q = torch.randint(0, 16, (32, 256), generator=g, dtype=torch.int32).to(torch.uint8)
+    sc = (torch.rand(32 * 256 // 128, 1, generator=g) * 0.01 + 0.001).to(torch.float16)
+    zr = torch.round(torch.rand(32 * 256 // 128, 1, generator=g) * 15).to(torch.float16)
+    bias = (torch.randn(32, generator=g) / 10).to(torch.float16)
+    W = (torch.randn(32, 256, generator=g) / 30).to(torch.float16)
+    lin_a = GemLiteLinear(4, 128, 256, 32, DType.FP16, DType.FP16)
+    lin_a.pack(W_q, sc, zr, bias)
+    layers = {"a16w4": lin_a, "a8w8": H.A8W8_dynamic(device="cpu", fp8=False).from_weights(W.clone()),
+              "bitnet": H.A16W158_INT(device="cpu").from_weights(torch.randint(-1, 2, (32, 256), generator=g).to(torch.float16), torch.tensor(0.03))}
+    blob.update(sd_in_W_q=G._np(W_q), sd_in_scales=G._np(sc), sd_in_zeros=G._np(zr), sd_in_bias=G._np(bias))
+    for name, lin in layers.items():
+        sd = lin.state_dict()
+        blob[f"sd_{name}__keys"] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            blob[f"sd_{name}__{k}"] = G._np(v)
+            blob[f"sd_{name}__{k}__dtype"] = np.array(str(v.dtype))
+        blob[f"sd_{name}__meta_args"] = np.array(lin.get_meta_args(), np.int64)
+        print(name, list(sd.keys()), lin.get_meta_args())
+    np.savez_compressed(os.path.join(out_dir, "state_dicts.npz"), **blob)
+
+
 if __name__ == "__main__" and os.environ.get("GEN_HOST_TABLES", "1") == "1":
     _out = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
     host_tables(_out)
     ctor_grid(_out)
     pack_grid(_out)
+    dtype_table_and_state_dicts(_out)

@@ -443,3 +443,39 @@ def test_c_consumer_links_and_queries(tmp_path):
                     f"-Wl,-rpath,{libdir}"], check=True, capture_output=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "gemv_wn_kernel<tile16,xdirect,16w>" in out and "libgemlite_hip gfx950" in out
+
+
+def _from_bits(arr, dtype_str):
+    t = torch.from_numpy(np.array(arr))
+    if dtype_str == "torch.bfloat16":
+        return t.view(torch.bfloat16)
+    if dtype_str == "torch.float8_e4m3fn":
+        return t.view(torch.float8_e4m3fn)
+    return t
+
+
+def test_dtype_codes_and_state_dict_format_match_the_reference():
+    """DType members / codes, and the reference's own state_dict() of three packed layers: loading it here gives the same
+    meta_args and tensors, and this package's state_dict() of the same layer has the same keys, dtypes and bits."""
+    from gemlite_amd import helper as H
+    z = np.load(os.path.join(GOLDEN, "state_dicts.npz"))
+    ref_codes = {str(n): int(v) for n, v in zip(z["dtype_names"], z["dtype_values"])}
+    mine = {d.name: d.value for d in DType}
+    assert mine == ref_codes
+    W_q, sc = torch.from_numpy(z["sd_in_W_q"]), torch.from_numpy(z["sd_in_scales"])
+    zr, bias = torch.from_numpy(z["sd_in_zeros"]), torch.from_numpy(z["sd_in_bias"])
+    built = GemLiteLinear(4, 128, 256, 32, DType.FP16, DType.FP16)
+    built.pack(W_q, sc, zr, bias)
+    for name in ("a16w4", "a8w8", "bitnet"):
+        keys = [str(k) for k in z[f"sd_{name}__keys"]]
+        sd = {k: _from_bits(z[f"sd_{name}__{k}"], str(z[f"sd_{name}__{k}__dtype"])) for k in keys}
+        lin = GemLiteLinear()
+        lin.load_state_dict(dict(sd))
+        assert lin.get_meta_args() == [int(v) for v in z[f"sd_{name}__meta_args"]], name
+        assert torch.equal(lin.W_q, sd["W_q"]) and torch.equal(lin.scales, sd["scales"]) and torch.equal(lin.zeros, sd["zeros"])
+        if name == "a16w4":  # the same layer packed here serialises to the same dictionary
+            mine_sd = built.state_dict()
+            assert list(mine_sd.keys()) == keys
+            for k in keys:
+                assert str(mine_sd[k].dtype) == str(z[f"sd_{name}__{k}__dtype"]), k
+                assert np.array_equal(_bits(mine_sd[k]), z[f"sd_{name}__{k}"]), k
