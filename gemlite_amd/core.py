@@ -109,28 +109,37 @@ def get_matmul_type(batch_size: int, W_nbits: int, mx_dtype: bool = False) -> st
 # ------------------------------------------------------------------------------------------------------
 _META_FIELDS = ("scaled_activations", "W_nbits", "group_size", "unpack_mask", "elements_per_sample", "input_dtype",
                 "output_dtype", "acc_dtype", "meta_dtype", "channel_scale_mode", "W_group_mode", "data_contiguous")
-_ARGS_CACHE: dict = {}
 TUNING_OVERRIDE = None  # development hook: 4 ints forwarded as gemlite_hip_forward_args.tuning (0 = library default)
 
+# Per-layer launch templates.  A template is the IMMUTABLE byte image of a gemlite_hip_forward_args whose static
+# fields (weights, metadata, strides, dtypes, modes) are filled in; every call copies it into a fresh struct and
+# adds the per-call fields (x, out, M, strides, scales_x, workspace, tuning) — no shared mutable state, so two
+# threads / streams may launch the same layer concurrently.  The key holds EVERY value the template is derived
+# from (addresses, shapes, strides, dtypes, numel, device, meta ints): an address reused by the allocator either
+# misses, or hits an entry that is correct by construction.
+_TEMPLATES: dict = {}
+_SIZEOF_ARGS = _hip.C.sizeof(_hip.ForwardArgs)
 
-def _static_args(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> _hip.ForwardArgs:
-    key = (W_q.data_ptr(), scales.data_ptr(), zeros.data_ptr(), tuple(meta_args), tuple(W_q.shape))
-    a = _ARGS_CACHE.get(key)
-    if a is not None:
-        return a
+
+def _template_key(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> tuple:
+    return (W_q.data_ptr(), tuple(W_q.shape), W_q.stride(), W_q.dtype, W_q.device.index,
+            scales.data_ptr(), tuple(scales.shape), scales.stride(), scales.dtype,
+            zeros.data_ptr(), tuple(zeros.shape), zeros.stride(), zeros.dtype, tuple(meta_args))
+
+
+def _build_template(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> bytes:
     (_sa, W_nbits, group_size, unpack_mask, e, in_dt, out_dt, acc_dt, meta_dt, c_mode, w_mode, contiguous) = meta_args
     a = _hip.ForwardArgs()
-    a.struct_size = _hip.C.sizeof(_hip.ForwardArgs)
+    a.struct_size = _SIZEOF_ARGS
+    a.matmul_type = -1
     a.w_q = W_q.data_ptr()
     a.scales = scales.data_ptr() if scales.numel() > 0 else None
     a.zeros = zeros.data_ptr() if zeros.numel() > 0 else None
     a.N = W_q.shape[1]
     a.K = W_q.shape[0] * e
     a.W_nbits, a.group_size, a.unpack_mask, a.elements_per_sample = W_nbits, group_size, unpack_mask, e
-    if e > 1:
-        a.w_pack_bits, a.w_dtype = W_q.element_size() * 8, TORCH_TO_DTYPE[W_q.dtype].value
-    else:
-        a.w_pack_bits, a.w_dtype = 0, TORCH_TO_DTYPE[W_q.dtype].value
+    a.w_pack_bits = W_q.element_size() * 8 if e > 1 else 0
+    a.w_dtype = TORCH_TO_DTYPE[W_q.dtype].value
     a.input_dtype, a.output_dtype, a.acc_dtype = in_dt, out_dt, acc_dt
     a.meta_dtype = TORCH_TO_DTYPE[scales.dtype].value if scales.numel() > 0 else meta_dt
     a.zeros_dtype = TORCH_TO_DTYPE[zeros.dtype].value if zeros.numel() > 0 else meta_dt
@@ -146,10 +155,19 @@ def _static_args(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> _hip.
         a.stride_meta_g, a.stride_meta_n = zeros.stride(0), zeros.stride(1)
     else:
         a.stride_meta_g, a.stride_meta_n = 0, 1
-    if len(_ARGS_CACHE) > 4096:
-        _ARGS_CACHE.clear()
-    _ARGS_CACHE[key] = a
-    return a
+    return bytes(a)
+
+
+def _static_args(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> _hip.ForwardArgs:
+    """A FRESH gemlite_hip_forward_args with the layer's static fields filled in (the caller owns it)."""
+    key = _template_key(W_q, scales, zeros, meta_args)
+    t = _TEMPLATES.get(key)
+    if t is None:
+        t = _build_template(W_q, scales, zeros, meta_args)
+        if len(_TEMPLATES) > 8192:
+            _TEMPLATES.clear()
+        _TEMPLATES[key] = t
+    return _hip.ForwardArgs.from_buffer_copy(t)
 
 
 def config_key(M: int, N: int, K: int, group_size: int, elements_per_sample: int, type_id: int) -> str:
@@ -163,9 +181,13 @@ def config_family(matmul_type: int, M: int, W_nbits: int) -> str:
     return GEMLITE_MATMUL_TYPES[matmul_type] if matmul_type >= 0 else get_matmul_type(M, W_nbits)
 
 
+_TUNING_MASK = (0xFF, 0xFF, 0xFF, 0x3)  # tuning[3]: only the documented x-path bits; development bits are not loadable
+
+
 def lookup_tuning(matmul_type: int, M: int, a) -> Optional[tuple]:
-    """tuning[4] for this launch from GEMLITE_HIP_CONFIG_CACHE (filled by load_config() or helper.autotune_layer()),
-    or None: the library's own planner decides.  Entries look like {"tuning": [t0, t1, t2, t3], "us": 4.5}."""
+    """tuning[4] for this launch from GEMLITE_HIP_CONFIG_CACHE (filled by load_config(), the shipped per-GPU table or
+    helper.autotune_layer()), or None: the library's own planner decides.  Entries look like
+    {"tuning": [t0, t1, t2, t3], "us": 4.5}."""
     if not GEMLITE_HIP_CONFIG_CACHE:
         return None
     fam = GEMLITE_HIP_CONFIG_CACHE.get(config_family(matmul_type, M, a.W_nbits))
@@ -174,17 +196,20 @@ def lookup_tuning(matmul_type: int, M: int, a) -> Optional[tuple]:
     entry = fam.get(config_key(M, a.N, a.K, a.group_size, a.elements_per_sample, a.type_id))
     if not entry or "tuning" not in entry:
         return None
-    t = tuple(int(v) for v in entry["tuning"])
-    return (t + (0, 0, 0, 0))[:4]
+    t = (tuple(int(v) for v in entry["tuning"]) + (0, 0, 0, 0))[:4]
+    return tuple(v & m for v, m in zip(t, _TUNING_MASK))
 
 
 def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x: Optional[Tensor], meta_args,
                 matmul_type: int, tuning=None) -> Tensor:
     """out[M, N] = epilogue(x[M, K] @ dequant(W_q)) — the seam the reference fills with
-    GEMLITE_TRITON_MAPPING[...].forward (core.py:184-190)."""
+    GEMLITE_TRITON_MAPPING[...].forward (core.py:184-190).  ONE C call per launch: the library plans, carves the
+    caller's per-stream workspace and launches; only if that workspace turns out too small is it regrown."""
     lib = _hip.load()
     _hip.require_gpu_tensor(x, "x")
     _hip.require_gpu_tensor(W_q, "W_q")
+    if x.device != W_q.device:
+        raise _hip.GemliteHipError(f"x is on {x.device}, the packed weight on {W_q.device}")
     a = _static_args(W_q, scales, zeros, meta_args)
     M, K = x.shape
     if K != a.K:
@@ -197,24 +222,30 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
     a.stride_om, a.stride_on = out.stride(0), out.stride(1)
     if scales_x is not None:
         a.scales_x, a.stride_sx_m = scales_x.data_ptr(), scales_x.stride(0)
-    else:
-        a.scales_x, a.stride_sx_m = None, 0
     if tuning is None:
         tuning = TUNING_OVERRIDE
     if tuning is None:
         tuning = lookup_tuning(matmul_type, M, a)
-    for i in range(4):
-        a.tuning[i] = 0 if tuning is None else int(tuning[i])
-    stream = _hip.current_stream_handle(x.device)
-    need = lib.gemlite_hip_workspace_bytes(_hip.C.byref(a))
-    if not need and a.tuning[3] & 4:
-        need = 1 << 20  # development: the timeline probes write into the workspace
-    if need:
-        ws = _hip.workspace(x.device, stream, need)
+    if tuning is not None:
+        for i in range(4):
+            a.tuning[i] = int(tuning[i])
+    dev_idx = x.device.index
+    guard = torch.cuda.device(dev_idx) if dev_idx != torch.cuda.current_device() else None
+    if guard is not None:
+        guard.__enter__()  # launches go to the tensor's device, not the thread's current one
+    try:
+        stream = _hip.current_stream_handle(x.device)
+        ws = _hip.workspace(x.device, stream, 0)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    else:
-        a.workspace, a.workspace_bytes = None, 0
-    rc = lib.gemlite_hip_forward(_hip.C.byref(a), stream)
+        rc = lib.gemlite_hip_forward(_hip.C.byref(a), stream)
+        if rc == _hip.ERR_WORKSPACE:
+            need = lib.gemlite_hip_workspace_bytes(_hip.C.byref(a))
+            ws = _hip.workspace(x.device, stream, need)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            rc = lib.gemlite_hip_forward(_hip.C.byref(a), stream)
+    finally:
+        if guard is not None:
+            guard.__exit__(None, None, None)
     if rc != 0:
         _hip.raise_for_status(rc, "gemlite_hip_forward")
     return out
@@ -244,13 +275,13 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
     return out
 
 
-@torch.library.custom_op("gemlite_amd::forward_functional", mutates_args=())
+@torch.library.custom_op("gemlite::forward_functional", mutates_args=())
 def forward_functional(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], meta_args: List[int],
                        matmul_type: int = -1) -> Tensor:
     return _forward_impl(x, bias, tensor_args, meta_args, matmul_type)
 
 
-@torch.library.register_fake("gemlite_amd::forward_functional")
+@torch.library.register_fake("gemlite::forward_functional")
 def _forward_functional_fake(x, bias, tensor_args, meta_args, matmul_type=-1):
     return torch.empty(x.shape[:-1] + (tensor_args[0].shape[1],), device=x.device, dtype=x.dtype)
 
