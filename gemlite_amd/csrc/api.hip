@@ -9,6 +9,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "gl_common.h"
 
 namespace gl {
@@ -18,6 +20,7 @@ bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
 const void* kmajor_w8a16_kernel_fn(int mb);
@@ -131,13 +134,17 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         if (p.gs_shift < 0) goto coverage;  // group size not a power of two
         if (want_gemv && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }
         if (!want_gemv) {
-            // AUTO: the tiled kernel from 33 rows (a half-empty 128-row tile still beats the LDS-staged streaming
-            // kernel: 4096^2, M = 64: ~20 us vs 47 us)
+            // Many rows: the 8-wave MFMA kernel (all bit widths) from 33 rows.  tuning[0]: 1 = LDS-staged streaming kernel,
+            // 2 = the 4-wave tiled kernel of round 1 (4-bit only; kept for A/B runs)
             const bool want_tiled = (mt == GEMLITE_MATMUL_GEMM || (mt == GEMLITE_MATMUL_AUTO && a.M > 32));
+            if (want_tiled && a.tuning[0] == 0 && plan_gemm_wn_mma(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
             if (want_tiled && a.tuning[0] != 1 && plan_gemm_wn_tiled(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
             // few rows: registers-only MFMA path (tuning[2] == 1 keeps the LDS-staged streaming kernel)
-            if (a.M <= 32 && a.tuning[2] != 1 && plan_gemm_wn_direct(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
-            if (plan_gemm_wn_stream(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
+            if (a.M <= 32 && a.tuning[2] != 1 && a.tuning[0] != 3 && plan_gemm_wn_direct(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
+            if (a.tuning[0] != 3 && plan_gemm_wn_stream(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
+            // shapes the few-row kernels do not take (K = 11008, 8960, ...): small tiles of the MFMA kernel, never the
+            // coverage kernel (tuning[0] == 3 forces this path for A/B runs)
+            if (plan_gemm_wn_mma(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
         }
         // AUTO with small M that the GEMV planner rejected may still fit the streaming kernel
         if (want_gemv && mt == GEMLITE_MATMUL_AUTO && plan_gemm_wn_stream(a, p, lp)) {
@@ -215,22 +222,44 @@ static int launch(const void* fn, dim3 grid, dim3 block, void** kargs, size_t ld
     return GEMLITE_OK;
 }
 
-static int ensure_lds(const void* fn, size_t lds) {
+// The current device must be a gfx950 part: the code object holds no other ISA.  Checked once per device id.
+static int check_device(int* dev_out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) { (void)hipGetLastError(); return GEMLITE_ERR_NO_DEVICE; }
+    *dev_out = dev;
+    static std::atomic<int> state[64];  // 0 unknown | 1 gfx950 | 2 something else
+    const int slot = dev & 63;
+    int st = state[slot].load(std::memory_order_relaxed);
+    if (st == 0) {
+        hipDeviceProp_t prop;
+        st = (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 2;
+        state[slot].store(st, std::memory_order_relaxed);
+    }
+    return st == 1 ? GEMLITE_OK : GEMLITE_ERR_NO_DEVICE;
+}
+
+// Raise the dynamic-LDS cap of a kernel above 64 KiB: once per (device, kernel) — the attribute is per device.
+static int ensure_lds(const void* fn, size_t lds, int dev) {
     if (lds <= 65536) return GEMLITE_OK;
-    static thread_local const void* done[8] = {nullptr};  // raise the dynamic-LDS cap once per kernel
-    for (const void* d : done) if (d == fn) return GEMLITE_OK;
+    struct Done { const void* fn; int dev; };
+    static thread_local Done done[32] = {};
+    for (const Done& d : done) if (d.fn == fn && d.dev == dev) return GEMLITE_OK;
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) { tl_last_hip_error = (int)err; (void)hipGetLastError(); return GEMLITE_ERR_LAUNCH; }
-    for (const void*& d : done) if (!d) { d = fn; break; }
+    static thread_local int next = 0;
+    done[next] = Done{fn, dev};
+    next = (next + 1) & 31;
     return GEMLITE_OK;
 }
+
+__global__ void gemlite_noop_kernel() {}
 
 extern "C" {
 
 int gemlite_hip_abi_version(void) { return GEMLITE_HIP_ABI_VERSION; }
 
 const char* gemlite_hip_build_info(void) {
-    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_direct, gemm_wn_stream, gemm_wn_tiled, gemm_a8w8, kmajor, generic, "
+    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_direct, gemm_wn_stream, gemm_wn_mma, gemm_wn_tiled, gemm_a8w8, kmajor, generic, "
            "act_quant_per_token, pack/unpack_over_cols";
 }
 
@@ -276,12 +305,22 @@ void gemlite_hip_set_profile_events(void* start_event, void* stop_event) {
     tl_evt_stop = stop_event;
 }
 
+int gemlite_hip_launch_noop(int32_t blocks, int32_t threads, void* stream) {
+    if (blocks <= 0 || threads <= 0 || threads > 1024) return GEMLITE_ERR_BAD_ARGUMENT;
+    void* none[1] = {nullptr};
+    return launch((const void*)gemlite_noop_kernel, dim3((unsigned)blocks, 1, 1), dim3((unsigned)threads, 1, 1), none, 0,
+                  (hipStream_t)stream);
+}
+
 int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
     const int v = validate(args);
     if (v != GEMLITE_OK) return v;
     Resolved r;
     resolve(*args, r);
     if (r.status != GEMLITE_OK) return r.status;
+    int dev = 0;
+    const int dv = check_device(&dev);
+    if (dv != GEMLITE_OK) return dv;
     hipStream_t st = (hipStream_t)stream;
     if (r.kind == K_GEMV_WN || r.kind == K_STREAM_WN || r.kind == K_TILED_WN) {
         if (r.lp.ws_bytes > 0) {
@@ -291,7 +330,7 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
         } else if (args->workspace && args->workspace_bytes >= COUNTER_BYTES) {
             r.wn.counters = (unsigned*)args->workspace;  // lets the opt-in timeline probes (tuning[3] & 4) find a buffer
         }
-        const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes);
+        const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes, dev);
         if (e != GEMLITE_OK) return e;
         void* kargs[] = {(void*)&r.wn};
         return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);

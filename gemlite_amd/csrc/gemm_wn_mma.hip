@@ -1,0 +1,546 @@
+// gemm_wn_mma.hip — fused unpack + dequant + tiled MFMA GEMM for packed low-bit weights (4 / 2 / 1 / 8-bit words),
+// the large-M (prefill) kernel.  Replaces gemm_INT_kernel (gemlite/triton_kernels/gemm_kernels.py:248-413) and, for
+// shapes the few-row kernels do not take, gemm_splitK_INT_kernel (gemm_splitK_kernels.py:277-450).
+//
+// Design (CDNA4; numbers in DESIGN.md §3.3):
+//   * Block = 8 waves = two waves per SIMD, tile (32*MI) x 128, K step KSTEP (128 or 256).  Wave (cg = wave & 3,
+//     kh = wave >> 2) owns ALL rows x columns [32cg, 32cg+32) x the kh-th HALF of every K step: the two waves of a SIMD
+//     work on different halves of K, so one wave's MFMAs cover the other's unpack arithmetic, LDS reads and memory
+//     requests, and a 256-row tile (the shape that needs the least dequant work per MFMA: 19 VALU per 8 MFMAs) no
+//     longer leaves the SIMD with a single in-order wave.  The two K halves are added through LDS in the epilogue.
+//   * B: one packed int32 word holds 8 (4-bit) / 16 / 32 / 4 consecutive k of ONE column, i.e. 1 / 2 / 4 / half of a
+//     lane's B fragment of v_mfma_f32_32x32x16 (lane = column l & 31, k-octet l >> 5).  The wave loads its words
+//     straight from HBM / L2 with buffer loads (voffset = column, soffset = packed row: no VALU per load),
+//     dequantises them in registers in natural k order and feeds MI MFMAs with each fragment.  Weights never touch LDS.
+//   * A (x): the (32*MI) x KSTEP tile of every step goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no
+//     VGPR staging and no ds_write; the 16-byte slots of a row are XOR-swizzled with (row & 15) by permuting the
+//     per-lane SOURCE address (the LDS image of a DMA is lane-linear), which makes the ds_read_b128 of 32 rows
+//     conflict-free.  Two stages; everything a step needs is requested one step (x) / two steps (weights) ahead,
+//     so ONE s_waitcnt vmcnt(0) + ONE s_barrier per step is all the synchronisation there is, and both sit a few
+//     MFMA slots before the end of the step so that the first fragments of the next stage are read under MFMAs.
+//   * K may be split over gridDim.y; slices are combined with the write-through slab + ticket protocol (gl_common.h).
+#include <type_traits>
+
+#include "gl_common.h"
+
+namespace gl {
+
+namespace mma {
+
+constexpr int BN = 128;
+constexpr int C_ROWS = 128;        // rows of the epilogue staging tile (one pass per 128 rows)
+constexpr int C_PITCH = BN + 4;    // floats per row of that tile
+constexpr int LOOKAHEAD = 4;       // A fragments requested ahead of their MFMA
+
+template <typename Tag>
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 mfma32<half_tag>(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 mfma32<bf16_tag>(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
+}
+
+// ---- geometry of one 64-k sub-block by bit width ------------------------------------------------------------------
+// WPL words per lane, packed row of word i for lane half h: rb + RI(i) + HS * h, k offset (inside the sub-block) of
+// MFMA slice u for lane half h: KO(u, h).
+template <int NBITS>
+struct Geo {
+    static constexpr int E = 32 / NBITS;
+    static constexpr int WPL = NBITS;                       // 4 -> 4 words, 2 -> 2, 1 -> 1, 8 -> 8
+    static constexpr int ROWS = 64 / E;                     // packed rows per sub-block
+    static constexpr int HS = NBITS == 8 ? 2 : 1;
+    static __device__ __forceinline__ constexpr int row_of(int i) { return NBITS == 8 ? 4 * (i >> 1) + (i & 1) : (NBITS == 1 ? 0 : 2 * i); }
+    static __device__ __forceinline__ constexpr int k_of(int u, int h) {
+        return NBITS == 2 ? 16 * (2 * (u >> 1) + h) + 8 * (u & 1) : (NBITS == 1 ? 32 * h + 8 * u : 8 * (2 * u + h));
+    }
+};
+
+// ---- integer codes of slice u as bytes: byte j of `ev` = code 2j, byte j of `od` = code 2j + 1 (natural k order) -----
+template <int NBITS>
+struct Extract;
+template <>
+struct Extract<4> {
+    __device__ __forceinline__ static void run(const uint32_t (&w)[4], int u, uint32_t& ev, uint32_t& od) {
+        ev = w[u] & 0x0F0F0F0Fu;
+        od = (w[u] >> 4) & 0x0F0F0F0Fu;
+    }
+};
+template <>
+struct Extract<8> {
+    __device__ __forceinline__ static void run(const uint32_t (&w)[8], int u, uint32_t& ev, uint32_t& od) {
+        ev = __builtin_amdgcn_perm(w[2 * u + 1], w[2 * u], 0x06040200u);  // bytes 0, 2 of each word
+        od = __builtin_amdgcn_perm(w[2 * u + 1], w[2 * u], 0x07050301u);  // bytes 1, 3
+    }
+};
+template <>
+struct Extract<2> {
+    // m_a = (w >> 2a) & 0x03030303: byte b of m_a = code 4b + a.  Slice t = u & 1 of word u >> 1 holds codes 8t .. 8t+7.
+    __device__ __forceinline__ static void run(const uint32_t (&w)[2], int u, uint32_t& ev, uint32_t& od) {
+        const uint32_t x = w[u >> 1];
+        const uint32_t m0 = x & 0x03030303u, m1 = (x >> 2) & 0x03030303u, m2 = (x >> 4) & 0x03030303u, m3 = (x >> 6) & 0x03030303u;
+        const uint32_t sel = (u & 1) ? 0x07030602u : 0x05010400u;  // {m0.b[2t], m2.b[2t], m0.b[2t+1], m2.b[2t+1]}
+        ev = __builtin_amdgcn_perm(m2, m0, sel);
+        od = __builtin_amdgcn_perm(m3, m1, sel);
+    }
+};
+template <>
+struct Extract<1> {
+    // m_a = (w >> a) & 0x01010101: byte b of m_a = bit 8b + a, i.e. code a of slice b
+    __device__ __forceinline__ static void run(const uint32_t (&w)[1], int u, uint32_t& ev, uint32_t& od) {
+        const uint32_t x = w[0];
+        uint32_t m[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) m[a] = (x >> a) & 0x01010101u;
+        const uint32_t s2 = 0x0C0C0400u + 0x00000101u * (uint32_t)u;  // {lo.b[u], hi.b[u], 0, 0}
+        const uint32_t e01 = __builtin_amdgcn_perm(m[2], m[0], s2), e23 = __builtin_amdgcn_perm(m[6], m[4], s2);
+        const uint32_t o01 = __builtin_amdgcn_perm(m[3], m[1], s2), o23 = __builtin_amdgcn_perm(m[7], m[5], s2);
+        ev = e01 | (e23 << 16);
+        od = o01 | (o23 << 16);
+    }
+};
+
+// ---- codes -> one B fragment (8 dequantised 16-bit floats, natural k order) --------------------------------------------
+template <typename Tag>
+struct Convert;
+template <>
+struct Convert<bf16_tag> {
+    float A, B;  // v = fma(q, A, B) in fp32, rounded once to bf16
+    __device__ __forceinline__ void set(float s, float z, float u13, float u4) {
+        A = s;
+        B = z * __builtin_fmaf(-u13, s, u4);
+    }
+    // pair j = codes 2j, 2j+1 of the slice: two v_cvt_f32_ubyte<j>, two v_fma_f32, one v_cvt_pk_bf16_f32
+    __device__ __forceinline__ uint32_t pair(uint32_t ev, uint32_t od, int j) const {
+        const float lo = (float)((ev >> (8 * j)) & 0xFFu), hi = (float)((od >> (8 * j)) & 0xFFu);
+        const b2_t v = {(__bf16)__builtin_fmaf(lo, A, B), (__bf16)__builtin_fmaf(hi, A, B)};
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+template <>
+struct Convert<half_tag> {
+    h2_t zsub2, s2, zadd2;  // v = fma(q - zsub, s, zadd) in fp16: rounds where the reference rounds (utils.py:73-87)
+    __device__ __forceinline__ void set(float s, float z, float u13, float u4) {
+        const _Float16 zs = (_Float16)(z * u13), za = (_Float16)(z * u4), sc = (_Float16)s;
+        zsub2 = (h2_t){zs, zs};
+        zadd2 = (h2_t){za, za};
+        s2 = (h2_t){sc, sc};
+    }
+    __device__ __forceinline__ uint32_t pair(uint32_t ev, uint32_t od, int j) const {
+        // {0, od.b[j], 0, ev.b[j]} | (1024, 1024): 1024 + q exactly, then q = that - 1024
+        const uint32_t sel = 0x0C040C00u + 0x00010001u * (uint32_t)j;
+        const uint32_t h = __builtin_amdgcn_perm(od, ev, sel) | 0x64006400u;
+        const h2_t q = __builtin_bit_cast(h2_t, h) - (h2_t){(_Float16)1024.0f, (_Float16)1024.0f};
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(q - zsub2, s2, zadd2));
+    }
+};
+
+// (in a __device__ function: a "v" constraint inside a lambda of the kernel body silently drops the kernel's host stub)
+__device__ __forceinline__ void opaque2(uint32_t& a, uint32_t& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from buffer offset (voff per lane + soff) to LDS [dst, dst + 1024), lane-linear.
+// (A __device__ function: the address-space cast inside a kernel-body lambda silently drops the kernel's host stub.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+}
+
+}  // namespace mma
+
+// MI 32-row blocks per wave (tile rows = 32 * MI), KSTEP k per step (each wave: KSTEP / 2).
+template <typename Tag, int NBITS, int MI, int KSTEP>
+__global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
+    using namespace mma;
+    using TR = F16Traits<Tag>;
+    using G = Geo<NBITS>;
+    constexpr int BM = 32 * MI, KW = KSTEP / 2, SUB = KW / 64, WPL = G::WPL;
+    constexpr int PITCH = KSTEP * 2, STAGE = BM * PITCH;  // bytes per row / per stage of x
+    constexpr int SLOTS_ROW = PITCH / 16;                  // 16-byte slots per row (16 or 32)
+    constexpr int PIECES = STAGE / 1024 / 8;               // 1-KiB LDS-DMA pieces per wave and stage
+    constexpr int NS = SUB * 4;                            // MFMA slices (k16) per wave and step
+    constexpr int NQ = NS * MI;                            // MFMA slots per wave and step
+    constexpr int L = LOOKAHEAD;
+    static_assert(SUB >= 1 && PIECES >= 1 && NQ >= 2 * L, "tile too small for the slot schedule");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][STAGE], later the epilogue tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, kh = wave >> 2;
+    const int col = lane & 31, h = lane >> 5;
+    const int mtiles = (p.M + BM - 1) / BM;
+    const int bid = blockIdx.x;
+    const int mt = bid % mtiles, nt = bid / mtiles;  // M tiles fastest: neighbours share the weight tile in L2
+    const int slice = blockIdx.y;
+    const int m0 = mt * BM;
+    const int n = nt * BN + cg * 32 + col;  // this lane's column
+
+    const int nsteps = p.rows_per_slice / (KSTEP / G::E);
+    const int row_s0 = slice * p.rows_per_slice;  // first packed row of the slice
+    const int k_s0 = row_s0 * G::E;
+
+    const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
+    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
+    const float u13 = (p.w_mode == 1 || p.w_mode == 3) ? 1.f : 0.f, u4 = p.w_mode == 4 ? 1.f : 0.f;
+    const int sw = (int)p.stride_wk;
+    const int ms = (need_s || need_z) ? (int)p.stride_meta_g : 0;
+    const int meta_rows = p.gs_shift >= 31 ? 1 : (p.K >> p.gs_shift);
+    const int meta_bytes = ((meta_rows - 1) * ms + p.N) * 2;
+    // every global access is a raw buffer access: run-ahead past the slice, rows >= M and absent metadata read zeros
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)row_s0 * sw), (short)0, p.rows_per_slice * sw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(need_s ? p.scales : (const void*)p.w), (short)0, need_s ? meta_bytes : 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(need_z ? p.zeros : (const void*)p.w), (short)0, need_z ? meta_bytes : 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, (short)0, (int)(((int64_t)(p.M - 1) * p.stride_xm + p.K) * 2), 0x00020000);
+
+    // ---- B stream --------------------------------------------------------------------------------------------------
+    struct BStep { uint32_t w[SUB][WPL]; uint32_t s[SUB], z[SUB]; };
+    const uint32_t wvoff = (uint32_t)(G::HS * h * sw + n) * 4u;
+    const uint32_t mvoff = (uint32_t)n * 2u;
+    const int wave_row0 = kh * (KW / G::E);  // first packed row of this wave's half inside a step
+    auto load_b = [&](BStep& b, int step) {
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb) {
+            const int rb = step * (KSTEP / G::E) + wave_row0 + sb * G::ROWS;  // packed row (slice-relative) of the sub-block
+#pragma unroll
+            for (int i = 0; i < WPL; ++i)
+                b.w[sb][i] = __builtin_amdgcn_raw_buffer_load_b32(rsW, wvoff, (uint32_t)((rb + G::row_of(i)) * sw) * 4u, 0);
+            const uint32_t mo = (uint32_t)(((k_s0 + rb * G::E) >> p.gs_shift) * ms) * 2u;
+            b.s[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsS, mvoff, mo, 0);
+            b.z[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsZ, mvoff, mo, 0);
+        }
+    };
+    // ---- A stream: LDS-DMA pieces.  Piece j of wave w covers LDS bytes [(w * PIECES + j) * 1024, +1024) of a stage;
+    //      lane i's 16 bytes land at +16 i, i.e. row (byte / PITCH), physical slot (byte % PITCH) / 16, which holds the
+    //      logical slot  phys ^ (row & 15)  of that row.
+    uint32_t xvoff[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int byte = (wave * PIECES + j) * 1024 + lane * 16;
+        const int r = byte / PITCH, phys = (byte % PITCH) / 16;
+        const int logical = phys ^ (r & 15);
+        xvoff[j] = m0 + r < p.M ? (uint32_t)(((int64_t)(m0 + r) * p.stride_xm + k_s0 + logical * 8) * 2) : 0x80000000u;
+    }
+    auto stage_x = [&](int stage, int step) {
+        // SGPR offset of the step: readfirstlane makes the uniformity provable (otherwise hipcc wraps every DMA in a
+        // waterfall loop: v_readfirstlane / s_and_saveexec per instruction)
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP * 2);
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j)
+            lds_dma16(rsX, smem + stage * STAGE + (wave * PIECES + j) * 1024, xvoff[j], so);
+    };
+    // A fragment of slot q = (slice g, row block mi): row mi*32 + col, k = kh*KW + (g/4)*64 + k_of(g%4, h)
+    int fbase[2][NS];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int g = 0; g < NS; ++g) {
+            const int k = kh * KW + (g >> 2) * 64 + G::k_of(g & 3, h);
+            const int slot = k >> 3;
+            fbase[st][g] = st * STAGE + col * PITCH + (((slot & ~15) | ((slot ^ col) & 15)) << 4);
+        }
+    auto read_frag = [&](int stage, int q) -> u32x4 {
+        return *(const u32x4*)(smem + fbase[stage][q / MI] + (q % MI) * 32 * PITCH);
+    };
+
+    f32x16 acc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    Convert<Tag> cv;
+    uint32_t ev = 0, od = 0;  // codes of the slice being dequantised
+    // Dequantisation of one slice (-> 4 registers of a B fragment) is cut into pieces that hide behind the MI MFMAs of
+    // the slice before it: piece 0 = (scale, zero) of the sub-block + code extraction, then the 4 pairs.
+    auto deq_piece = [&](const BStep& b, int g, int mi, u32x4& out) {
+        const int sb = g >> 2, u = g & 3;
+        if (mi == 0) {
+            if (u == 0) {  // (scale, zero) of the sub-block; slices 1..3 reuse them
+                const float sc = need_s ? TR::to_float((uint16_t)b.s[sb]) : 1.f;
+                const float zr = need_z ? TR::to_float((uint16_t)b.z[sb]) : scalar_zero;
+                cv.set(sc, zr, u13, u4);
+            }
+            Extract<NBITS>::run(b.w[sb], u, ev, od);
+            // opaque to the optimiser: otherwise byte i becomes v_bfe_u32 + v_cvt_f32_ubyte0 instead of one v_cvt_f32_ubyte<i>
+            opaque2(ev, od);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((MI == 8 ? j + 1 : (j * MI) / 4) == mi) out[j] = cv.pair(ev, od, j);
+    };
+
+    BStep ring[4];
+    u32x4 af[L];
+    u32x4 bfrag[2];
+
+    // ---- prologue ----------------------------------------------------------------------------------------------------
+    load_b(ring[0], 0);
+    load_b(ring[1], nsteps > 1 ? 1 : 0);
+    stage_x(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) deq_piece(ring[0], 0, mi, bfrag[0]);
+#pragma unroll
+    for (int q = 0; q < L; ++q) af[q] = read_frag(0, q);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // One K step; J = step & 3 selects the ring slot / stage statically.  The step is written as NQ MFMA "slots"; slot q
+    // issues MFMA q, one piece of the next slice's dequantisation, the A fragment needed L slots later and its share of
+    // the step's memory requests (weights of step + 2, x of step + 1), and the order is pinned with sched_barrier:
+    // left alone, the machine scheduler pulls every ds_read back to just before its MFMA (LDS latency exposed) and
+    // groups the requests at the top of the step.
+    constexpr int NLB = SUB * (WPL + 2);   // weight / metadata requests per step
+    constexpr int NL = NLB + PIECES;       // + LDS-DMA pieces
+    constexpr int NQI = NQ - L;            // slots that may issue requests (all must precede the vmcnt(0) of the step)
+    auto do_step = [&](auto Jc, int step) {
+        constexpr int J = decltype(Jc)::value;
+        constexpr int stage = J & 1;
+        const BStep& bc = ring[J];
+        const BStep& bn = ring[(J + 1) & 3];
+        BStep& bl = ring[(J + 2) & 3];
+        // run-ahead past the slice re-reads its last step (never consumed): the SGPR offset of a buffer access is not
+        // part of the range check, so "out of range reads zeros" must not be relied upon here
+        const int lstep = __builtin_amdgcn_readfirstlane(step + 2 < nsteps ? step + 2 : nsteps - 1);
+        // the last step has no successor: it re-requests its own tile into the idle stage (branch-free; nobody reads it,
+        // and the step's vmcnt(0) + barrier retire the DMA before the epilogue reuses the LDS)
+        const uint32_t xso = (uint32_t)__builtin_amdgcn_readfirstlane((step + 1 < nsteps ? step + 1 : step) * KSTEP * 2);
+        auto request = [&](int it) {
+            if (it < NLB) {
+                const int sb = it / (WPL + 2), i = it % (WPL + 2);
+                const int rb = lstep * (KSTEP / G::E) + wave_row0 + sb * G::ROWS;
+                if (i < WPL) {
+                    bl.w[sb][i] = __builtin_amdgcn_raw_buffer_load_b32(rsW, wvoff, (uint32_t)((rb + G::row_of(i)) * sw) * 4u, 0);
+                } else {
+                    const uint32_t mo = (uint32_t)(((k_s0 + rb * G::E) >> p.gs_shift) * ms) * 2u;
+                    if (i == WPL) bl.s[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsS, mvoff, mo, 0);
+                    else bl.z[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsZ, mvoff, mo, 0);
+                }
+            } else {
+                const int j = it - NLB;
+                lds_dma16(rsX, smem + (stage ^ 1) * STAGE + (wave * PIECES + j) * 1024, xvoff[j], xso);
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int g = q / MI, mi = q % MI;
+            acc[mi] = mfma32<Tag>(af[q % L], bfrag[g & 1], acc[mi]);
+            if (g + 1 < NS) deq_piece(bc, g + 1, mi, bfrag[(g + 1) & 1]);
+            else deq_piece(bn, 0, mi, bfrag[(g + 1) & 1]);  // the next step's first slice
+            if (q == NQI) {
+                // everything this block requested for the next step has landed in every wave, and every wave has
+                // issued AND completed its reads of the current stage: the next stage may be read, this one refilled
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
+            else af[q % L] = read_frag(stage ^ 1, q + L - NQ);
+            if (q < NQI) {
+#pragma unroll
+                for (int it = (q * NL) / NQI; it < ((q + 1) * NL) / NQI; ++it) request(it);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+        do_step(std::integral_constant<int, 0>{}, s0);
+        if (s0 + 1 >= nsteps) break;
+        do_step(std::integral_constant<int, 1>{}, s0 + 1);
+        if (s0 + 2 >= nsteps) break;
+        do_step(std::integral_constant<int, 2>{}, s0 + 2);
+        if (s0 + 3 >= nsteps) break;
+        do_step(std::integral_constant<int, 3>{}, s0 + 3);
+    }
+
+    // ---- epilogue 1: add the two K halves (waves 4..7 hand their accumulators to waves 0..3 through LDS) ------------
+    __syncthreads();
+    {
+        float* xch = (float*)smem;  // [cg][mi][e4][lane][4]
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                float* a = xch + (((cg * MI + mi) * 4 + e4) * 64 + lane) * 4;
+                if (kh == 1) *(f32x4*)a = (f32x4){acc[mi][4 * e4], acc[mi][4 * e4 + 1], acc[mi][4 * e4 + 2], acc[mi][4 * e4 + 3]};
+            }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const f32x4 v = *(const f32x4*)(xch + (((cg * MI + mi) * 4 + e4) * 64 + lane) * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[mi][4 * e4 + t] += v[t];
+                }
+        }
+    }
+
+    // ---- epilogue 2: the tile is transposed through LDS (128 rows per pass) so that slabs and the output move as
+    //      16-byte row segments; C fragment of a 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    float* ct = (float*)smem;  // [C_ROWS][C_PITCH]
+    constexpr int PASS_ROWS = BM < C_ROWS ? BM : C_ROWS;
+    unsigned* flag = (unsigned*)(smem + PASS_ROWS * C_PITCH * 4);
+    constexpr int NPASS = BM / PASS_ROWS, MIP = PASS_ROWS / 32;
+    constexpr int UNITS = (PASS_ROWS * BN / 4 + 511) / 512;  // float4 units per thread and pass
+    constexpr int NOUT = BM * BN;
+    const int64_t ncol0 = (int64_t)nt * BN;
+    float* slab = p.slabs + ((int64_t)bid * p.splitk) * NOUT;  // wave-uniform base of this tile's slabs
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        __syncthreads();  // the exchange buffer / the previous pass is no longer read
+        if (kh == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MIP; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    ct[r * C_PITCH + cg * 32 + col] = acc[ps * MIP + mi][e];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + ps * PASS_ROWS + r;
+            if (r < PASS_ROWS && m < p.M) {
+                const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
+                if (p.splitk == 1) store_out4_t<Tag>(p.epi, v, m, ncol0 + c4);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                            (slice * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);  // sc1
+            }
+        }
+    }
+    if (p.splitk == 1) return;
+    __syncthreads();
+    if (!splitk_arrive_is_last(p.counters + bid, p.splitk, flag)) return;
+    // last arriver: slices outer, units inner -> every slice's 16-byte loads are in flight together
+    for (int ps = 0; ps < NPASS; ++ps) {
+        f32x4 sum[UNITS];
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) sum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.splitk; ++s) {
+            u32x4 t[UNITS];
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) {
+                const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+                t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (s * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) sum[i] += __builtin_bit_cast(f32x4, t[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + ps * PASS_ROWS + r;
+            if (r < PASS_ROWS && m < p.M) store_out4_t<Tag>(p.epi, sum[i], m, ncol0 + c4);
+        }
+    }
+    if (tid == 0) splitk_reset(p.counters + bid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side planning.  tuning[1]: 0 auto | n force split-K n;  tuning[2]: 0 auto | 1/2/4/8 force MI (tile rows / 32)
+// ---------------------------------------------------------------------------------------------------------------
+typedef void (*mma_kernel_fn)(const WnParams);
+template <typename Tag, int NBITS>
+static const void* mma_pick_mi(int mi) {
+    mma_kernel_fn f = nullptr;  // typed pointer first: a direct cast of the specialisation to void* does not instantiate the host stub
+    switch (mi) {
+        case 8: f = gemm_wn_mma_kernel<Tag, NBITS, 8, 128>; break;
+        case 4: f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128>; break;
+        case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256>; break;
+        case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256>; break;
+        default: break;
+    }
+    return (const void*)f;
+}
+template <typename Tag>
+static const void* mma_pick(int nbits, int mi) {
+    switch (nbits) {
+        case 4: return mma_pick_mi<Tag, 4>(mi);
+        case 2: return mma_pick_mi<Tag, 2>(mi);
+        case 1: return mma_pick_mi<Tag, 1>(mi);
+        case 8: return mma_pick_mi<Tag, 8>(mi);
+        default: return nullptr;
+    }
+}
+
+bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
+    const int nbits = a.W_nbits;
+    if (nbits != 4 && nbits != 2 && nbits != 1 && nbits != 8) return false;
+    const int e = 32 / nbits;
+    if (a.N % mma::BN != 0) return false;
+    if (a.output_dtype != a.input_dtype) return false;
+    const bool uses_s = a.W_group_mode >= 2 || a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
+    if (uses_s && a.meta_dtype != a.input_dtype) return false;
+    if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
+    if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
+    if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte LDS-DMA pieces
+    if (p.group_size % 64 != 0) return false;  // one (scale, zero) pair per column and 64-k sub-block
+    // tile rows: the largest tile that M fills at least half (a dequantised fragment feeds MI MFMAs)
+    int mi = a.M > 128 ? 8 : (a.M > 64 ? 4 : (a.M > 32 ? 2 : 1));
+    if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4 || a.tuning[2] == 8) mi = a.tuning[2];
+    const int kstep = mi >= 4 ? 128 : 256;
+    if (a.K % kstep != 0) {
+        if (a.K % 128 != 0 || a.tuning[2] != 0) return false;
+        mi = mi < 4 ? 4 : mi;  // K = 128 * odd: only the 128-k-step variants apply
+    }
+    const int ks = mi >= 4 ? 128 : 256;
+    const int bm = 32 * mi;
+    const int rows = (int)(a.K / e), step_rows = ks / e;
+    const int units = rows / step_rows;
+    // buffer descriptors: 32-bit byte offsets
+    if ((int64_t)rows * a.stride_wk * 4 >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31)) return false;
+    if (((int64_t)(a.K / (p.group_size > 0 ? p.group_size : a.K)) * p.stride_meta_g + a.N) * 2 >= (1ll << 31)) return false;
+    const int64_t tiles = (int64_t)(a.N / mma::BN) * ((a.M + bm - 1) / bm);
+    auto ok = [&](int sk) { return sk >= 1 && units % sk == 0; };
+    int splitk = 0;
+    if (a.tuning[1] > 0) {
+        if (!ok(a.tuning[1])) return false;
+        splitk = a.tuning[1];
+    } else {
+        // one block per CU (8 waves = two per SIMD): the fewest K slices that give every CU a block, as long as a
+        // slice keeps at least 4 steps (prologue + epilogue + combine are paid per block)
+        for (int sk = 1; sk <= units && sk <= 32; ++sk) {
+            if (!ok(sk) || units / sk < 4) continue;
+            splitk = sk;
+            if (tiles * sk >= 224) break;
+        }
+        if (!splitk) splitk = 1;
+    }
+    if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
+    if ((uint64_t)splitk * bm * mma::BN * 4 >= (1ull << 31)) return false;  // slab buffer descriptor range
+    const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
+    const void* fn = f16 ? mma_pick<half_tag>(nbits, mi) : mma_pick<bf16_tag>(nbits, mi);
+    if (!fn) return false;
+    p.splitk = splitk;
+    p.rows_per_slice = rows / splitk;
+    lp.fn = fn;
+    static const char* names[4][4] = {
+        {"gemm_w4_mma_kernel<32x128>", "gemm_w4_mma_kernel<64x128>", "gemm_w4_mma_kernel<128x128>", "gemm_w4_mma_kernel<256x128>"},
+        {"gemm_w2_mma_kernel<32x128>", "gemm_w2_mma_kernel<64x128>", "gemm_w2_mma_kernel<128x128>", "gemm_w2_mma_kernel<256x128>"},
+        {"gemm_w1_mma_kernel<32x128>", "gemm_w1_mma_kernel<64x128>", "gemm_w1_mma_kernel<128x128>", "gemm_w1_mma_kernel<256x128>"},
+        {"gemm_w8_mma_kernel<32x128>", "gemm_w8_mma_kernel<64x128>", "gemm_w8_mma_kernel<128x128>", "gemm_w8_mma_kernel<256x128>"}};
+    lp.name = names[nbits == 4 ? 0 : (nbits == 2 ? 1 : (nbits == 1 ? 2 : 3))][mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))];
+    lp.grid = dim3((unsigned)tiles, splitk, 1);
+    lp.block = dim3(512, 1, 1);
+    const size_t stages = (size_t)2 * bm * ks * 2;
+    const size_t xch = (size_t)4 * mi * 4 * 64 * 16;  // K-half exchange: [cg][mi][e4][lane] float4
+    const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * mma::C_PITCH * 4 + 16;
+    lp.lds_bytes = stages > xch ? stages : xch;
+    if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
+    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * mma::BN * 4 : 0;
+    lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
+    return true;
+}
+
+}  // namespace gl

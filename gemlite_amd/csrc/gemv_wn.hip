@@ -85,10 +85,12 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
     const int slice = blockIdx.y;
     const int n0 = tile * TC + c * 4;
 
-    const int rows_slice = p.rows_per_slice;          // multiple of NW*CHUNK
-    const int rows_wave = rows_slice / NW;            // each wave takes a contiguous part
+    const int rows_slice = p.rows_per_slice;          // multiple of CHUNK
     const int row_s0 = slice * rows_slice;            // first packed row of the slice
-    const int row_w0 = wave * rows_wave;              // wave start, relative to the slice
+    // chunks of the slice are dealt round-robin to the waves (wave w: chunks w, w + NW, ...), so any chunk count
+    // works — K = 11008 or 8960 (43 / 35 chunks of 32 rows) as well as the powers of two
+    const int row_w0 = wave * CHUNK;                  // first row of this wave's chunk 0, relative to the slice
+    constexpr int CSTRIDE = NW * CHUNK;               // rows between consecutive chunks of one wave
     const int pairs = rows_slice * HALF;              // LDS dwords per x row
     const int nspans = rows_slice * E / 32;           // 32-k spans per x row
 
@@ -112,19 +114,20 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
 #pragma unroll
     for (int i = 0; i < R; ++i) wo[i] = (uint32_t)(row_s0 + row_w0 + g * R + i) * sw4 + (uint32_t)n0 * 4u;
     const uint32_t xo = (uint32_t)(row_s0 + row_w0 + g * R) * (uint32_t)(E * 2);  // XD: byte offset of row 0's x chunk
-    const int nchunks = rows_wave / CHUNK;  // 1, or even (planner)
+    const int nch_slice = rows_slice / CHUNK;
+    const int nchunks = (nch_slice - wave + NW - 1) / NW;  // may be 0 for the last waves of a short slice
     struct Chunk { u32x4 w[R]; u32x2 s, z; u32x4 x[XD ? R : 1]; };
     const uint16_t* xg = (const uint16_t*)p.x;
     const char* wb = (const char*)p.w;
     auto load_chunk = [&](Chunk& ck, int chunk) {
-        const int row = row_s0 + row_w0 + chunk * CHUNK + g * R;
+        const int row = row_s0 + row_w0 + chunk * CSTRIDE + g * R;
         const uint32_t mo = ((uint32_t)group_of(row * E, p.gs_shift) * mstride + (uint32_t)n0) * 2u;
         if constexpr (XD) {  // x first: it is the cheaper (cached) request and is needed together with w
-            const uint32_t xc = xo + (uint32_t)(chunk * CHUNK) * (uint32_t)(E * 2);
+            const uint32_t xc = xo + (uint32_t)(chunk * CSTRIDE) * (uint32_t)(E * 2);
 #pragma unroll
             for (int i = 0; i < R; ++i) ck.x[i] = *(const u32x4*)((const char*)xg + (xc + (uint32_t)(i * E * 2)));
         }
-        const uint32_t co = (uint32_t)(chunk * CHUNK) * sw4;  // uniform
+        const uint32_t co = (uint32_t)(chunk * CSTRIDE) * sw4;  // uniform
 #pragma unroll
         for (int i = 0; i < R; ++i) ck.w[i] = *(const u32x4*)(wb + (wo[i] + co));
         ck.s = *(const u32x2*)((const char*)sp + mo);
@@ -190,18 +193,18 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
 
     // opt-in timeline (tuning[3] & 4, needs a workspace): lane 0 of every wave of block (0,0) stores s_memtime stamps
     const bool probe = (p.flags & 4) && p.counters && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0;
-    unsigned long long* stamps = (unsigned long long*)(p.counters + 4096) + wave * 16;
+    unsigned long long* stamps = (unsigned long long*)(p.counters + MAX_SPLITK_COUNTERS) + wave * 16;
     auto stamp = [&](int i) {
         if (probe) stamps[i] = __builtin_readcyclecounter();
     };
     stamp(0);
     Chunk A, B;
     if constexpr (XD) {
-        pipeline2_prime(nchunks, A, B, load_chunk);
+        if (nchunks > 0) pipeline2_prime(nchunks, A, B, load_chunk);
     } else {
         u32x4 xv[4];
         fetch_x(xv, tid);
-        pipeline2_prime(nchunks, A, B, load_chunk);
+        if (nchunks > 0) pipeline2_prime(nchunks, A, B, load_chunk);
         put_x(xv, tid);
         for (int task = tid + NT; task < ntasks; task += NT) {  // large K * MB only
             fetch_x(xv, task);
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
     };
 
     auto compute = [&](const Chunk& ck, int chunk) {
-        const int row_rel = row_w0 + chunk * CHUNK + g * R;  // first of this lane's R rows (slice-relative)
+        const int row_rel = row_w0 + chunk * CSTRIDE + g * R;  // first of this lane's R rows (slice-relative)
         float acc[MB][4];
         float xd_sum = 0.f;  // XD: sum of the run's true x
 #pragma unroll
@@ -322,10 +325,11 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
         }
     };
 
-    pipeline2_run(nchunks, A, B, load_chunk, [&](const Chunk& ck, int ch) {
-        compute(ck, ch);
-        if (ch == 0) stamp(2);  // first chunk consumed (its data had arrived)
-    });
+    if (nchunks > 0)
+        pipeline2_run(nchunks, A, B, load_chunk, [&](const Chunk& ck, int ch) {
+            compute(ck, ch);
+            if (ch == 0) stamp(2);  // first chunk consumed (its data had arrived)
+        });
     stamp(3);  // all chunks consumed
 
     // ---- reduce over the G row sub-groups of the wave (lane bits CQ..5) --------------------------------
@@ -484,14 +488,21 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
             if (cq == 3 && rr != 4 && rr != 2) continue;
             if (rr == 8 && cq == 4 && nbits != 8) continue;       // 8 rows in flight only where they are needed
             if (nbits == 1 && rr != 1) continue;                   // 16 x-dwords per packed row
-            if ((rr * e) % 32 != 0 || rpg % rr != 0 || rows % (4 * G * rr) != 0) continue;
+            if ((rr * e) % 32 != 0 || rpg % rr != 0 || rows % (G * rr) != 0) continue;
             r = rr;
         }
+        // K = 11008 / 8960 (Llama-2-7B down_proj, Qwen2.5-1.5B): 16-column tiles need 64-row chunks with 4 rows per
+        // lane; the 16-wave direct-x variant takes 2 rows per lane (32-row chunks: 43 / 35 of them)
+        bool force_xd16 = false;
+        if (!r && cq == 2 && nbits == 4 && mb == 1 && rows % (G * 2) == 0 && rpg % 2 == 0 && (a.tuning[3] & 3) != 1) {
+            r = 2;
+            force_xd16 = true;
+        }
         if (!r) return false;
-        const int block_rows = 4 * G * r;  // packed rows per block step
-        if (rows % block_rows != 0) return false;
+        const int chunk_rows = G * r;  // packed rows one wave consumes per step; chunks are dealt round-robin to the waves
+        if (rows % chunk_rows != 0) return false;
         const int tiles = (int)(a.N / tc);
-        const int units = rows / block_rows;  // max number of K slices
+        const int units = rows / chunk_rows;  // chunks = max number of K slices
         auto ok = [&](int sk) {  // slices must divide the steps and keep the LDS copy of x within 64 KiB
             if (sk < 1 || units % sk != 0) return false;
             return (int64_t)mb * (rows / sk) * e * 2 <= 65536;
@@ -511,19 +522,20 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         }
         if (tiles > MAX_SPLITK_COUNTERS && splitk > 1) return false;
         // tuning[3]: 0 auto | 1 stage x in LDS | 2 load x directly.  Direct x pays when a wave has <= 2 steps.
-        const int steps = units / splitk;
+        const int steps = (units / splitk + 3) / 4;  // chunks per wave (4 waves)
         const int xmode = a.tuning[3] & 3;
-        bool xd = nbits == 4 && mb == 1 && r == 4 && (xmode == 2 || (xmode == 0 && steps <= 2));
+        bool xd = force_xd16 || (nbits == 4 && mb == 1 && r == 4 && (xmode == 2 || (xmode == 0 && steps <= 2)));
         // tuning[2]: 0 auto | 4 | 8 waves per block.  8 waves: one chunk per wave, two waves per SIMD (short K only)
-        int nw = 4;
-        if (xd && cq <= 3 && splitk == 1) {
+        int nw = force_xd16 ? 16 : 4;
+        if (force_xd16 && splitk != 1) return false;
+        if (xd && !force_xd16 && cq <= 3 && splitk == 1) {
             const int want = a.tuning[2];
             // measured at 4096 x 4096 (profiles/r01_run21): 4 waves 5.28 us, 8 waves 4.69-4.80 us, 16 waves 4.48 us
             const int opt_nw[3] = {16, 8, 8}, opt_r[3] = {2, 4, 2}, opt_key[3] = {16, 8, 82};
             for (int oi = 0; oi < 3; ++oi) {
                 if (!(want == opt_key[oi] || (want == 0 && oi < 2))) continue;
-                const int br = opt_nw[oi] * G * opt_r[oi];
-                if (rows % br != 0 || rows / br > 2 || rpg % opt_r[oi] != 0) continue;
+                const int cr = G * opt_r[oi];  // chunk rows; at most two chunks per wave
+                if (rows % cr != 0 || (rows / cr + opt_nw[oi] - 1) / opt_nw[oi] > 2 || rpg % opt_r[oi] != 0) continue;
                 nw = opt_nw[oi];
                 r = opt_r[oi];
                 break;

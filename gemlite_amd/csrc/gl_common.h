@@ -274,8 +274,11 @@ __device__ __forceinline__ void group_affine(float s, float z, int w_mode, float
 
 // Workspace layout: [arrival counters: MAX_SPLITK_COUNTERS x u32 | slabs].  The counters sit at a FIXED
 // place so that slab payload of one shape can never alias the counters of another; kernels leave them zero.
-constexpr int MAX_SPLITK_COUNTERS = 65536;
-constexpr uint64_t COUNTER_BYTES = (uint64_t)MAX_SPLITK_COUNTERS * 4;
+// The last 4096 words of the block belong to the opt-in timeline probes (tuning[3] & 4): never used as tickets.
+constexpr int COUNTER_WORDS = 65536;
+constexpr int PROBE_WORDS = 4096;
+constexpr int MAX_SPLITK_COUNTERS = COUNTER_WORDS - PROBE_WORDS;
+constexpr uint64_t COUNTER_BYTES = (uint64_t)COUNTER_WORDS * 4;
 
 // ---------------------------------------------------------------------------------------------
 // split-K hand-off words: write-through (sc1) stores / loads at agent scope

@@ -163,6 +163,11 @@ const char* gemlite_hip_kernel_name(const gemlite_hip_forward_args* args);
  * own device duration.  Pass NULL, NULL to clear.  Events are hipEvent_t passed as void*. */
 void gemlite_hip_set_profile_events(void* start_event, void* stop_event);
 
+/* Measurement aid: launches an EMPTY kernel of `blocks` x `threads` on `stream` (honours
+ * gemlite_hip_set_profile_events).  bench.py uses it to report the floor of the per-launch event clock next
+ * to every kernel duration it quotes (on MI355X an empty kernel already reads ~4 us). */
+int gemlite_hip_launch_noop(int32_t blocks, int32_t threads, void* stream);
+
 /* Per-token dynamic activation quantisation: for each row m of x[M,K] (fp16/bf16/fp32)
  *   s[m] = max(amax(|x[m,:]|) / qmax, 1e-6) (fp32);  y = clamp(x / s, qmin, qmax);
  *   int8: round half away from zero;  fp8: round-to-nearest-even cast.

@@ -31,10 +31,7 @@ def forward_cpu(x: torch.Tensor, packed_kn: torch.Tensor, scales_g: torch.Tensor
     return x.float() @ W.t()
 
 
-def time_cpu_baseline(M: int, N: int, K: int, W_nbits: int, group_size: int, budget_s: float = 12.0, seed: int = 0):
-    """Bounded timing of the CPU path on all host cores.  Returns (seconds_per_call, calls, threads)."""
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
+def _make_problem(M, N, K, W_nbits, group_size, seed=0):
     g = torch.Generator().manual_seed(seed)
     W_q = torch.randint(0, 2 ** W_nbits, (N, K), generator=g, dtype=torch.int32)
     e = 32 // W_nbits
@@ -43,11 +40,50 @@ def time_cpu_baseline(M: int, N: int, K: int, W_nbits: int, group_size: int, bud
     scales = torch.rand(N * K // group_size, 1, generator=g) * 0.01 + 0.001
     zeros = torch.rand(N * K // group_size, 1, generator=g) * (2 ** W_nbits - 1)
     x = torch.randn(M, K, generator=g) / 10
-    forward_cpu(x, packed, scales, zeros, W_nbits, group_size)  # warm-up
+    return x, packed, scales, zeros
+
+
+def _time_calls(fn, budget_s, max_calls=2000, min_calls=1):
+    fn()  # warm-up
     calls, t0 = 0, time.perf_counter()
     while True:
-        forward_cpu(x, packed, scales, zeros, W_nbits, group_size)
+        fn()
         calls += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or calls >= 2000:
-            return el / calls, calls, threads
+        if (el >= budget_s and calls >= min_calls) or calls >= max_calls:
+            return el / calls, calls
+
+
+def time_cpu_baseline(M: int, N: int, K: int, W_nbits: int, group_size: int, budget_s: float = 12.0, seed: int = 0):
+    """Bounded timing of the CPU path.  The thread count is SWEPT (oversubscribing the elementwise unpack / dequant ops
+    with every hardware thread of a big host is several times slower than a moderate count) and the best setting is
+    timed for the remaining budget.  Also times the "matmul only on pre-dequantised fp32 W" variant (SURVEY.md §8 d).
+    Returns dict(sec_per_call, calls, threads, sweep={threads: sec}, matmul_only_sec, matmul_only_threads)."""
+    ncpu = os.cpu_count() or 1
+    x, packed, scales, zeros = _make_problem(M, N, K, W_nbits, group_size, seed)
+    run = lambda: forward_cpu(x, packed, scales, zeros, W_nbits, group_size)  # noqa: E731
+    cands = sorted({t for t in (4, 8, 16, 32, 64, 128, ncpu) if 1 <= t <= ncpu})
+    sweep, t_start = {}, time.perf_counter()
+    for t in cands:
+        torch.set_num_threads(t)
+        sec, _ = _time_calls(run, budget_s=0.25, max_calls=3)
+        sweep[t] = sec
+        if time.perf_counter() - t_start > budget_s * 0.4:
+            break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    left = max(1.0, budget_s * 0.75 - (time.perf_counter() - t_start))
+    sec, calls = _time_calls(run, budget_s=left)
+    # matmul only: W dequantised once, outside the timed region
+    N_ = packed.shape[1]
+    W = ((unpack_over_k(packed, W_nbits).reshape(-1, group_size).float() - zeros) * scales).reshape(N_, -1)
+    xf = x.float()
+    mm, mm_threads = None, None
+    for t in cands:
+        torch.set_num_threads(t)
+        s_mm, _ = _time_calls(lambda: xf @ W.t(), budget_s=0.15, max_calls=20, min_calls=3)
+        if mm is None or s_mm < mm:
+            mm, mm_threads = s_mm, t
+    torch.set_num_threads(best)
+    return dict(sec_per_call=sec, calls=calls, threads=best, sweep={int(k): round(v, 5) for k, v in sweep.items()},
+                matmul_only_sec=mm, matmul_only_threads=mm_threads, host_cpus=ncpu)

@@ -1,0 +1,70 @@
+"""Device time of the 8-wave MFMA kernel (gemm_wn_mma) across tile heights / split-K factors, next to the round-1
+tiled kernel (tuning[0] = 2) and the few-row kernels; one line per configuration.  Run on the MI355X:
+    gpurun -- 'bash scripts/gpu.sh probe:probe_mma.py'"""
+import os, sys, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gemlite_amd import GemLiteLinear, _hip
+from gemlite_amd.core import _hip_matmul
+from gemlite_amd.dtypes import TORCH_TO_DTYPE
+from gemlite_amd.bench_utils import kernel_device_us
+from tests.test_gpu_parity import _kernel_name  # noqa
+
+DEV = torch.device("cuda:0")
+g = torch.Generator(device=DEV).manual_seed(0)
+
+
+def layers(N, K, nbits, gs, tdt, n):
+    out = []
+    for _ in range(n):
+        W_q = torch.randint(0, 2 ** nbits, (N, K), generator=g, dtype=torch.int32, device=DEV).to(torch.uint8)
+        s = (torch.rand(N * K // gs, 1, generator=g, device=DEV) * 0.01 + 0.001).to(tdt)
+        z = (torch.rand(N * K // gs, 1, generator=g, device=DEV) * (2 ** nbits - 1)).to(tdt)
+        code = TORCH_TO_DTYPE[tdt]
+        out.append(GemLiteLinear(nbits, gs, K, N, code, code).pack(W_q, s, z, None))
+    return out
+
+
+def run(tag, N, K, nbits, M, tdt, tunings, nl=8, gs=128, mt=-1):
+    mods = layers(N, K, nbits, gs, tdt, nl)
+    x = (torch.randn(M, K, generator=g, device=DEV) / 10).to(tdt)
+    flops = 2.0 * M * N * K
+    for t in tunings:
+        i = [0]
+
+        def launch():
+            lin = mods[i[0] % nl]
+            i[0] += 1
+            return _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), mt, t)
+        try:
+            us = kernel_device_us(launch, iters=40, warmup=4)
+            name = _kernel_name(mods[0], x, mt, t)
+        except Exception as e:
+            print(json.dumps(dict(tag=tag, tuning=t, error=str(e)[:80])), flush=True)
+            continue
+        print(json.dumps(dict(tag=tag, M=M, tuning=t, kernel=name, us=round(us, 2), tflops=round(flops / us / 1e6, 1),
+                              frac=round(flops / us / 1e6 / 2500, 3))), flush=True)
+    del mods
+    torch.cuda.empty_cache()
+
+
+bf, hf = torch.bfloat16, torch.float16
+which = sys.argv[1:] or ["cfgA", "cfgB", "fp16", "rows", "w2", "oddk"]
+if "cfgA" in which:
+    run("cfgA bf16", 4096, 4096, 4, 256, bf, [(0, 0, 0, 0), (0, 8, 8, 0), (0, 4, 8, 0), (0, 2, 8, 0), (0, 4, 4, 0), (0, 2, 4, 0), (0, 8, 4, 0),
+                                               (2, 0, 0, 0)], nl=32)
+if "cfgB" in which:
+    run("cfgB bf16", 8192, 8192, 4, 256, bf, [(0, 0, 0, 0), (0, 4, 8, 0), (0, 2, 8, 0), (0, 8, 8, 0), (0, 2, 4, 0), (0, 4, 4, 0), (2, 0, 0, 0)], nl=8)
+if "fp16" in which:
+    run("cfgA fp16", 4096, 4096, 4, 256, hf, [(0, 0, 0, 0), (0, 4, 4, 0), (2, 0, 0, 0)], nl=32)
+    run("cfgB fp16", 8192, 8192, 4, 256, hf, [(0, 0, 0, 0), (2, 0, 0, 0)], nl=8)
+if "rows" in which:
+    for M in (33, 64, 128, 512, 1024):
+        run(f"4096 bf16 M={M}", 4096, 4096, 4, M, bf, [(0, 0, 0, 0), (2, 0, 0, 0)], nl=16)
+    for M in (8, 16, 32):
+        run(f"4096 fp16 M={M}", 4096, 4096, 4, M, hf, [(0, 0, 0, 0), (3, 0, 0, 0)], nl=32)
+if "w2" in which:
+    run("A16W2 16384 bf16", 16384, 16384, 2, 256, bf, [(0, 0, 0, 0), (1, 0, 0, 0)], nl=2)
+if "oddk" in which:
+    for M in (1, 8, 32, 64):
+        run(f"K=11008 fp16 M={M}", 4096, 11008, 4, M, hf, [(0, 0, 0, 0)], nl=12)

@@ -24,7 +24,7 @@ for name, (N, K, tun) in {"cfgA_tile16_xd_4w": (4096, 4096, (2, 1, 4, 4 | 2)), "
             torch.cuda.synchronize()
             ws = list(_hip._workspaces.values())[0]
             nw = tun[2] if tun[2] in (8, 16) else 4
-            st = ws[4096 * 4: 4096 * 4 + nw * 16 * 8].view(torch.int64).cpu().numpy().reshape(nw, 16)
+            st = ws[(65536 - 4096) * 4: (65536 - 4096) * 4 + nw * 16 * 8].view(torch.int64).cpu().numpy().reshape(nw, 16)
             recs.append(st[:, :7].copy())
     r = np.stack(recs[len(layers):])            # drop the first (warm-up) rotation
     t0 = r[:, :, 0].min(axis=1, keepdims=True)[:, :, None]

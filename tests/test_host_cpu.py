@@ -89,20 +89,36 @@ def test_struct_abi_and_validation():
     (dict(M=4, gs=64), "gemm_wn_direct_kernel<tile16>"),   # group size 64: registers-only kernel up to 16 rows
     (dict(M=24, gs=64), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32
     (dict(M=4, gs=32), "gemm_wn_stream_kernel"),
-    (dict(M=48), "gemm_w4_tiled_kernel<128x128>"),    # from 33 rows: the tiled kernel (half-empty tile beats streaming)
+    (dict(M=48), "gemm_w4_mma_kernel<64x128>"),       # from 33 rows: the 8-wave MFMA kernel, tile rows follow M
     (dict(M=48, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK at 33..64 rows: LDS-staged streaming kernel
-    (dict(M=48, nbits=2), "gemm_wn_stream_kernel"),   # 2-bit has no tiled kernel
+    (dict(M=48, nbits=2), "gemm_w2_mma_kernel<64x128>"),   # every bit width has the tiled MFMA kernel
+    (dict(M=48, nbits=1), "gemm_w1_mma_kernel<64x128>"),
+    (dict(M=200, nbits=8), "gemm_w8_mma_kernel<256x128>"),
+    (dict(M=48, tuning=(1, 0, 0, 0)), "gemm_wn_stream_kernel"),          # tuning[0] = 1: LDS-staged streaming kernel
+    (dict(M=48, tuning=(2, 0, 0, 0)), "gemm_w4_tiled_kernel<128x128>"),  # tuning[0] = 2: the 4-wave kernel of round 1
+    (dict(M=48, gs=32), "gemm_wn_stream_kernel"),     # group size 32: two groups per 64-k sub-block
+    # K = 11008 / 8960 (Llama-2-7B down_proj, Qwen2.5-1.5B): specialised kernels at every M, never the coverage kernel
+    (dict(M=1, N=4096, K=11008), "gemv_wn_kernel<tile16,xdirect,16w>"),
+    (dict(M=1, N=4096, K=11008, gs=64), "gemv_wn_kernel<tile16,xdirect,16w>"),
+    (dict(M=1, N=1536, K=8960), "gemv_wn_kernel<tile32>"),
+    (dict(M=4, N=4096, K=11008), "gemm_w4_mma_kernel<32x128>"),
+    (dict(M=32, N=4096, K=11008, gs=64), "gemm_w4_mma_kernel<32x128>"),
+    (dict(M=16, N=1536, K=8960), "gemm_w4_mma_kernel<32x128>"),
+    (dict(M=64, N=4096, K=11008), "gemm_w4_mma_kernel<64x128>"),
+    (dict(M=256, N=4096, K=11008), "gemm_w4_mma_kernel<256x128>"),
     (dict(M=1, nbits=2), "gemv_wn_kernel<tile16>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64>"),
     (dict(M=16), "gemm_wn_direct_kernel<tile32>"),
-    (dict(M=1, mt=4), "gemm_w4_tiled_kernel<128x128>"),   # manual GEMM family at M=1 -> the tiled MFMA kernel
-    (dict(M=128), "gemm_w4_tiled_kernel<128x128>"),
-    (dict(M=256), "gemm_w4_tiled_kernel<128x128>"),
-    (dict(M=256, N=8192, K=8192, in_dt=2), "gemm_w4_tiled_kernel<128x128>"),
-    (dict(M=256, tuning=(0, 0, 8, 0)), "gemm_w4_tiled_kernel<256x128>"),   # opt-in: 256-row tiles, one block per CU
-    (dict(M=256, tuning=(0, 0, 4, 0)), "gemm_w4_tiled_kernel<legacy>"),
-    (dict(M=256, nbits=2), "gemm_wn_stream_kernel"),  # 2-bit: streaming kernel with row tiles
+    (dict(M=1, mt=4), "gemm_w4_mma_kernel<32x128>"),   # manual GEMM family at M=1 -> the tiled MFMA kernel
+    (dict(M=128), "gemm_w4_mma_kernel<128x128>"),
+    (dict(M=256), "gemm_w4_mma_kernel<256x128>"),
+    (dict(M=256, N=8192, K=8192, in_dt=2), "gemm_w4_mma_kernel<256x128>"),
+    (dict(M=256, tuning=(0, 0, 4, 0)), "gemm_w4_mma_kernel<128x128>"),   # tuning[2]: tile rows / 32
+    (dict(M=256, tuning=(2, 0, 8, 0)), "gemm_w4_tiled_kernel<256x128>"),
+    (dict(M=256, tuning=(2, 0, 4, 0)), "gemm_w4_tiled_kernel<legacy>"),
+    (dict(M=256, nbits=2), "gemm_w2_mma_kernel<256x128>"),
+    (dict(M=256, N=16384, K=16384, nbits=2), "gemm_w2_mma_kernel<256x128>"),   # BASELINE config 5
     (dict(M=4, mt=3), "gemm_wn_direct_kernel<tile16>"),  # manual GEMM_SPLITK
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
     (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
@@ -479,3 +495,48 @@ def test_dtype_codes_and_state_dict_format_match_the_reference():
             for k in keys:
                 assert str(mine_sd[k].dtype) == str(z[f"sd_{name}__{k}__dtype"]), k
                 assert np.array_equal(_bits(mine_sd[k]), z[f"sd_{name}__{k}"]), k
+
+
+def test_forward_functional_is_registered_under_the_reference_namespace_with_a_fake_impl():
+    """Reference: @torch.library.custom_op("gemlite::forward_functional") + register_fake (core.py:128-135,197-206).
+    hqq / vLLM resolve torch.ops.gemlite.forward_functional; the fake impl must give shape/dtype without touching data."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import gemlite_amd.core  # noqa: F401 (registers the op)
+    op = torch.ops.gemlite.forward_functional
+    assert "gemlite::forward_functional" in str(op.default._schema)
+    meta = [0, 4, 64, 15, 8, 1, 1, 0, 1, 0, 4, 1]
+    with FakeTensorMode():
+        x = torch.empty(3, 5, 64, dtype=torch.float16)
+        W = torch.empty(8, 32, dtype=torch.int32)
+        s = torch.empty(1, 32, dtype=torch.float16)
+        z = torch.empty(1, 32, dtype=torch.float16)
+        y = op(x, None, [W, s, z], meta, -1)
+        assert tuple(y.shape) == (3, 5, 32) and y.dtype == torch.float16
+    # schema: (Tensor x, Tensor? bias, Tensor[] tensor_args, int[] meta_args, int matmul_type=-1) -> Tensor
+    sch = op.default._schema
+    assert [a.name for a in sch.arguments] == ["x", "bias", "tensor_args", "meta_args", "matmul_type"]
+
+
+def test_launch_templates_are_immutable_and_keyed_by_everything_they_hold():
+    """a shared mutable per-layer struct raced between threads and could go stale.  Now: an immutable byte
+    template per layer, copied per call; the key carries addresses, shapes, strides, dtypes and the meta ints."""
+    from gemlite_amd import core
+    W = torch.zeros(8, 32, dtype=torch.int32)
+    s = torch.ones(1, 32, dtype=torch.float16)
+    z = torch.ones(1, 32, dtype=torch.float16)
+    meta = [0, 4, 64, 15, 8, 1, 1, 0, 1, 0, 4, 1]
+    a, b = core._static_args(W, s, z, meta), core._static_args(W, s, z, meta)
+    assert a is not b and bytes(a) == bytes(b)
+    a.M, a.x = 7, 0x1234  # per-call fields of one struct never leak into the next
+    c = core._static_args(W, s, z, meta)
+    assert c.M == 0 and not c.x
+    k1 = core._template_key(W, s, z, meta)
+    assert core._template_key(W, s.float(), z, meta) != k1            # dtype is part of the key
+    assert core._template_key(W.t().contiguous().t(), s, z, meta) != k1  # so are the strides (and the address)
+    assert core._template_key(W, s, z, meta[:-1] + [0]) != k1
+    assert core.lookup_tuning(-1, 1, a) is None
+    core.GEMLITE_HIP_CONFIG_CACHE.setdefault("GEMV_REVSPLITK", {})[core.config_key(1, a.N, a.K, 64, 8, a.type_id)] = {"tuning": [2, 1, 16, 7]}
+    try:
+        assert core.lookup_tuning(-1, 1, a) == (2, 1, 16, 3)  # development bits of tuning[3] are not loadable from a table
+    finally:
+        core.GemLiteLinear.reset_config()
