@@ -92,8 +92,9 @@ class HipEvents:
         return ms.value if rc == 0 else float("nan")
 
 
-def kernel_device_us(launch, iters: int = 30, warmup: int = 3) -> float:
-    """Mean device duration (us) of the library kernel that `launch()` starts, from per-launch HIP events."""
+def kernel_device_us(launch, iters: int = 30, warmup: int = 3, before_each=None) -> float:
+    """Mean device duration (us) of the library kernel that `launch()` starts, from per-launch HIP events.
+    `before_each()` (optional) runs before every timed launch, e.g. a cache flush."""
     import torch
     from . import _hip
     lib = _hip.load()
@@ -102,6 +103,8 @@ def kernel_device_us(launch, iters: int = 30, warmup: int = 3) -> float:
     ev = HipEvents()
     pairs = [(ev.create(), ev.create()) for _ in range(iters)]
     for a, b in pairs:
+        if before_each is not None:
+            before_each()
         lib.gemlite_hip_set_profile_events(a, b)
         launch()
     torch.cuda.synchronize()

@@ -13,6 +13,7 @@ the GPU — there is no CPU / eager fallback and a missing library raises.
 """
 import json
 import logging
+import os
 import threading
 from typing import List, Optional, Union
 
@@ -208,6 +209,8 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
     lib = _hip.load()
     _hip.require_gpu_tensor(x, "x")
     _hip.require_gpu_tensor(W_q, "W_q")
+    if not _AUTOLOAD_DONE:
+        autoload_default_config(x.device.index or 0)
     if x.device != W_q.device:
         raise _hip.GemliteHipError(f"x is on {x.device}, the packed weight on {W_q.device}")
     a = _static_args(W_q, scales, zeros, meta_args)
@@ -511,3 +514,51 @@ class GemLiteLinearHIP(torch.nn.Module):
 
 GemLiteLinear = GemLiteLinearHIP
 GemLiteLinearTriton = GemLiteLinearHIP  # the reference's class name; there is no Triton here
+
+
+# ------------------------------------------------------------------------------------------------------
+# shipped per-GPU tuning table, picked by device name like the reference's configs/*.json (core.py:634-654)
+# ------------------------------------------------------------------------------------------------------
+_ARCH_TAGS = {"gfx950": "mi355x"}  # boxes report "AMD Radeon Graphics" / "AMD Instinct MI355X": the ISA name is reliable
+_AUTOLOAD_DONE = False
+
+
+def get_default_cache_config(device_index: int = 0) -> Optional[str]:
+    """Path of the shipped table whose tag occurs in the device name (longest tag first), or in its ISA name."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
+    if not os.path.isdir(root) or not torch.cuda.is_available():
+        return None
+    props = torch.cuda.get_device_properties(device_index)
+    name = props.name.lower().replace(" ", "_")
+    arch = getattr(props, "gcnArchName", "").split(":")[0].lower()
+    tags = sorted((f[:-5] for f in os.listdir(root) if f.endswith(".json")), key=len, reverse=True)
+    for tag in tags:
+        if tag in name or _ARCH_TAGS.get(arch) == tag:
+            return os.path.join(root, tag + ".json")
+    return None
+
+
+def autoload_default_config(device_index: int = 0) -> Optional[str]:
+    """Load the shipped table once (first GPU launch, or explicitly).  Entries already in the cache win."""
+    global _AUTOLOAD_DONE
+    if _AUTOLOAD_DONE:
+        return None
+    _AUTOLOAD_DONE = True
+    if os.environ.get("GEMLITE_HIP_NO_DEFAULT_CONFIG"):
+        return None
+    path = get_default_cache_config(device_index)
+    if path is None:
+        return None
+    try:
+        with _FILE_LOCK, open(path, "r") as f:
+            config = json.load(f)
+        for fam, entries in config.items():
+            if isinstance(entries, dict):
+                tgt = GEMLITE_HIP_CONFIG_CACHE.setdefault(fam, {})
+                for k, v in entries.items():
+                    tgt.setdefault(k, v)
+        logger.warning("Loaded " + path + " config.")
+        return path
+    except Exception as e:  # a broken table must never break the forward path
+        logger.error(f"Failed to load the default config '{path}': {e}")
+        return None

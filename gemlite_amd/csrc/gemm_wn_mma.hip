@@ -146,6 +146,41 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
 }
 
+// ---- memory requests the compiler must NOT wait for.  hipcc answers any use of a tracked load with vmcnt(0) while an
+// LDS-DMA is outstanding, which would drain the x / weight pipeline every step; these requests are therefore issued from
+// inline asm and retired by hand with COUNTED s_waitcnt (cdna_hip_programming.md §5.7): loads return in issue order, so
+// "vmcnt(n)" = everything but the newest n requests of this wave has landed.  A loaded register is handed to the compiler
+// with tie() right after the wait that covers it.  s_nop 4: SALU-written SGPR / M0 -> VMEM wait states (nothing inside an
+// asm string is padded by the compiler).
+typedef uint32_t srd_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ srd_t make_srd(const void* base, uint32_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    srd_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xFFFFu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void req_u32(uint32_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void req_u16(uint32_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_ushort %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+// one LDS-DMA piece: 64 lanes x 16 bytes from buffer offset (voff per lane + soff) to LDS [lds_addr, +1024), lane-linear
+__device__ __forceinline__ void req_lds16(srd_t rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void tie(uint32_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ uint32_t lds_addr_of(const unsigned char* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
 }  // namespace mma
 
 // MI 32-row blocks per wave (tile rows = 32 * MI), KSTEP k per step (each wave: KSTEP / 2).
@@ -169,15 +204,38 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     const int cg = wave & 3, kh = wave >> 2;
     const int col = lane & 31, h = lane >> 5;
     const int mtiles = (p.M + BM - 1) / BM;
-    const int bid = blockIdx.x;
+    // (tile, K slice) of this block.  Block b runs on XCD b % 8 and every XCD has its own L2: all blocks of one XCD take
+    // the SAME K slice, so the x rows of that slice (re-read by every column tile) stay in that L2 instead of being
+    // fetched from the Infinity Cache by all 8 (cfgB: 256 MiB of x traffic per launch).  Speed only; any map is correct.
+    int bid = blockIdx.x, slice = blockIdx.y;
+    {
+        const int T = gridDim.x, S = gridDim.y;
+        if (!(p.flags & 8) && S > 1 && (8 % S) == 0 && ((T * S) & 7) == 0) {
+            const int lin = blockIdx.x + T * blockIdx.y, xcd = lin & 7, idx = lin >> 3;
+            slice = xcd % S;
+            bid = idx * (8 / S) + xcd / S;
+        }
+    }
     const int mt = bid % mtiles, nt = bid / mtiles;  // M tiles fastest: neighbours share the weight tile in L2
-    const int slice = blockIdx.y;
     const int m0 = mt * BM;
     const int n = nt * BN + cg * 32 + col;  // this lane's column
 
-    const int nsteps = p.rows_per_slice / (KSTEP / G::E);
-    const int row_s0 = slice * p.rows_per_slice;  // first packed row of the slice
+    // K steps of this slice: the units are dealt as evenly as possible (rows_per_slice = ALL packed rows here), so any
+    // step count works (K = 11008: 43 steps of 256)
+    constexpr int STEP_ROWS = KSTEP / G::E;
+    const int units = p.rows_per_slice / STEP_ROWS;
+    const int s_begin = (int)((int64_t)slice * units / p.splitk), s_end = (int)((int64_t)(slice + 1) * units / p.splitk);
+    const int nsteps = s_end - s_begin;
+    const int row_s0 = s_begin * STEP_ROWS;  // first packed row of the slice
     const int k_s0 = row_s0 * G::E;
+
+    // opt-in timeline (tuning[3] & 4): lane 0 of every wave of block (0, 0) stores s_memtime stamps behind the tickets
+    const bool probe = (p.flags & 4) && p.counters && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0;
+    unsigned long long* stamps = (unsigned long long*)(p.counters + MAX_SPLITK_COUNTERS) + wave * 16;
+    auto stamp = [&](int i) {
+        if (probe) stamps[i] = __builtin_readcyclecounter();
+    };
+    stamp(0);
 
     const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
     const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
@@ -186,31 +244,37 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     const int ms = (need_s || need_z) ? (int)p.stride_meta_g : 0;
     const int meta_rows = p.gs_shift >= 31 ? 1 : (p.K >> p.gs_shift);
     const int meta_bytes = ((meta_rows - 1) * ms + p.N) * 2;
-    // every global access is a raw buffer access: run-ahead past the slice, rows >= M and absent metadata read zeros
-    const __amdgpu_buffer_rsrc_t rsW =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)row_s0 * sw), (short)0, p.rows_per_slice * sw * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(need_s ? p.scales : (const void*)p.w), (short)0, need_s ? meta_bytes : 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(need_z ? p.zeros : (const void*)p.w), (short)0, need_z ? meta_bytes : 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.x, (short)0, (int)(((int64_t)(p.M - 1) * p.stride_xm + p.K) * 2), 0x00020000);
+    // buffer descriptors (rows >= M and absent metadata read zeros through the range check on the per-lane offset)
+    const srd_t rsW = make_srd(p.w + (int64_t)row_s0 * sw, (uint32_t)(nsteps * STEP_ROWS * sw) * 4u);
+    const srd_t rsS = make_srd(need_s ? p.scales : (const void*)p.w, need_s ? (uint32_t)meta_bytes : 4u);
+    const srd_t rsZ = make_srd(need_z ? p.zeros : (const void*)p.w, need_z ? (uint32_t)meta_bytes : 4u);
+    const srd_t rsX = make_srd(p.x, (uint32_t)(((int64_t)(p.M - 1) * p.stride_xm + p.K) * 2));
 
     // ---- B stream --------------------------------------------------------------------------------------------------
     struct BStep { uint32_t w[SUB][WPL]; uint32_t s[SUB], z[SUB]; };
     const uint32_t wvoff = (uint32_t)(G::HS * h * sw + n) * 4u;
     const uint32_t mvoff = (uint32_t)n * 2u;
     const int wave_row0 = kh * (KW / G::E);  // first packed row of this wave's half inside a step
-    auto load_b = [&](BStep& b, int step) {
+    constexpr int NLB = SUB * (WPL + 2);   // weight / metadata requests per step and wave
+    // request `it` (0 .. NLB-1) of step `step` (slice-relative) into ring slot b
+    auto req_b = [&](BStep& b, int step, int it) {
+        const int sb = it / (WPL + 2), i = it % (WPL + 2);
+        const int rb = step * STEP_ROWS + wave_row0 + sb * G::ROWS;  // packed row (slice-relative) of the sub-block
+        if (i < WPL) {
+            req_u32(b.w[sb][i], rsW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane((rb + G::row_of(i)) * sw * 4));
+        } else {
+            const uint32_t mo = (uint32_t)__builtin_amdgcn_readfirstlane((((k_s0 + rb * G::E) >> p.gs_shift) * ms) * 2);
+            if (i == WPL) req_u16(b.s[sb], rsS, mvoff, mo);
+            else req_u16(b.z[sb], rsZ, mvoff, mo);
+        }
+    };
+    auto tie_b = [&](BStep& b) {
 #pragma unroll
         for (int sb = 0; sb < SUB; ++sb) {
-            const int rb = step * (KSTEP / G::E) + wave_row0 + sb * G::ROWS;  // packed row (slice-relative) of the sub-block
 #pragma unroll
-            for (int i = 0; i < WPL; ++i)
-                b.w[sb][i] = __builtin_amdgcn_raw_buffer_load_b32(rsW, wvoff, (uint32_t)((rb + G::row_of(i)) * sw) * 4u, 0);
-            const uint32_t mo = (uint32_t)(((k_s0 + rb * G::E) >> p.gs_shift) * ms) * 2u;
-            b.s[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsS, mvoff, mo, 0);
-            b.z[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsZ, mvoff, mo, 0);
+            for (int i = 0; i < WPL; ++i) tie(b.w[sb][i]);
+            tie(b.s[sb]);
+            tie(b.z[sb]);
         }
     };
     // ---- A stream: LDS-DMA pieces.  Piece j of wave w covers LDS bytes [(w * PIECES + j) * 1024, +1024) of a stage;
@@ -224,13 +288,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         const int logical = phys ^ (r & 15);
         xvoff[j] = m0 + r < p.M ? (uint32_t)(((int64_t)(m0 + r) * p.stride_xm + k_s0 + logical * 8) * 2) : 0x80000000u;
     }
-    auto stage_x = [&](int stage, int step) {
-        // SGPR offset of the step: readfirstlane makes the uniformity provable (otherwise hipcc wraps every DMA in a
-        // waterfall loop: v_readfirstlane / s_and_saveexec per instruction)
-        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP * 2);
-#pragma unroll
-        for (int j = 0; j < PIECES; ++j)
-            lds_dma16(rsX, smem + stage * STAGE + (wave * PIECES + j) * 1024, xvoff[j], so);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PIECES) * 1024u);
+    auto req_x = [&](int stage, int step, int j) {
+        req_lds16(rsX, lds0 + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP * 2));
     };
     // A fragment of slot q = (slice g, row block mi): row mi*32 + col, k = kh*KW + (g/4)*64 + k_of(g%4, h)
     int fbase[2][NS];
@@ -277,12 +337,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     u32x4 af[L];
     u32x4 bfrag[2];
 
-    // ---- prologue ----------------------------------------------------------------------------------------------------
-    load_b(ring[0], 0);
-    load_b(ring[1], nsteps > 1 ? 1 : 0);
-    stage_x(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    // ---- prologue: x of step 0, weights of steps 0 and 1 -----------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
+#pragma unroll
+    for (int it = 0; it < NLB; ++it) req_b(ring[0], 0, it);
+#pragma unroll
+    for (int it = 0; it < NLB; ++it) req_b(ring[1], nsteps > 1 ? 1 : 0, it);
+    wait_vm<0>();
+    tie_b(ring[0]);
+    tie_b(ring[1]);
     __builtin_amdgcn_s_barrier();
+    stamp(1);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) deq_piece(ring[0], 0, mi, bfrag[0]);
 #pragma unroll
@@ -290,66 +356,57 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     __builtin_amdgcn_sched_barrier(0);
 
     // One K step; J = step & 3 selects the ring slot / stage statically.  The step is written as NQ MFMA "slots"; slot q
-    // issues MFMA q, one piece of the next slice's dequantisation, the A fragment needed L slots later and its share of
-    // the step's memory requests (weights of step + 2, x of step + 1), and the order is pinned with sched_barrier:
-    // left alone, the machine scheduler pulls every ds_read back to just before its MFMA (LDS latency exposed) and
-    // groups the requests at the top of the step.
-    constexpr int NLB = SUB * (WPL + 2);   // weight / metadata requests per step
-    constexpr int NL = NLB + PIECES;       // + LDS-DMA pieces
-    constexpr int NQI = NQ - L;            // slots that may issue requests (all must precede the vmcnt(0) of the step)
+    // issues MFMA q, one piece of the next slice's dequantisation, the A fragment needed L slots later and — in the first
+    // slots — the step's memory requests: x of step + 1 FIRST (LDS-DMA), then the weights of step + 2.  The order is
+    // pinned with sched_barrier (left alone, the machine scheduler pulls every ds_read back to just before its MFMA and
+    // groups the requests).  Waits are counted: at slot NQ - L "all but the NLB newest requests" = this step's DMA has
+    // landed (the weights just requested stay in flight for another step), then the block barrier: every wave's part of
+    // the next stage is in LDS and every wave has finished reading the current stage.
+    constexpr int NL = NLB + PIECES;
+    constexpr int NQI = NQ - L;                       // request slots
+    constexpr int RPS = (NL + NQI - 1) / NQI;         // requests per slot
+    constexpr int QW = NQ - (MI > L ? MI : L);        // slot from which the NEXT step's weights are dequantised
+    static_assert(NL <= 48, "vmcnt is a 6-bit counter");
     auto do_step = [&](auto Jc, int step) {
         constexpr int J = decltype(Jc)::value;
         constexpr int stage = J & 1;
         const BStep& bc = ring[J];
-        const BStep& bn = ring[(J + 1) & 3];
+        BStep& bn = ring[(J + 1) & 3];
         BStep& bl = ring[(J + 2) & 3];
-        // run-ahead past the slice re-reads its last step (never consumed): the SGPR offset of a buffer access is not
-        // part of the range check, so "out of range reads zeros" must not be relied upon here
-        const int lstep = __builtin_amdgcn_readfirstlane(step + 2 < nsteps ? step + 2 : nsteps - 1);
-        // the last step has no successor: it re-requests its own tile into the idle stage (branch-free; nobody reads it,
-        // and the step's vmcnt(0) + barrier retire the DMA before the epilogue reuses the LDS)
-        const uint32_t xso = (uint32_t)__builtin_amdgcn_readfirstlane((step + 1 < nsteps ? step + 1 : step) * KSTEP * 2);
-        auto request = [&](int it) {
-            if (it < NLB) {
-                const int sb = it / (WPL + 2), i = it % (WPL + 2);
-                const int rb = lstep * (KSTEP / G::E) + wave_row0 + sb * G::ROWS;
-                if (i < WPL) {
-                    bl.w[sb][i] = __builtin_amdgcn_raw_buffer_load_b32(rsW, wvoff, (uint32_t)((rb + G::row_of(i)) * sw) * 4u, 0);
-                } else {
-                    const uint32_t mo = (uint32_t)(((k_s0 + rb * G::E) >> p.gs_shift) * ms) * 2u;
-                    if (i == WPL) bl.s[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsS, mvoff, mo, 0);
-                    else bl.z[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsZ, mvoff, mo, 0);
-                }
-            } else {
-                const int j = it - NLB;
-                lds_dma16(rsX, smem + (stage ^ 1) * STAGE + (wave * PIECES + j) * 1024, xvoff[j], xso);
-            }
-        };
+        // Past the end of the slice the requests repeat the last step (never consumed): the SGPR offset of a buffer
+        // access is not range-checked, so "out of range reads zeros" cannot be relied on; and the last step re-requests
+        // its own x tile into the idle stage, which keeps the counted waits identical for every step.
+        const int lstep = step + 2 < nsteps ? step + 2 : nsteps - 1;
+        const int xstep = step + 1 < nsteps ? step + 1 : step;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int g = q / MI, mi = q % MI;
             acc[mi] = mfma32<Tag>(af[q % L], bfrag[g & 1], acc[mi]);
-            if (g + 1 < NS) deq_piece(bc, g + 1, mi, bfrag[(g + 1) & 1]);
-            else deq_piece(bn, 0, mi, bfrag[(g + 1) & 1]);  // the next step's first slice
             if (q == NQI) {
-                // everything this block requested for the next step has landed in every wave, and every wave has
-                // issued AND completed its reads of the current stage: the next stage may be read, this one refilled
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+                wait_vm<NLB>();
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the current stage are complete
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
+            if (q == QW) {  // weights of step + 1 (requested one step ago) have landed: everything older than this step's requests
+                if (QW < NQI) wait_vm<NL>();
+                tie_b(bn);
+            }
+            if (g + 1 < NS) deq_piece(bc, g + 1, mi, bfrag[(g + 1) & 1]);
+            else deq_piece(bn, 0, mi, bfrag[(g + 1) & 1]);  // the next step's first slice
             if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
             else af[q % L] = read_frag(stage ^ 1, q + L - NQ);
-            if (q < NQI) {
 #pragma unroll
-                for (int it = (q * NL) / NQI; it < ((q + 1) * NL) / NQI; ++it) request(it);
+            for (int it = q * RPS; it < (q + 1) * RPS && it < NL; ++it) {
+                if (it < PIECES) req_x(stage ^ 1, xstep, it);
+                else req_b(bl, lstep, it - PIECES);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     for (int s0 = 0; s0 < nsteps; s0 += 4) {
         do_step(std::integral_constant<int, 0>{}, s0);
+        if (s0 == 0) stamp(2);
         if (s0 + 1 >= nsteps) break;
         do_step(std::integral_constant<int, 1>{}, s0 + 1);
         if (s0 + 2 >= nsteps) break;
@@ -357,6 +414,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         if (s0 + 3 >= nsteps) break;
         do_step(std::integral_constant<int, 3>{}, s0 + 3);
     }
+    // retire every outstanding request (the last steps' run-ahead) before the registers / LDS are reused
+    wait_vm<0>();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tie_b(ring[r]);
+    stamp(3);
 
     // ---- epilogue 1: add the two K halves (waves 4..7 hand their accumulators to waves 0..3 through LDS) ------------
     __syncthreads();
@@ -382,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         }
     }
 
+    stamp(4);
     // ---- epilogue 2: the tile is transposed through LDS (128 rows per pass) so that slabs and the output move as
     //      16-byte row segments; C fragment of a 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     float* ct = (float*)smem;  // [C_ROWS][C_PITCH]
@@ -418,9 +481,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
             }
         }
     }
+    stamp(5);
     if (p.splitk == 1) return;
     __syncthreads();
-    if (!splitk_arrive_is_last(p.counters + bid, p.splitk, flag)) return;
+    const bool last = splitk_arrive_is_last(p.counters + bid, p.splitk, flag);
+    stamp(6);
+    if (!last) return;
     // last arriver: slices outer, units inner -> every slice's 16-byte loads are in flight together
     for (int ps = 0; ps < NPASS; ++ps) {
         f32x4 sum[UNITS];
@@ -444,6 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         }
     }
     if (tid == 0) splitk_reset(p.counters + bid);
+    stamp(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -502,7 +569,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if ((int64_t)rows * a.stride_wk * 4 >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31)) return false;
     if (((int64_t)(a.K / (p.group_size > 0 ? p.group_size : a.K)) * p.stride_meta_g + a.N) * 2 >= (1ll << 31)) return false;
     const int64_t tiles = (int64_t)(a.N / mma::BN) * ((a.M + bm - 1) / bm);
-    auto ok = [&](int sk) { return sk >= 1 && units % sk == 0; };
+    auto ok = [&](int sk) { return sk >= 1 && sk <= units; };  // uneven slices are fine (the kernel deals the steps)
     int splitk = 0;
     if (a.tuning[1] > 0) {
         if (!ok(a.tuning[1])) return false;
@@ -523,7 +590,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     const void* fn = f16 ? mma_pick<half_tag>(nbits, mi) : mma_pick<bf16_tag>(nbits, mi);
     if (!fn) return false;
     p.splitk = splitk;
-    p.rows_per_slice = rows / splitk;
+    p.rows_per_slice = rows;  // ALL packed rows: the kernel derives each slice's step range itself
     lp.fn = fn;
     static const char* names[4][4] = {
         {"gemm_w4_mma_kernel<32x128>", "gemm_w4_mma_kernel<64x128>", "gemm_w4_mma_kernel<128x128>", "gemm_w4_mma_kernel<256x128>"},

@@ -306,16 +306,21 @@ def warmup(*_a, **_k):
 # tuning[] candidates per kernel family of libgemlite_hip (include/gemlite_hip.h: tuning[0..3]); (0,0,0,0) = planner
 _TUNING_CANDIDATES = {
     "gemv": [(0, 0, 0, 0), (2, 1, 4, 0), (2, 1, 8, 0), (2, 1, 16, 0), (3, 1, 0, 0), (3, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 4, 0, 0)],
-    "few_rows": [(0, 0, 0, 0), (1, 1, 0, 0), (2, 1, 0, 0), (2, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 4, 0, 0), (0, 0, 1, 0)],
-    "tiled": [(0, 0, 0, 0), (0, 1, 0, 0), (0, 2, 0, 0), (0, 4, 0, 0), (0, 8, 0, 0), (0, 4, 8, 0), (0, 8, 8, 0)],
+    "few_rows": [(0, 0, 0, 0), (1, 1, 0, 0), (2, 1, 0, 0), (2, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 4, 0, 0), (0, 0, 1, 0),
+                 (3, 0, 0, 0), (3, 0, 1, 0), (3, 0, 2, 0)],
+    # 8-wave MFMA kernel: tuning[1] = K slices, tuning[2] = tile rows / 32
+    "tiled": [(0, 0, 0, 0), (0, 1, 0, 0), (0, 2, 0, 0), (0, 4, 0, 0), (0, 8, 0, 0), (0, 2, 4, 0), (0, 4, 4, 0), (0, 8, 4, 0),
+              (0, 2, 8, 0), (0, 4, 8, 0), (0, 8, 8, 0), (0, 0, 2, 0), (0, 0, 4, 0), (0, 0, 8, 0)],
 }
 
 
-def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, candidates=None, verbose: bool = False) -> dict:
+def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, candidates=None, verbose: bool = False,
+                   cold: bool = False) -> dict:
     """Measured search over the library's tuning knobs for one packed layer — the HIP counterpart of the reference's
     per-shape Triton autotune (core.py:559-654, helper.py:1067-1118).  For each M, every candidate that the
     library accepts is timed (device time from per-launch HIP events, `iters` launches, weights warm) and the best is
-    stored in GEMLITE_HIP_CONFIG_CACHE under the reference's key; `GemLiteLinear.cache_config(path)` /
+    stored in GEMLITE_HIP_CONFIG_CACHE under the reference's key (`cold=True` rewrites a 512 MiB buffer before every timed
+    launch so that the weights come from HBM, as they do inside a model, instead of the 256 MiB Infinity Cache); `GemLiteLinear.cache_config(path)` /
     `load_config(path)` persist and reload the table, and every later launch of that shape uses it.
     Returns {M: {"tuning": [...], "us": best, "default_us": planner}}."""
     from . import core as _core
@@ -326,18 +331,20 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
     in_t = _core.DTYPE_TO_TORCH[layer.input_dtype.value if not layer.scaled_activations else layer.output_dtype.value]
     meta = layer.get_meta_args()
     out = {}
+    flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev) if cold else None
     for M in batch_sizes:
         x = (torch.randn(M, layer.in_features, device=dev) / 10).to(in_t)
         scales_x = None
         if layer.scaled_activations:
             from .quant_utils import scale_activations_per_token
             x, scales_x = scale_activations_per_token(x, w_dtype=_core.DTYPE_TO_TORCH[layer.input_dtype.value])
-        fam = "gemv" if M == 1 else ("few_rows" if M <= 64 else "tiled")
+        fam = "gemv" if M == 1 else ("few_rows" if M <= 32 else "tiled")
         best, default_us = None, None
         for cand in (candidates or _TUNING_CANDIDATES[fam]):
             try:  # device time of the kernel itself (per-launch HIP events), not host-bound wall time
                 us = kernel_device_us(lambda: _core._hip_matmul(x, layer.W_q, layer.scales, layer.zeros, scales_x, meta,
-                                                                -1, cand), iters=iters)
+                                                                -1, cand), iters=iters,
+                                      before_each=(lambda: flush.fill_(1)) if flush is not None else None)
             except (NotImplementedError, GemliteHipError):
                 continue  # this candidate does not apply to the shape
             if us != us:

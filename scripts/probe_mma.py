@@ -52,9 +52,9 @@ bf, hf = torch.bfloat16, torch.float16
 which = sys.argv[1:] or ["cfgA", "cfgB", "fp16", "rows", "w2", "oddk"]
 if "cfgA" in which:
     run("cfgA bf16", 4096, 4096, 4, 256, bf, [(0, 0, 0, 0), (0, 8, 8, 0), (0, 4, 8, 0), (0, 2, 8, 0), (0, 4, 4, 0), (0, 2, 4, 0), (0, 8, 4, 0),
-                                               (2, 0, 0, 0)], nl=32)
+                                               (0, 4, 4, 8), (2, 0, 0, 0)], nl=32)
 if "cfgB" in which:
-    run("cfgB bf16", 8192, 8192, 4, 256, bf, [(0, 0, 0, 0), (0, 4, 8, 0), (0, 2, 8, 0), (0, 8, 8, 0), (0, 2, 4, 0), (0, 4, 4, 0), (2, 0, 0, 0)], nl=8)
+    run("cfgB bf16", 8192, 8192, 4, 256, bf, [(0, 0, 0, 0), (0, 4, 8, 0), (0, 4, 8, 8), (0, 2, 8, 0), (0, 8, 8, 0), (0, 2, 4, 0), (0, 4, 4, 0), (0, 3, 8, 0), (2, 0, 0, 0)], nl=8)
 if "fp16" in which:
     run("cfgA fp16", 4096, 4096, 4, 256, hf, [(0, 0, 0, 0), (0, 4, 4, 0), (2, 0, 0, 0)], nl=32)
     run("cfgB fp16", 8192, 8192, 4, 256, hf, [(0, 0, 0, 0), (2, 0, 0, 0)], nl=8)

@@ -598,13 +598,15 @@ def test_mma_kernel_bit_widths_tiles_and_splits(nbits, tdt):
     for mi, M in ((1, 29), (2, 64), (4, 100), (8, 256), (8, 300), (4, 130)):
         x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
         y_or = _oracle_from_layer(lin, x)
-        for sk in (0, 1, 5):
+        for sk in (0, 1, 3, 4):  # 3 / 4 slices of 5 or 10 steps: uneven K slices
             tuning = (0, sk, mi, 0)
             name = _kernel_name(lin, x, 4, tuning)
             assert name.startswith(f"gemm_w{nbits}_mma_kernel<{32 * mi}x128>"), name
             y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 4, tuning)
             torch.cuda.synchronize()
-            _compare(f"mma/w{nbits}/{str(tdt)[6:]}/M{M}/mi{mi}/sk{sk}", y, y_or, lin.output_dtype.value, extra=dict(kernel=name))
+            # 8-bit codes: |y| grows with the code range, the absolute gate of the 4-bit fixtures does not apply
+            _compare(f"mma/w{nbits}/{str(tdt)[6:]}/M{M}/mi{mi}/sk{sk}", y, y_or, lin.output_dtype.value,
+                     abs_gate=None if nbits == 8 else 1e-3, extra=dict(kernel=name))
 
 
 @pytest.mark.parametrize("gs", [128, 64])
