@@ -19,6 +19,7 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
 bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
+bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 const void* generic_kernel_fn();
@@ -46,7 +47,7 @@ static int dtype_size(int dt) {
     }
 }
 
-enum Kind { K_NONE = 0, K_GEMV_WN, K_STREAM_WN, K_TILED_WN, K_KMAJOR, K_GENERIC };
+enum Kind { K_NONE = 0, K_GEMV_WN, K_STREAM_WN, K_TILED_WN, K_KMAJOR, K_A8_MMA, K_GENERIC };
 
 struct Resolved {
     Kind kind = K_NONE;
@@ -167,7 +168,13 @@ coverage:
     g.stride_meta_g = per_group_meta ? a.stride_meta_g : 0;
     g.stride_meta_n = per_group_meta ? a.stride_meta_n : ((a.W_group_mode == 1 && !a.zero_is_scalar) ? 1 : 0);
     r.gp = g;
-    // A8W8 (int8 / fp8) with enough rows for the matrix core; tuning[0] == 1 keeps the streaming kernel
+    // A8W8 (int8 / fp8) from 2 rows: the 8-wave MFMA kernel.  tuning[0]: 1 = streaming kernel (one wave per column),
+    // 2 = the 4-wave MFMA kernel of round 1 (M >= 32)
+    if (!packed && a.tuning[0] == 0 && a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
+        a.matmul_type != GEMLITE_MATMUL_GEMV_REVSPLITK && plan_gemm_a8w8_mma(a, r.gp, r.lp)) {
+        r.kind = K_A8_MMA;
+        return;
+    }
     if (!packed && a.tuning[0] != 1 && a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
         a.matmul_type != GEMLITE_MATMUL_GEMV_REVSPLITK && plan_gemm_a8w8(a, r.lp)) {
         r.kind = K_KMAJOR;  // same launch path: GenericParams, no workspace
@@ -333,6 +340,17 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
         const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes, dev);
         if (e != GEMLITE_OK) return e;
         void* kargs[] = {(void*)&r.wn};
+        return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
+    }
+    if (r.kind == K_A8_MMA) {
+        if (r.lp.ws_bytes > 0) {
+            if (!args->workspace || args->workspace_bytes < r.lp.ws_bytes) return GEMLITE_ERR_WORKSPACE;
+            r.gp.counters = (unsigned*)args->workspace;
+            r.gp.slabs = (float*)((char*)args->workspace + COUNTER_BYTES);
+        }
+        const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes, dev);
+        if (e != GEMLITE_OK) return e;
+        void* kargs[] = {(void*)&r.gp};
         return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
     }
     void* kargs[] = {(void*)&r.gp};

@@ -14,6 +14,7 @@
 // as zeros through the buffer descriptor.  K is not split; the planner takes the largest of 128x128 / 64x128 / 64x64
 // that gives every CU a block (4096 x 4096, M = 256: 64x64 -> 256 blocks).
 #include "gl_common.h"
+#include "gl_async.h"
 
 #include <type_traits>
 
@@ -171,6 +172,333 @@ __global__ __launch_bounds__(256, 2) void gemm_a8w8_kernel(const GenericParams p
                 const int n = n0 + wn * 32 * NI + ni * 32 + col;
                 if (m < p.M) epilogue_store(p.epi, AC::to_float(acc[mi][ni], e), m, n);
             }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 8-wave kernel (default).  Same skeleton as gemm_wn_mma.hip: tile (32 MI) x 128, wave (cg, kh) owns all rows x 32
+// columns x one half of every 256-byte K step; x goes global -> LDS by LDS-DMA (XOR-swizzled through the source
+// address), the wave's B fragments — 16 consecutive bytes of ONE weight row = exactly a lane's operand of
+// v_mfma_i32_32x32x32_i8 — go HBM -> registers with one 16-byte load per lane and 32-k slice, two steps ahead, and feed
+// MI MFMAs each; nothing is dequantised.  Requests come from inline asm with counted waits (gl_async.h); K may be split
+// over gridDim.y (raw int32 / fp32 accumulator words travel through the slabs, so int8 stays exact).
+// ---------------------------------------------------------------------------------------------------------------
+// 4 consecutive outputs of one row from fp32 values: channel scaling (scales of fp32 / fp16 / bf16: one uniform
+// three-way branch, vector loads), cast, one vector store
+__device__ __forceinline__ void store_out4_any(const Epilogue& e, f32x4 v, int64_t m, int64_t n0) {
+    if (e.c_mode == 1 || e.c_mode == 3) {
+        f32x4 sw;
+        if (e.meta_dt == GEMLITE_DT_FP32) sw = *(const f32x4*)((const float*)e.scales_w + n0);
+        else if (e.meta_dt == GEMLITE_DT_FP16) sw = load4_t<half_tag>(e.scales_w, n0);
+        else sw = load4_t<bf16_tag>(e.scales_w, n0);
+        v *= sw;
+    }
+    if (e.c_mode == 2 || e.c_mode == 3) {
+        const float sx = e.scales_x[m * e.stride_sx_m];
+        v *= (f32x4){sx, sx, sx, sx};
+    }
+    if (e.out_dt == GEMLITE_DT_FP32) {
+        *(f32x4*)((float*)e.out + m * e.stride_om + n0) = v;
+        return;
+    }
+    u32x2 o;
+    if (e.out_dt == GEMLITE_DT_FP16) {
+        o[0] = (uint32_t)F16Traits<half_tag>::from_float(v[0]) | ((uint32_t)F16Traits<half_tag>::from_float(v[1]) << 16);
+        o[1] = (uint32_t)F16Traits<half_tag>::from_float(v[2]) | ((uint32_t)F16Traits<half_tag>::from_float(v[3]) << 16);
+    } else {
+        o[0] = (uint32_t)F16Traits<bf16_tag>::from_float(v[0]) | ((uint32_t)F16Traits<bf16_tag>::from_float(v[1]) << 16);
+        o[1] = (uint32_t)F16Traits<bf16_tag>::from_float(v[2]) | ((uint32_t)F16Traits<bf16_tag>::from_float(v[3]) << 16);
+    }
+    *(u32x2*)((uint16_t*)e.out + m * e.stride_om + n0) = o;
+}
+
+template <int DT, int MI>
+__global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericParams p) {
+    using namespace async;
+    using AC = A8Acc<DT>;
+    typedef typename AC::T acc_t;
+    constexpr bool INT = DT == GEMLITE_DT_INT8;
+    constexpr int BM = 32 * MI, BN = 128, KSTEP = 256, KW = 128;
+    constexpr int PITCH = KSTEP, STAGE = BM * PITCH;
+    constexpr int PIECES = STAGE / 1024 / 8;  // LDS-DMA pieces per wave and stage (= MI)
+    constexpr int NS = KW / 32;               // 32-k slices per wave and step
+    constexpr int NQ = NS * MI, L = MI >= 4 ? 4 : (MI == 2 ? 4 : 2);
+    constexpr int C_ROWS = 128, C_PITCH = BN + 4;
+    static_assert(PIECES >= 1 && NQ >= 2 * L, "tile too small for the slot schedule");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][STAGE], later the epilogue tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, kh = wave >> 2;
+    const int col = lane & 31, h = lane >> 5;
+    const int mtiles = (p.M + BM - 1) / BM;
+    int bid = blockIdx.x, slice = blockIdx.y;
+    {  // blocks of one XCD (block b runs on XCD b % 8) share a K slice: its x rows stay in that XCD's L2 (speed only)
+        const int T = gridDim.x, S = gridDim.y;
+        if ((p.flags & 8) && S > 1 && (8 % S) == 0 && ((T * S) & 7) == 0) {
+            const int lin = blockIdx.x + T * blockIdx.y, xcd = lin & 7, idx = lin >> 3;
+            slice = xcd % S;
+            bid = idx * (8 / S) + xcd / S;
+        }
+    }
+    const int mt = bid % mtiles, nt = bid / mtiles;
+    const int m0 = mt * BM;
+    const int n = nt * BN + cg * 32 + col;  // this lane's output column = its weight row
+
+    const int units = p.K / KSTEP;
+    const int s_begin = (int)((int64_t)slice * units / p.splitk), s_end = (int)((int64_t)(slice + 1) * units / p.splitk);
+    const int nsteps = s_end - s_begin;
+    const int k_s0 = s_begin * KSTEP;
+
+    const srd_t rsX = make_srd(p.x, (uint32_t)((int64_t)(p.M - 1) * p.stride_xm + p.K));
+    const __amdgpu_buffer_rsrc_t brW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + p.K), 0x00020000);
+    // B fragment of slice g: 16 bytes at weight row n, k = k_s0 + step * 256 + kh * 128 + g * 32 + h * 16
+    const uint32_t wvoff = (uint32_t)((int64_t)n * p.stride_wn + k_s0 + kh * KW + h * 16);
+    struct BStep { u32x4 w[NS]; };
+    auto req_b = [&](BStep& b, int step, int g) {
+        // a tracked buffer load: the compiler retires it with its own counted vmcnt (see gemm_wn_mma.hip)
+        b.w[g] = __builtin_amdgcn_raw_buffer_load_b128(brW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP + g * 32), 0);
+    };
+    // x: piece j of wave w covers LDS bytes [(w * PIECES + j) * 1024, +1024) of a stage: row = byte / 256, physical
+    // 16-byte slot (byte % 256) / 16 holds the logical slot phys ^ (row & 15)
+    uint32_t xvoff[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int byte = (wave * PIECES + j) * 1024 + lane * 16;
+        const int r = byte / PITCH, phys = (byte % PITCH) / 16;
+        const int logical = phys ^ (r & 15);
+        xvoff[j] = m0 + r < p.M ? (uint32_t)((int64_t)(m0 + r) * p.stride_xm + k_s0 + logical * 16) : 0x80000000u;
+    }
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PIECES) * 1024u);
+    auto req_x = [&](int stage, int step, int j) {
+        req_lds16(rsX, lds0 + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP));
+    };
+    int fbase[2][NS];  // A fragment of (slice g, row block mi): row mi*32 + col, byte kh*128 + g*32 + h*16
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int g = 0; g < NS; ++g) {
+            const int slot = (kh * KW + g * 32 + h * 16) >> 4;
+            fbase[st][g] = st * STAGE + col * PITCH + (((slot ^ col) & 15) << 4);
+        }
+    auto read_frag = [&](int stage, int q) -> u32x4 {
+        return *(const u32x4*)(smem + fbase[stage][q / MI] + (q % MI) * 32 * PITCH);
+    };
+
+    acc_t acc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[i] = AC::zero();
+
+    BStep ring[4];
+    u32x4 af[L];
+
+    // ---- prologue: x of step 0, weights of steps 0 and 1 -----------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
+#pragma unroll
+    for (int g = 0; g < NS; ++g) req_b(ring[0], 0, g);
+#pragma unroll
+    for (int g = 0; g < NS; ++g) req_b(ring[1], nsteps > 1 ? 1 : 0, g);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < L; ++q) af[q] = read_frag(0, q);
+    __builtin_amdgcn_sched_barrier(0);
+
+    constexpr int NLB = NS, NL = NLB + PIECES, NQI = NQ - L;
+    constexpr int RPS = (NL + NQI - 1) / NQI;
+    auto do_step = [&](auto Jc, int step) {
+        constexpr int J = decltype(Jc)::value;
+        constexpr int stage = J & 1;
+        const BStep& bc = ring[J];
+        BStep& bl = ring[(J + 2) & 3];
+        const int lstep = step + 2 < nsteps ? step + 2 : nsteps - 1;  // run-ahead repeats the last step (never consumed)
+        const int xstep = step + 1 < nsteps ? step + 1 : step;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int g = q / MI, mi = q % MI;
+            acc[mi] = AC::mma(af[q % L], bc.w[g], acc[mi]);
+            if (q == NQI) {
+                wait_vm<NLB>();                      // this step's x DMA has landed
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
+            else af[q % L] = read_frag(stage ^ 1, q + L - NQ);
+#pragma unroll
+            for (int it = q * RPS; it < (q + 1) * RPS && it < NL; ++it) {
+                if (it < PIECES) req_x(stage ^ 1, xstep, it);
+                else req_b(bl, lstep, it - PIECES);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+        do_step(std::integral_constant<int, 0>{}, s0);
+        if (s0 + 1 >= nsteps) break;
+        do_step(std::integral_constant<int, 1>{}, s0 + 1);
+        if (s0 + 2 >= nsteps) break;
+        do_step(std::integral_constant<int, 2>{}, s0 + 2);
+        if (s0 + 3 >= nsteps) break;
+        do_step(std::integral_constant<int, 3>{}, s0 + 3);
+    }
+    wait_vm<0>();
+
+    // ---- epilogue 1: add the two K halves through LDS (raw 32-bit accumulator words: int32 stays exact) -------------
+    __syncthreads();
+    {
+        acc_t* xch = (acc_t*)smem;  // [cg][mi][lane] whole accumulators (64 bytes per lane)
+        if (kh == 1) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xch[(cg * MI + mi) * 64 + lane] = acc[mi];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] += xch[(cg * MI + mi) * 64 + lane];
+        }
+    }
+    // ---- epilogue 2: transpose through LDS (128 rows per pass): slabs / output move as 16-byte row segments ------------
+    typedef typename std::conditional<INT, int, float>::type word_t;
+    typedef word_t word4 __attribute__((ext_vector_type(4)));
+    word_t* ct = (word_t*)smem;  // [PASS_ROWS][C_PITCH]
+    constexpr int PASS_ROWS = BM < C_ROWS ? BM : C_ROWS;
+    unsigned* flag = (unsigned*)(smem + PASS_ROWS * C_PITCH * 4);
+    constexpr int NPASS = BM / PASS_ROWS, MIP = PASS_ROWS / 32;
+    constexpr int UNITS = (PASS_ROWS * BN / 4 + 511) / 512;
+    constexpr int NOUT = BM * BN;
+    const int64_t ncol0 = (int64_t)nt * BN;
+    float* slab = p.slabs + ((int64_t)bid * p.splitk) * NOUT;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
+    auto finish = [&](word4 v, int m, int c4) {
+        f32x4 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = (float)v[j];
+        store_out4_any(p.epi, f, m, ncol0 + c4);
+    };
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MIP; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    ct[r * C_PITCH + cg * 32 + col] = acc[ps * MIP + mi][e];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + ps * PASS_ROWS + r;
+            if (r < PASS_ROWS && m < p.M) {
+                const word4 v = *(const word4*)(ct + r * C_PITCH + c4);
+                if (p.splitk == 1) finish(v, m, c4);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                            (slice * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);  // sc1
+            }
+        }
+    }
+    if (p.splitk == 1) return;
+    __syncthreads();
+    if (!splitk_arrive_is_last(p.counters + bid, p.splitk, flag)) return;
+    for (int ps = 0; ps < NPASS; ++ps) {
+        word4 sum[UNITS];
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) sum[i] = (word4){0, 0, 0, 0};
+        for (int sl = 0; sl < p.splitk; ++sl) {
+            u32x4 t[UNITS];
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) {
+                const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+                t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (sl * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) sum[i] += __builtin_bit_cast(word4, t[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + ps * PASS_ROWS + r;
+            if (r < PASS_ROWS && m < p.M) finish(sum[i], m, c4);
+        }
+    }
+    if (tid == 0) splitk_reset(p.counters + bid);
+}
+
+typedef void (*a8_kernel_fn)(const GenericParams);
+template <int DT>
+static const void* a8_pick(int mi) {
+    a8_kernel_fn f = nullptr;
+    switch (mi) {
+        case 8: f = gemm_a8w8_mma_kernel<DT, 8>; break;
+        case 4: f = gemm_a8w8_mma_kernel<DT, 4>; break;
+        case 2: f = gemm_a8w8_mma_kernel<DT, 2>; break;
+        case 1: f = gemm_a8w8_mma_kernel<DT, 1>; break;
+        default: break;
+    }
+    return (const void*)f;
+}
+
+// 8-wave kernel: M >= 2 (tuning[0]: 2 = the 4-wave kernel of round 1; tuning[1] = K slices; tuning[2] = tile rows / 32)
+bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
+    if (a.elements_per_sample != 1 || a.W_group_mode != 0 || a.M < 2) return false;
+    if (a.w_dtype != a.input_dtype) return false;
+    if (!(a.input_dtype == GEMLITE_DT_INT8 || a.input_dtype == GEMLITE_DT_FP8E4 || a.input_dtype == GEMLITE_DT_FP8E5)) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 128 != 0 || a.K % 256 != 0) return false;
+    if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
+    if ((int64_t)a.M * a.stride_xm >= (1ll << 31) || (int64_t)a.N * a.stride_wn >= (1ll << 31)) return false;
+    if (!(a.output_dtype == GEMLITE_DT_FP32 || a.output_dtype == GEMLITE_DT_FP16 || a.output_dtype == GEMLITE_DT_BF16)) return false;
+    if ((a.channel_scale_mode == 1 || a.channel_scale_mode == 3) &&
+        !(a.meta_dtype == GEMLITE_DT_FP32 || a.meta_dtype == GEMLITE_DT_FP16 || a.meta_dtype == GEMLITE_DT_BF16)) return false;
+    if ((a.channel_scale_mode == 1 || a.channel_scale_mode == 3) && ((uintptr_t)a.scales % 16) != 0) return false;
+    const int units = (int)(a.K / 256);
+    // Tile rows: nothing is dequantised here, so a small tile costs no extra arithmetic (only more weight re-reads from
+    // L2) while every K slice costs slab traffic and a tail: take the TALLEST tile (<= the rows M fills) that still gives
+    // >= 112 tiles, i.e. at most two K slices; below that, the smallest tile with as many slices as needed.
+    const int cap = a.M > 128 ? 8 : (a.M > 64 ? 4 : (a.M > 32 ? 2 : 1));
+    int mi = 1;
+    for (int c = cap; c >= 1; c >>= 1) {
+        if ((int64_t)(a.N / 128) * ((a.M + 32 * c - 1) / (32 * c)) >= 112) { mi = c; break; }
+    }
+    if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4 || a.tuning[2] == 8) mi = a.tuning[2];
+    const int bm = 32 * mi;
+    const int64_t tiles = (int64_t)(a.N / 128) * ((a.M + bm - 1) / bm);
+    int splitk = 0;
+    if (a.tuning[1] > 0) {
+        if (a.tuning[1] > units) return false;
+        splitk = a.tuning[1];
+    } else {
+        for (int sk = 1; sk <= units && sk <= 32; ++sk) {
+            if (units / sk < 2) continue;
+            splitk = sk;
+            if (tiles * sk >= 224) break;
+        }
+        if (!splitk) splitk = 1;
+    }
+    if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
+    if ((uint64_t)splitk * bm * 128 * 4 >= (1ull << 31)) return false;
+    const void* fn = a.input_dtype == GEMLITE_DT_INT8 ? a8_pick<GEMLITE_DT_INT8>(mi)
+                     : (a.input_dtype == GEMLITE_DT_FP8E4 ? a8_pick<GEMLITE_DT_FP8E4>(mi) : a8_pick<GEMLITE_DT_FP8E5>(mi));
+    if (!fn) return false;
+    g.splitk = splitk;
+    g.flags = a.tuning[3];
+    lp.fn = fn;
+    lp.name = mi == 8 ? "gemm_a8w8_mma_kernel<256x128>" : (mi == 4 ? "gemm_a8w8_mma_kernel<128x128>"
+              : (mi == 2 ? "gemm_a8w8_mma_kernel<64x128>" : "gemm_a8w8_mma_kernel<32x128>"));
+    lp.grid = dim3((unsigned)tiles, splitk, 1);
+    lp.block = dim3(512, 1, 1);
+    const size_t stages = (size_t)2 * bm * 256, xch = (size_t)4 * mi * 64 * 64;
+    const size_t c_b = (size_t)(bm < 128 ? bm : 128) * 132 * 4 + 16;
+    lp.lds_bytes = stages > xch ? stages : xch;
+    if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
+    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * 128 * 4 : 0;
+    lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
+    return true;
 }
 
 // M >= 32, unpacked 8-bit weights with the same dtype as the activations, no group metadata (channel / token scales

@@ -22,10 +22,13 @@
 #include <type_traits>
 
 #include "gl_common.h"
+#include "gl_async.h"
 
 namespace gl {
 
 namespace mma {
+
+using namespace async;
 
 constexpr int BN = 128;
 constexpr int C_ROWS = 128;        // rows of the epilogue staging tile (one pass per 128 rows)
@@ -146,41 +149,6 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
 }
 
-// ---- memory requests the compiler must NOT wait for.  hipcc answers any use of a tracked load with vmcnt(0) while an
-// LDS-DMA is outstanding, which would drain the x / weight pipeline every step; these requests are therefore issued from
-// inline asm and retired by hand with COUNTED s_waitcnt (cdna_hip_programming.md §5.7): loads return in issue order, so
-// "vmcnt(n)" = everything but the newest n requests of this wave has landed.  A loaded register is handed to the compiler
-// with tie() right after the wait that covers it.  s_nop 4: SALU-written SGPR / M0 -> VMEM wait states (nothing inside an
-// asm string is padded by the compiler).
-typedef uint32_t srd_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ srd_t make_srd(const void* base, uint32_t bytes) {
-    const uint64_t b = (uint64_t)base;
-    srd_t r;
-    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
-    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xFFFFu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-    return r;
-}
-__device__ __forceinline__ void req_u32(uint32_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
-    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void req_u16(uint32_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
-    asm volatile("s_nop 4\n\tbuffer_load_ushort %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-}
-// one LDS-DMA piece: 64 lanes x 16 bytes from buffer offset (voff per lane + soff) to LDS [lds_addr, +1024), lane-linear
-__device__ __forceinline__ void req_lds16(srd_t rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void tie(uint32_t& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ uint32_t lds_addr_of(const unsigned char* p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
-}
-
 }  // namespace mma
 
 // MI 32-row blocks per wave (tile rows = 32 * MI), KSTEP k per step (each wave: KSTEP / 2).
@@ -204,13 +172,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     const int cg = wave & 3, kh = wave >> 2;
     const int col = lane & 31, h = lane >> 5;
     const int mtiles = (p.M + BM - 1) / BM;
-    // (tile, K slice) of this block.  Block b runs on XCD b % 8 and every XCD has its own L2: all blocks of one XCD take
-    // the SAME K slice, so the x rows of that slice (re-read by every column tile) stay in that L2 instead of being
-    // fetched from the Infinity Cache by all 8 (cfgB: 256 MiB of x traffic per launch).  Speed only; any map is correct.
+    // (tile, K slice) of this block.  Opt-in (tuning[3] & 8): block b runs on XCD b % 8 and every XCD has its own L2, so
+    // giving all blocks of one XCD the SAME K slice keeps that slice's x rows (re-read by every column tile) in one L2.
+    // Measured SLOWER (cfgB 53 vs 46 us, cfgA 21.2 vs 19.1 us: 32 CUs asking for the same lines at once), so the default
+    // is the plain (x = tile, y = slice) grid.  Speed only; any map is correct.
     int bid = blockIdx.x, slice = blockIdx.y;
     {
         const int T = gridDim.x, S = gridDim.y;
-        if (!(p.flags & 8) && S > 1 && (8 % S) == 0 && ((T * S) & 7) == 0) {
+        if ((p.flags & 8) && S > 1 && (8 % S) == 0 && ((T * S) & 7) == 0) {
             const int lin = blockIdx.x + T * blockIdx.y, xcd = lin & 7, idx = lin >> 3;
             slice = xcd % S;
             bid = idx * (8 / S) + xcd / S;
@@ -245,9 +214,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     const int meta_rows = p.gs_shift >= 31 ? 1 : (p.K >> p.gs_shift);
     const int meta_bytes = ((meta_rows - 1) * ms + p.N) * 2;
     // buffer descriptors (rows >= M and absent metadata read zeros through the range check on the per-lane offset)
-    const srd_t rsW = make_srd(p.w + (int64_t)row_s0 * sw, (uint32_t)(nsteps * STEP_ROWS * sw) * 4u);
-    const srd_t rsS = make_srd(need_s ? p.scales : (const void*)p.w, need_s ? (uint32_t)meta_bytes : 4u);
-    const srd_t rsZ = make_srd(need_z ? p.zeros : (const void*)p.w, need_z ? (uint32_t)meta_bytes : 4u);
     const srd_t rsX = make_srd(p.x, (uint32_t)(((int64_t)(p.M - 1) * p.stride_xm + p.K) * 2));
 
     // ---- B stream --------------------------------------------------------------------------------------------------
@@ -257,24 +223,24 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     const int wave_row0 = kh * (KW / G::E);  // first packed row of this wave's half inside a step
     constexpr int NLB = SUB * (WPL + 2);   // weight / metadata requests per step and wave
     // request `it` (0 .. NLB-1) of step `step` (slice-relative) into ring slot b
+    // (the weight / metadata requests are ordinary buffer loads the compiler tracks: it retires them with its own COUNTED
+    //  vmcnt — it cannot see the asm DMAs, so its count can only over-wait, never under-wait — and it never copies a
+    //  register whose load is still in flight, which it is free to do with the output of an asm load)
+    const __amdgpu_buffer_rsrc_t brW =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)row_s0 * sw), (short)0, nsteps * STEP_ROWS * sw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(need_s ? p.scales : (const void*)p.w), (short)0, need_s ? meta_bytes : 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brZ = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(need_z ? p.zeros : (const void*)p.w), (short)0, need_z ? meta_bytes : 4, 0x00020000);
     auto req_b = [&](BStep& b, int step, int it) {
         const int sb = it / (WPL + 2), i = it % (WPL + 2);
         const int rb = step * STEP_ROWS + wave_row0 + sb * G::ROWS;  // packed row (slice-relative) of the sub-block
         if (i < WPL) {
-            req_u32(b.w[sb][i], rsW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane((rb + G::row_of(i)) * sw * 4));
+            b.w[sb][i] = __builtin_amdgcn_raw_buffer_load_b32(brW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane((rb + G::row_of(i)) * sw * 4), 0);
         } else {
             const uint32_t mo = (uint32_t)__builtin_amdgcn_readfirstlane((((k_s0 + rb * G::E) >> p.gs_shift) * ms) * 2);
-            if (i == WPL) req_u16(b.s[sb], rsS, mvoff, mo);
-            else req_u16(b.z[sb], rsZ, mvoff, mo);
-        }
-    };
-    auto tie_b = [&](BStep& b) {
-#pragma unroll
-        for (int sb = 0; sb < SUB; ++sb) {
-#pragma unroll
-            for (int i = 0; i < WPL; ++i) tie(b.w[sb][i]);
-            tie(b.s[sb]);
-            tie(b.z[sb]);
+            if (i == WPL) b.s[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brS, mvoff, mo, 0);
+            else b.z[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brZ, mvoff, mo, 0);
         }
     };
     // ---- A stream: LDS-DMA pieces.  Piece j of wave w covers LDS bytes [(w * PIECES + j) * 1024, +1024) of a stage;
@@ -344,9 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     for (int it = 0; it < NLB; ++it) req_b(ring[0], 0, it);
 #pragma unroll
     for (int it = 0; it < NLB; ++it) req_b(ring[1], nsteps > 1 ? 1 : 0, it);
-    wait_vm<0>();
-    tie_b(ring[0]);
-    tie_b(ring[1]);
+    wait_vm<0>();  // the DMA (asm); the compiler waits for the weights where they are first used
     __builtin_amdgcn_s_barrier();
     stamp(1);
 #pragma unroll
@@ -365,13 +329,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     constexpr int NL = NLB + PIECES;
     constexpr int NQI = NQ - L;                       // request slots
     constexpr int RPS = (NL + NQI - 1) / NQI;         // requests per slot
-    constexpr int QW = NQ - (MI > L ? MI : L);        // slot from which the NEXT step's weights are dequantised
     static_assert(NL <= 48, "vmcnt is a 6-bit counter");
     auto do_step = [&](auto Jc, int step) {
         constexpr int J = decltype(Jc)::value;
         constexpr int stage = J & 1;
         const BStep& bc = ring[J];
-        BStep& bn = ring[(J + 1) & 3];
+        const BStep& bn = ring[(J + 1) & 3];
         BStep& bl = ring[(J + 2) & 3];
         // Past the end of the slice the requests repeat the last step (never consumed): the SGPR offset of a buffer
         // access is not range-checked, so "out of range reads zeros" cannot be relied on; and the last step re-requests
@@ -387,10 +350,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the current stage are complete
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-            }
-            if (q == QW) {  // weights of step + 1 (requested one step ago) have landed: everything older than this step's requests
-                if (QW < NQI) wait_vm<NL>();
-                tie_b(bn);
             }
             if (g + 1 < NS) deq_piece(bc, g + 1, mi, bfrag[(g + 1) & 1]);
             else deq_piece(bn, 0, mi, bfrag[(g + 1) & 1]);  // the next step's first slice
@@ -414,10 +373,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         if (s0 + 3 >= nsteps) break;
         do_step(std::integral_constant<int, 3>{}, s0 + 3);
     }
-    // retire every outstanding request (the last steps' run-ahead) before the registers / LDS are reused
+    // retire every outstanding request (the last step's run-ahead DMA) before the LDS is reused
     wait_vm<0>();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tie_b(ring[r]);
     stamp(3);
 
     // ---- epilogue 1: add the two K halves (waves 4..7 hand their accumulators to waves 0..3 through LDS) ------------

@@ -1,0 +1,45 @@
+// gl_async.h — memory requests that the compiler must not wait for, and the counted waits that retire them.
+#pragma once
+#include "gl_common.h"
+
+namespace gl {
+namespace async {
+
+// ---- memory requests the compiler must NOT wait for.  hipcc answers any use of a tracked load with vmcnt(0) while an
+// LDS-DMA is outstanding, which would drain the x / weight pipeline every step; these requests are therefore issued from
+// inline asm and retired by hand with COUNTED s_waitcnt (cdna_hip_programming.md §5.7): loads return in issue order, so
+// "vmcnt(n)" = everything but the newest n requests of this wave has landed.  A loaded register is handed to the compiler
+// with tie() right after the wait that covers it.  s_nop 4: SALU-written SGPR / M0 -> VMEM wait states (nothing inside an
+// asm string is padded by the compiler).
+typedef uint32_t srd_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ srd_t make_srd(const void* base, uint32_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    srd_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xFFFFu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void req_u32(uint32_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void req_u16(uint32_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_ushort %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+// one LDS-DMA piece: 64 lanes x 16 bytes from buffer offset (voff per lane + soff) to LDS [lds_addr, +1024), lane-linear
+__device__ __forceinline__ void req_lds16(srd_t rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void tie(uint32_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ uint32_t lds_addr_of(const unsigned char* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
+
+}  // namespace async
+}  // namespace gl

@@ -375,6 +375,11 @@ struct GenericParams {
     int group_size, w_mode, meta_dt, zeros_dt, zero_is_scalar;
     int int_acc;              // int8 x integer weights: exact int32 accumulation
     int64_t stride_xm, stride_xk, stride_wk, stride_wn, stride_meta_g, stride_meta_n;
+    // split-K of the A8W8 MFMA kernel (workspace, same layout as WnParams)
+    float* slabs;
+    unsigned* counters;
+    int splitk;
+    int flags;
 };
 
 // host-side launch description produced by the dispatcher

@@ -491,15 +491,30 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
     W = (torch.randn(2048, 4096) / 30).half()
     lin = gemlite_amd.helper.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights(W)
     x = (torch.randn(77, 4096) / 10).half().to(DEV)
-    assert _kernel_name(lin, torch.empty(77, 4096, dtype=torch.int8)).startswith("gemm_a8w8_kernel"), _kernel_name(lin, x)
+    assert _kernel_name(lin, torch.empty(77, 4096, dtype=torch.int8)).startswith("gemm_a8w8_mma_kernel"), _kernel_name(lin, x)
     y = lin(x)
-    gemlite_amd.core.TUNING_OVERRIDE = (1, 0, 0, 0)
-    try:
-        y2 = lin(x)
-    finally:
-        gemlite_amd.core.TUNING_OVERRIDE = None
+    outs = {}
+    # streaming kernel | 4-wave MFMA kernel of round 1 | 8-wave kernel: every tile height, K split 1 / 3 (uneven) / 8
+    for t in ((1, 0, 0, 0), (2, 0, 0, 0), (0, 1, 1, 0), (0, 3, 2, 0), (0, 8, 4, 0), (0, 1, 8, 0), (0, 5, 8, 0)):
+        gemlite_amd.core.TUNING_OVERRIDE = t
+        try:
+            outs[t] = lin(x)
+        finally:
+            gemlite_amd.core.TUNING_OVERRIDE = None
     torch.cuda.synchronize()
-    assert torch.equal(y, y2)
+    for t, y2 in outs.items():
+        assert torch.equal(y, y2), t
+    for M in (2, 5, 16, 31):  # few rows: the 32-row tile of the MFMA kernel instead of one wave per column
+        xs = (torch.randn(M, 4096) / 10).half().to(DEV)
+        assert _kernel_name(lin, torch.empty(M, 4096, dtype=torch.int8)).startswith("gemm_a8w8_mma_kernel<32x128>")
+        ya = lin(xs)
+        gemlite_amd.core.TUNING_OVERRIDE = (1, 0, 0, 0)
+        try:
+            yb = lin(xs)
+        finally:
+            gemlite_amd.core.TUNING_OVERRIDE = None
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), M
 
 
 @pytest.mark.parametrize("M", [1, 64])

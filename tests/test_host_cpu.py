@@ -42,6 +42,8 @@ def _args(M=1, N=4096, K=4096, nbits=4, gs=128, in_dt=1, w_mode=4, c_mode=0, e=N
     a.w_pack_bits, a.w_dtype = (32, 6) if e > 1 else (0, kw.get("w_dtype", in_dt))
     a.input_dtype = a.output_dtype = a.meta_dtype = a.zeros_dtype = in_dt
     a.output_dtype = kw.get("out_dt", in_dt if in_dt in (0, 1, 2) else 1)
+    if in_dt in (3, 4, 8):  # 8-bit activations: the per-channel weight scales are fp32 (helper.py:474-475)
+        a.meta_dtype = kw.get("meta_dt", 0)
     a.channel_scale_mode, a.W_group_mode = c_mode, w_mode
     a.stride_xm, a.stride_xk = K, 1
     a.stride_wk, a.stride_wn = (N, 1) if e > 1 else (1, K)
@@ -121,11 +123,13 @@ def test_struct_abi_and_validation():
     (dict(M=256, N=16384, K=16384, nbits=2), "gemm_w2_mma_kernel<256x128>"),   # BASELINE config 5
     (dict(M=4, mt=3), "gemm_wn_direct_kernel<tile16>"),  # manual GEMM_SPLITK
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
-    (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
-    (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_kernel<64x64>"),    # A8W8 int8 on MFMA
-    (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_kernel<64x64>"),   # fp8 x fp8
-    (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_kernel<64x128>"),
-    (dict(M=4096, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_kernel<128x128>"),
+    (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # A8W8 int8 on MFMA from 2 rows
+    (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),
+    (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<64x128>"),   # fp8 x fp8: tallest tile with >= 112 tiles
+    (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<128x128>"),
+    (dict(M=4096, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<256x128>"),
+    (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<256x128>"),  # config 5
+    (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(2, 0, 0, 0)), "gemm_a8w8_kernel<64x64>"),  # round-1 kernel
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(1, 0, 0, 0)), "kmajor_matmul_kernel"),
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "kmajor_w8a16_kernel"),   # A16W8 int8, pre-scale
     (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "kmajor_w8a16_kernel"),  # fp8 W, bf16 x
