@@ -110,6 +110,7 @@ def get_matmul_type(batch_size: int, W_nbits: int, mx_dtype: bool = False) -> st
 # ------------------------------------------------------------------------------------------------------
 _META_FIELDS = ("scaled_activations", "W_nbits", "group_size", "unpack_mask", "elements_per_sample", "input_dtype",
                 "output_dtype", "acc_dtype", "meta_dtype", "channel_scale_mode", "W_group_mode", "data_contiguous")
+FUSE_ACT_QUANT_M1 = True  # decode of dynamically quantised layers: activation quantisation fused into the matmul kernel
 TUNING_OVERRIDE = None  # development hook: 4 ints forwarded as gemlite_hip_forward_args.tuning (0 = library default)
 
 # Per-layer launch templates.  A template is the IMMUTABLE byte image of a gemlite_hip_forward_args whose static
@@ -267,8 +268,12 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
         raise NotImplementedError("MX / NV block-scaled dtypes are outside this build's scope")
     scales_x = None
     if bool(meta_args[0]) and DType(in_code) in FP8_INT8_DTYPES:
-        # dynamic per-token activation quantisation (core.py:155-175)
-        x, scales_x = scale_activations_per_token(x, w_dtype=DTYPE_TO_TORCH[in_code])
+        # dynamic per-token activation quantisation (core.py:155-175).  One row of 16-bit activations against unpacked
+        # 8-bit weights (decode): the library quantises x inside the matmul kernel's prologue — one launch, not two.
+        fused = (FUSE_ACT_QUANT_M1 and x.numel() == x.shape[-1] and meta_args[4] == 1 and meta_args[10] == 0 and
+                 x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0)
+        if not fused:
+            x, scales_x = scale_activations_per_token(x, w_dtype=DTYPE_TO_TORCH[in_code])
     x2 = x.view(-1, x.shape[-1])
     # matmul_type < 0 (auto) is resolved inside the library: the HIP kernel families have their own M
     # thresholds (GEMV <= 4 rows, streaming MFMA above), unlike the Triton ones of get_matmul_type()

@@ -25,6 +25,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
 const void* kmajor_w8a16_kernel_fn(int mb);
+const void* kmajor_fused_quant_kernel_fn(int qdt);
 const void* act_quant_kernel_fn();
 const void* pack_kernel_fn();
 const void* unpack_kernel_fn();
@@ -71,6 +72,15 @@ static Epilogue make_epilogue(const gemlite_hip_forward_args& a) {
     return e;
 }
 
+// Dynamic activation quantisation fused into the matmul (M = 1): the caller passes the UNQUANTISED 16-bit x, no scales_x,
+// and the 8-bit unpacked weights of a dynamically quantised layer (channel_scale_mode 2 / 3).
+static bool wants_fused_quant(const gemlite_hip_forward_args* a) {
+    return a->M == 1 && a->elements_per_sample == 1 && !a->scales_x &&
+           (a->channel_scale_mode == 2 || a->channel_scale_mode == 3) && a->W_group_mode == 0 &&
+           (a->input_dtype == GEMLITE_DT_FP16 || a->input_dtype == GEMLITE_DT_BF16) &&
+           (a->w_dtype == GEMLITE_DT_INT8 || a->w_dtype == GEMLITE_DT_FP8E4 || a->w_dtype == GEMLITE_DT_FP8E5);
+}
+
 static int validate(const gemlite_hip_forward_args* a) {
     if (!a || a->struct_size != sizeof(gemlite_hip_forward_args)) return GEMLITE_ERR_BAD_ARGUMENT;
     if (!a->x || !a->w_q || !a->out) return GEMLITE_ERR_BAD_ARGUMENT;
@@ -89,7 +99,7 @@ static int validate(const gemlite_hip_forward_args* a) {
     const bool need_z = a->W_group_mode == 1 || a->W_group_mode >= 3;
     if (need_s && !a->scales) return GEMLITE_ERR_BAD_ARGUMENT;
     if (need_z && !a->zeros) return GEMLITE_ERR_BAD_ARGUMENT;
-    if ((a->channel_scale_mode == 2 || a->channel_scale_mode == 3) && !a->scales_x) return GEMLITE_ERR_BAD_ARGUMENT;
+    if ((a->channel_scale_mode == 2 || a->channel_scale_mode == 3) && !a->scales_x && !wants_fused_quant(a)) return GEMLITE_ERR_BAD_ARGUMENT;
     if (a->elements_per_sample > 1) {
         if (a->w_pack_bits != 8 && a->w_pack_bits != 16 && a->w_pack_bits != 32 && a->w_pack_bits != 64)
             return GEMLITE_ERR_BAD_ARGUMENT;
@@ -168,6 +178,18 @@ coverage:
     g.stride_meta_g = per_group_meta ? a.stride_meta_g : 0;
     g.stride_meta_n = per_group_meta ? a.stride_meta_n : ((a.W_group_mode == 1 && !a.zero_is_scalar) ? 1 : 0);
     r.gp = g;
+    // M = 1 of a dynamically quantised layer with the activation quantisation fused into the prologue
+    if (wants_fused_quant(&a)) {
+        if (a.stride_wk != 1 || a.stride_xk != 1 || a.K % 16 != 0 || a.stride_wn % 16 != 0 || a.K > 65536 ||
+            (((uintptr_t)a.w_q | (uintptr_t)a.x) % 16) != 0) { r.status = GEMLITE_ERR_UNSUPPORTED; return; }
+        r.kind = K_KMAJOR;
+        r.lp.fn = kmajor_fused_quant_kernel_fn(a.w_dtype);
+        r.lp.name = "kmajor_fused_quant_kernel";
+        r.lp.grid = dim3((unsigned)((a.N + 7) / 8), 1, 1);
+        r.lp.block = dim3(512, 1, 1);
+        r.lp.lds_bytes = (size_t)((a.K + 15) & ~15) + 64;
+        return;
+    }
     // A8W8 (int8 / fp8) from 2 rows: the 8-wave MFMA kernel.  tuning[0]: 1 = streaming kernel (one wave per column),
     // 2 = the 4-wave MFMA kernel of round 1 (M >= 32)
     if (!packed && a.tuning[0] == 0 && a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
@@ -354,7 +376,8 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
         return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
     }
     void* kargs[] = {(void*)&r.gp};
-    return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, 0, st);
+    if (r.lp.lds_bytes > 65536) return GEMLITE_ERR_UNSUPPORTED;
+    return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
 }
 
 int gemlite_hip_scale_activations_per_token(const void* x, void* y, float* scales, int64_t M, int64_t K,

@@ -186,17 +186,18 @@ __global__ __launch_bounds__(256, 2) void gemm_a8w8_kernel(const GenericParams p
 // 4 consecutive outputs of one row from fp32 values: channel scaling (scales of fp32 / fp16 / bf16: one uniform
 // three-way branch, vector loads), cast, one vector store
 __device__ __forceinline__ void store_out4_any(const Epilogue& e, f32x4 v, int64_t m, int64_t n0) {
+    // same operation order as epilogue_scale(): mode 3 multiplies by the PRODUCT s_x[m] * s_w[n] (bit-identical outputs)
+    f32x4 sw = {1.f, 1.f, 1.f, 1.f};
     if (e.c_mode == 1 || e.c_mode == 3) {
-        f32x4 sw;
         if (e.meta_dt == GEMLITE_DT_FP32) sw = *(const f32x4*)((const float*)e.scales_w + n0);
         else if (e.meta_dt == GEMLITE_DT_FP16) sw = load4_t<half_tag>(e.scales_w, n0);
         else sw = load4_t<bf16_tag>(e.scales_w, n0);
-        v *= sw;
     }
     if (e.c_mode == 2 || e.c_mode == 3) {
         const float sx = e.scales_x[m * e.stride_sx_m];
-        v *= (f32x4){sx, sx, sx, sx};
+        sw = e.c_mode == 3 ? (f32x4){sx * sw[0], sx * sw[1], sx * sw[2], sx * sw[3]} : (f32x4){sx, sx, sx, sx};
     }
+    if (e.c_mode != 0) v *= sw;
     if (e.out_dt == GEMLITE_DT_FP32) {
         *(f32x4*)((float*)e.out + m * e.stride_om + n0) = v;
         return;
@@ -212,7 +213,7 @@ __device__ __forceinline__ void store_out4_any(const Epilogue& e, f32x4 v, int64
     *(u32x2*)((uint16_t*)e.out + m * e.stride_om + n0) = o;
 }
 
-template <int DT, int MI>
+template <int DT, int MI, int RD>
 __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericParams p) {
     using namespace async;
     using AC = A8Acc<DT>;
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
     constexpr int NS = KW / 32;               // 32-k slices per wave and step
     constexpr int NQ = NS * MI, L = MI >= 4 ? 4 : (MI == 2 ? 4 : 2);
     constexpr int C_ROWS = 128, C_PITCH = BN + 4;
-    static_assert(PIECES >= 1 && NQ >= 2 * L, "tile too small for the slot schedule");
+    constexpr int PD = RD - 2;  // weights are requested PD steps ahead: a step is only 4 MI MFMAs per wave (128 MI cycles)
+                                // and an HBM round trip under load 2-3k cycles, so the small tiles need a deep ring
+    static_assert(PIECES >= 1 && NQ >= 2 * L && RD % 2 == 0 && RD >= 4, "tile too small for the slot schedule");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][STAGE], later the epilogue tiles
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -290,16 +293,16 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[i] = AC::zero();
 
-    BStep ring[4];
+    BStep ring[RD];
     u32x4 af[L];
 
-    // ---- prologue: x of step 0, weights of steps 0 and 1 -----------------------------------------------------------
+    // ---- prologue: x of step 0, weights of steps 0 .. PD-1 ------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
 #pragma unroll
-    for (int g = 0; g < NS; ++g) req_b(ring[0], 0, g);
+    for (int r = 0; r < PD; ++r)
 #pragma unroll
-    for (int g = 0; g < NS; ++g) req_b(ring[1], nsteps > 1 ? 1 : 0, g);
+        for (int g = 0; g < NS; ++g) req_b(ring[r], r < nsteps ? r : nsteps - 1, g);
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -312,8 +315,8 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
         constexpr int J = decltype(Jc)::value;
         constexpr int stage = J & 1;
         const BStep& bc = ring[J];
-        BStep& bl = ring[(J + 2) & 3];
-        const int lstep = step + 2 < nsteps ? step + 2 : nsteps - 1;  // run-ahead repeats the last step (never consumed)
+        BStep& bl = ring[(J + PD) % RD];
+        const int lstep = step + PD < nsteps ? step + PD : nsteps - 1;  // run-ahead repeats the last step (never consumed)
         const int xstep = step + 1 < nsteps ? step + 1 : step;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+    for (int s0 = 0; s0 < nsteps; s0 += RD) {
         do_step(std::integral_constant<int, 0>{}, s0);
         if (s0 + 1 >= nsteps) break;
         do_step(std::integral_constant<int, 1>{}, s0 + 1);
@@ -343,6 +346,18 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
         do_step(std::integral_constant<int, 2>{}, s0 + 2);
         if (s0 + 3 >= nsteps) break;
         do_step(std::integral_constant<int, 3>{}, s0 + 3);
+        if constexpr (RD > 4) {
+            if (s0 + 4 >= nsteps) break;
+            do_step(std::integral_constant<int, 4 % RD>{}, s0 + 4);
+            if (s0 + 5 >= nsteps) break;
+            do_step(std::integral_constant<int, 5 % RD>{}, s0 + 5);
+        }
+        if constexpr (RD > 6) {
+            if (s0 + 6 >= nsteps) break;
+            do_step(std::integral_constant<int, 6 % RD>{}, s0 + 6);
+            if (s0 + 7 >= nsteps) break;
+            do_step(std::integral_constant<int, 7 % RD>{}, s0 + 7);
+        }
     }
     wait_vm<0>();
 
@@ -435,10 +450,10 @@ template <int DT>
 static const void* a8_pick(int mi) {
     a8_kernel_fn f = nullptr;
     switch (mi) {
-        case 8: f = gemm_a8w8_mma_kernel<DT, 8>; break;
-        case 4: f = gemm_a8w8_mma_kernel<DT, 4>; break;
-        case 2: f = gemm_a8w8_mma_kernel<DT, 2>; break;
-        case 1: f = gemm_a8w8_mma_kernel<DT, 1>; break;
+        case 8: f = gemm_a8w8_mma_kernel<DT, 8, 4>; break;
+        case 4: f = gemm_a8w8_mma_kernel<DT, 4, 6>; break;
+        case 2: f = gemm_a8w8_mma_kernel<DT, 2, 8>; break;
+        case 1: f = gemm_a8w8_mma_kernel<DT, 1, 8>; break;
         default: break;
     }
     return (const void*)f;

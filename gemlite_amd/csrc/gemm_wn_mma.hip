@@ -152,7 +152,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 }  // namespace mma
 
 // MI 32-row blocks per wave (tile rows = 32 * MI), KSTEP k per step (each wave: KSTEP / 2).
-template <typename Tag, int NBITS, int MI, int KSTEP>
+template <typename Tag, int NBITS, int MI, int KSTEP, int RD>
 __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     using namespace mma;
     using TR = F16Traits<Tag>;
@@ -164,7 +164,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     constexpr int NS = SUB * 4;                            // MFMA slices (k16) per wave and step
     constexpr int NQ = NS * MI;                            // MFMA slots per wave and step
     constexpr int L = LOOKAHEAD;
-    static_assert(SUB >= 1 && PIECES >= 1 && NQ >= 2 * L, "tile too small for the slot schedule");
+    constexpr int PD = RD - 2;  // weights are requested PD steps ahead (ring of RD steps: short steps need a deep ring —
+                                // an HBM round trip under load is 2-3k cycles, a step of the 32-row tile 512)
+    static_assert(SUB >= 1 && PIECES >= 1 && NQ >= 2 * L && RD % 2 == 0 && RD >= 4, "tile too small for the slot schedule");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][STAGE], later the epilogue tiles
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -299,17 +301,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
             if ((MI == 8 ? j + 1 : (j * MI) / 4) == mi) out[j] = cv.pair(ev, od, j);
     };
 
-    BStep ring[4];
+    BStep ring[RD];
     u32x4 af[L];
     u32x4 bfrag[2];
 
-    // ---- prologue: x of step 0, weights of steps 0 and 1 -----------------------------------------------------------
+    // ---- prologue: x of step 0, weights of steps 0 .. PD-1 ------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
 #pragma unroll
-    for (int it = 0; it < NLB; ++it) req_b(ring[0], 0, it);
+    for (int r = 0; r < PD; ++r)
 #pragma unroll
-    for (int it = 0; it < NLB; ++it) req_b(ring[1], nsteps > 1 ? 1 : 0, it);
+        for (int it = 0; it < NLB; ++it) req_b(ring[r], r < nsteps ? r : nsteps - 1, it);
     wait_vm<0>();  // the DMA (asm); the compiler waits for the weights where they are first used
     __builtin_amdgcn_s_barrier();
     stamp(1);
@@ -334,12 +336,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         constexpr int J = decltype(Jc)::value;
         constexpr int stage = J & 1;
         const BStep& bc = ring[J];
-        const BStep& bn = ring[(J + 1) & 3];
-        BStep& bl = ring[(J + 2) & 3];
+        const BStep& bn = ring[(J + 1) % RD];
+        BStep& bl = ring[(J + PD) % RD];
         // Past the end of the slice the requests repeat the last step (never consumed): the SGPR offset of a buffer
         // access is not range-checked, so "out of range reads zeros" cannot be relied on; and the last step re-requests
         // its own x tile into the idle stage, which keeps the counted waits identical for every step.
-        const int lstep = step + 2 < nsteps ? step + 2 : nsteps - 1;
+        const int lstep = step + PD < nsteps ? step + PD : nsteps - 1;
         const int xstep = step + 1 < nsteps ? step + 1 : step;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+    for (int s0 = 0; s0 < nsteps; s0 += RD) {  // unrolled by the ring depth: every ring / stage index is static
         do_step(std::integral_constant<int, 0>{}, s0);
         if (s0 == 0) stamp(2);
         if (s0 + 1 >= nsteps) break;
@@ -372,6 +374,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         do_step(std::integral_constant<int, 2>{}, s0 + 2);
         if (s0 + 3 >= nsteps) break;
         do_step(std::integral_constant<int, 3>{}, s0 + 3);
+        if constexpr (RD > 4) {
+            if (s0 + 4 >= nsteps) break;
+            do_step(std::integral_constant<int, 4 % RD>{}, s0 + 4);
+            if (s0 + 5 >= nsteps) break;
+            do_step(std::integral_constant<int, 5 % RD>{}, s0 + 5);
+        }
+        if constexpr (RD > 6) {
+            if (s0 + 6 >= nsteps) break;
+            do_step(std::integral_constant<int, 6 % RD>{}, s0 + 6);
+            if (s0 + 7 >= nsteps) break;
+            do_step(std::integral_constant<int, 7 % RD>{}, s0 + 7);
+        }
     }
     // retire every outstanding request (the last step's run-ahead DMA) before the LDS is reused
     wait_vm<0>();
@@ -478,10 +492,10 @@ template <typename Tag, int NBITS>
 static const void* mma_pick_mi(int mi) {
     mma_kernel_fn f = nullptr;  // typed pointer first: a direct cast of the specialisation to void* does not instantiate the host stub
     switch (mi) {
-        case 8: f = gemm_wn_mma_kernel<Tag, NBITS, 8, 128>; break;
-        case 4: f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128>; break;
-        case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256>; break;
-        case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256>; break;
+        case 8: f = gemm_wn_mma_kernel<Tag, NBITS, 8, 128, 4>; break;
+        case 4: f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128, (NBITS == 8 ? 4 : 6)>; break;
+        case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256, (NBITS == 8 ? 4 : 6)>; break;
+        case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256, (NBITS == 8 ? 6 : 8)>; break;
         default: break;
     }
     return (const void*)f;
@@ -510,8 +524,20 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte LDS-DMA pieces
     if (p.group_size % 64 != 0) return false;  // one (scale, zero) pair per column and 64-k sub-block
-    // tile rows: the largest tile that M fills at least half (a dequantised fragment feeds MI MFMAs)
-    int mi = a.M > 128 ? 8 : (a.M > 64 ? 4 : (a.M > 32 ? 2 : 1));
+    // Tile rows.  A dequantised fragment feeds MI MFMAs, so tall tiles need the least unpack arithmetic — but every K
+    // slice costs slab traffic through memory (the XCD L2s are not coherent) plus a serial tail, and measured
+    // (profiles/r02: probe_mma_v3.log) the second effect wins: cfgA 64-row tiles x 2 slices 18.6 us vs 256 x 8 30.4,
+    // cfgB 128 x 2: 44.8 vs 256 x 4: 48.2.  Rule: the tallest tile (<= what M fills, >= 64 rows) that still yields >= 128
+    // tiles, i.e. at most two K slices; else >= 64 tiles; if none does, the tallest tile M fills.
+    const int cap = a.M > 128 ? 8 : (a.M > 64 ? 4 : (a.M > 32 ? 2 : 1));
+    auto tiles_of = [&](int c) { return (int64_t)(a.N / mma::BN) * ((a.M + 32 * c - 1) / (32 * c)); };
+    int mi = cap;
+    for (int want = 128; want >= 64; want >>= 1) {  // >= 128 tiles (<= 2 K slices), else >= 64 (<= 4), else the cap
+        int found = 0;
+        for (int c = cap; c >= 2 && !found; c >>= 1)
+            if (a.K % (c >= 4 ? 128 : 256) == 0 && tiles_of(c) >= want) found = c;
+        if (found) { mi = found; break; }
+    }
     if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4 || a.tuning[2] == 8) mi = a.tuning[2];
     const int kstep = mi >= 4 ? 128 : 256;
     if (a.K % kstep != 0) {

@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
 // ---------------------------------------------------------------------------------------------
 // host-side planning
 // ---------------------------------------------------------------------------------------------
-template <typename Tag, int NBITS, int MB, int R, int CQ, bool XD = false>
+template <typename Tag, int NBITS, int MB, int R, int CQ, bool XD = false, int NW = 4>
 static const void* inst() {
     // only the (bits, rows, tile) combinations the planner can pick are instantiated
     constexpr bool used = (CQ == 2 && R == 4 && (NBITS == 4 || NBITS == 2)) ||
@@ -407,7 +407,7 @@ static const void* inst() {
                           (CQ == 4 && ((R == 8 && NBITS == 8) || (R == 4 && (NBITS == 4 || NBITS == 2)) ||
                                        (R == 2 && NBITS == 2) || (R == 1 && NBITS == 1)));
     if constexpr (used && (R * (32 / NBITS)) % 32 == 0 && NBITS <= F16Traits<Tag>::MAX_QBITS) {
-        return (const void*)gemv_wn_kernel<Tag, NBITS, MB, R, CQ, XD>;
+        return (const void*)gemv_wn_kernel<Tag, NBITS, MB, R, CQ, XD, NW>;
     } else {
         return nullptr;
     }
@@ -424,6 +424,10 @@ static const void* pick_shape(int cq, int r, bool xd, int nw) {
         } else {
             return nullptr;
         }
+    }
+    if (nw == 8) {  // two waves per SIMD: one wave's unpack arithmetic overlaps the other's memory wait (long K)
+        if (r != 4) return nullptr;
+        return cq == 4 ? inst<Tag, NBITS, MB, 4, 4, false, 8>() : (cq == 3 ? inst<Tag, NBITS, MB, 4, 3, false, 8>() : nullptr);
     }
     if (cq == 2) return r == 4 ? inst<Tag, NBITS, MB, 4, 2>() : nullptr;
     if (cq == 3) return r == 4 ? inst<Tag, NBITS, MB, 4, 3>() : (r == 2 ? inst<Tag, NBITS, MB, 2, 3>() : nullptr);
@@ -450,6 +454,7 @@ static const void* pick_bits(int nbits, int mb, int cq, int r, bool xd, int nw =
     }
 }
 
+constexpr bool GEMV_AUTO_8W = false;  // flipped once measured (profiles/r02)
 // Decide variant / grid / split-K / LDS for the GEMV kernel.  Returns false if this shape is not covered.
 bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
     const int nbits = a.W_nbits;
@@ -541,10 +546,20 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
                 break;
             }
         }
+        // LDS-x path with 8 waves (tuning[2] == 8; auto when every wave still gets >= 4 chunks: the long-K shapes, where
+        // one wave per SIMD spends ~2/3 of its time in unpack arithmetic that nothing overlaps with the weight stream)
+        if (!xd && r == 4 && cq >= 3 && (nbits == 4 || nbits == 2) &&
+            (a.tuning[2] == 8 || (a.tuning[2] == 0 && GEMV_AUTO_8W && (units / splitk) >= 32)))
+            nw = 8;
         const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, xd, nw)
                                                            : pick_bits<bf16_tag>(nbits, mb, cq, r, xd, nw);
+        if (!fn && !xd && nw == 8) {
+            nw = 4;
+            fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, false) : pick_bits<bf16_tag>(nbits, mb, cq, r, false);
+        }
         if (!fn && xd) {
             xd = false;
+            nw = 4;
             fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, false)
                                                   : pick_bits<bf16_tag>(nbits, mb, cq, r, false);
         }
@@ -555,7 +570,8 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         lp.name = (xd && nw == 16) ? "gemv_wn_kernel<tile16,xdirect,16w>"
                   : (xd && nw == 8) ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect,8w>" : "gemv_wn_kernel<tile32,xdirect,8w>")
                   : xd ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect>" : (cq == 3 ? "gemv_wn_kernel<tile32,xdirect>" : "gemv_wn_kernel<tile64,xdirect>"))
-                     : (cq == 2 ? "gemv_wn_kernel<tile16>" : (cq == 3 ? "gemv_wn_kernel<tile32>" : "gemv_wn_kernel<tile64>"));
+                     : (nw == 8 ? (cq == 3 ? "gemv_wn_kernel<tile32,8w>" : "gemv_wn_kernel<tile64,8w>")
+                                : (cq == 2 ? "gemv_wn_kernel<tile16>" : (cq == 3 ? "gemv_wn_kernel<tile32>" : "gemv_wn_kernel<tile64>")));
         lp.grid = dim3(tiles, splitk, 1);
         lp.block = dim3(64 * nw, 1, 1);
         lp.lds_bytes = (size_t)mb * p.rows_per_slice * (e / 2) * 4 + (size_t)2 * mb * (p.rows_per_slice * e / 32) * 4 +

@@ -21,6 +21,15 @@ for step in "$@"; do
       for c in FETCH_SIZE WRITE_SIZE; do
         timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $PWD/$O/pmc_$c -o bench -- python bench.py --no-cpu-baseline --steps 5 --warmup 1 --no-graph --kernel-samples 8 > $O/pmc_$c.log 2>&1
       done ;;
+    pmc_mma)  # SQ counter passes (8 per pass) on one workload, eager launches, few steps
+      W=${GL_PMC_WORKLOAD:-a16w4_8192_m256}
+      P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
+      P2="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SALU"
+      P3="SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_IFETCH"
+      i=0; for P in "$P1" "$P2" "$P3"; do i=$((i+1))
+        timeout 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $PWD/$O/pmc_${W}_pass$i -o p -- python bench.py --workload $W --single --no-cpu-baseline --steps 3 --warmup 1 --no-graph --kernel-samples 8 > $O/pmc_${W}_pass$i.log 2>&1
+      done
+      python scripts/pmc_summary.py $O/pmc_${W}_pass* | tee $O/pmc_${W}_summary.txt ;;
     ubench) for b in ${GL_UBENCH:-launch_floor}; do timeout 300 scripts/ubench/$b ${GL_UBENCH_ARGS} > $O/ubench_$b.log 2>&1; cat $O/ubench_$b.log; done ;;
     probe:*) timeout 900 python scripts/${step#probe:} > $O/$(basename ${step#probe:} .py).log 2>&1; tail -60 $O/$(basename ${step#probe:} .py).log ;;
     sh:*) bash -c "${step#sh:}" ;;

@@ -49,19 +49,14 @@ def run(tag, N, K, nbits, M, tdt, tunings, nl=8, gs=128, mt=-1):
 
 
 bf, hf = torch.bfloat16, torch.float16
-which = sys.argv[1:] or ["cfgA", "cfgB", "a8"]
+which = sys.argv[1:] or ["cfgA", "cfgB", "a8", "rows"]
 if "cfgA" in which:
-    run("cfgA bf16", 4096, 4096, 4, 256, bf, [(0, 0, 0, 0), (0, 4, 4, 0), (0, 2, 4, 0), (0, 2, 2, 0), (0, 1, 2, 0), (0, 3, 2, 0), (0, 4, 2, 0),
-                                               (0, 1, 1, 0), (0, 2, 1, 0), (0, 4, 8, 0), (2, 0, 0, 0)], nl=32)
+    run("cfgA bf16", 4096, 4096, 4, 256, bf, [(0, 0, 0, 0), (0, 4, 4, 0), (0, 2, 2, 0), (0, 1, 1, 0), (0, 4, 8, 0), (2, 0, 0, 0)], nl=32)
 if "cfgB" in which:
-    run("cfgB bf16", 8192, 8192, 4, 256, bf, [(0, 0, 0, 0), (0, 2, 4, 0), (0, 1, 2, 0), (0, 2, 2, 0), (0, 1, 4, 0), (0, 3, 8, 0), (0, 1, 1, 0),
-                                               (2, 0, 0, 0)], nl=8)
-    run("cfgB fp16", 8192, 8192, 4, 256, hf, [(0, 0, 0, 0), (0, 1, 2, 0), (0, 2, 4, 0)], nl=8)
+    run("cfgB bf16", 8192, 8192, 4, 256, bf, [(0, 0, 0, 0), (0, 2, 4, 0), (0, 1, 2, 0), (0, 3, 8, 0), (0, 4, 8, 0), (2, 0, 0, 0)], nl=8)
 if "rows" in which:
-    for M in (33, 64, 128, 512, 1024):
-        run(f"4096 bf16 M={M}", 4096, 4096, 4, M, bf, [(0, 0, 0, 0), (2, 0, 0, 0)], nl=16)
-    for M in (8, 16, 32):
-        run(f"4096 fp16 M={M}", 4096, 4096, 4, M, hf, [(0, 0, 0, 0), (3, 0, 0, 0)], nl=32)
+    for M in (64, 128, 512):
+        run(f"4096 bf16 M={M}", 4096, 4096, 4, M, bf, [(0, 0, 0, 0), (0, 0, 1, 0), (0, 0, 2, 0), (0, 0, 4, 0), (0, 0, 8, 0), (2, 0, 0, 0)], nl=16)
 if "w2" in which:
     run("A16W2 16384 bf16", 16384, 16384, 2, 256, bf, [(0, 0, 0, 0), (0, 1, 4, 0)], nl=2)
 if "oddk" in which:
@@ -79,7 +74,7 @@ if "a8" in which:
             x = (torch.randn(M, K, generator=g, device=DEV) / 10).half()
             xq, sx = scale_activations_per_token(x, qdt)
             ops = 2.0 * M * N * K
-            tun = [(0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0)] + ([(0, 1, 2, 0), (0, 2, 4, 0), (0, 4, 8, 0), (0, 4, 4, 0), (0, 1, 1, 0)] if M == 256 else [])
+            tun = [(0, 0, 0, 0), (2, 0, 0, 0)] + ([(1, 0, 0, 0)] if M <= 16 else []) + ([(0, 2, 2, 0), (0, 2, 4, 0), (0, 4, 8, 0), (0, 4, 4, 0), (0, 1, 1, 0)] if M == 256 else [])
             for t in tun:
                 i = [0]
 

@@ -733,3 +733,27 @@ def test_forward_functional_custom_op_matches_the_module_and_compiles():
     torch.cuda.synchronize()
     assert y_comp.shape == y_eager.shape
     assert float((y_comp.float() - y_eager.float()).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+def test_fused_activation_quant_at_m1_is_bit_identical_to_the_two_launch_path(kind):
+    """at M = 1 the per-token activation quantisation runs inside the matmul kernel's prologue.
+    Same arithmetic as scale_activations_per_token + the streaming matmul -> bit-identical outputs."""
+    torch.manual_seed(11)
+    W = (torch.randn(4096, 4096) / 30).half()
+    proc = (gemlite_amd.helper.A8W8_int8_dynamic if kind == "int8" else gemlite_amd.helper.A8W8_fp8_dynamic)(device=DEV, dtype=torch.float16)
+    lin = proc.from_weights(W)
+    for shape in ((1, 4096), (1, 1, 4096), (4096,)):
+        x = (torch.randn(*shape) / 10).half().to(DEV)
+        y_fused = lin(x)
+        gemlite_amd.core.FUSE_ACT_QUANT_M1 = False
+        try:
+            y_two = lin(x)
+        finally:
+            gemlite_amd.core.FUSE_ACT_QUANT_M1 = True
+        torch.cuda.synchronize()
+        assert y_fused.shape == y_two.shape and torch.equal(y_fused, y_two), (kind, shape)
+    x = (torch.randn(1, 4096) / 10).half().to(DEV)
+    xq, sx = O.scale_activations_per_token(x, O.INT8 if kind == "int8" else O.FP8E4)
+    y_or = (xq @ O.to_f64(lin.W_q.data)) * (sx.astype(np.float64) * O.to_f64(lin.scales.data).reshape(1, -1))
+    _compare(f"fused-quant/{kind}", lin(x), y_or, 1, abs_gate=5e-3)
