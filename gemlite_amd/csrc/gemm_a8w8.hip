@@ -213,7 +213,7 @@ __device__ __forceinline__ void store_out4_any(const Epilogue& e, f32x4 v, int64
     *(u32x2*)((uint16_t*)e.out + m * e.stride_om + n0) = o;
 }
 
-template <int DT, int MI, int RD>
+template <int DT, int MI, int RD, int NST>
 __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericParams p) {
     using namespace async;
     using AC = A8Acc<DT>;
@@ -227,8 +227,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
     constexpr int C_ROWS = 128, C_PITCH = BN + 4;
     constexpr int PD = RD - 2;  // weights are requested PD steps ahead: a step is only 4 MI MFMAs per wave (128 MI cycles)
                                 // and an HBM round trip under load 2-3k cycles, so the small tiles need a deep ring
-    static_assert(PIECES >= 1 && NQ >= 2 * L && RD % 2 == 0 && RD >= 4, "tile too small for the slot schedule");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][STAGE], later the epilogue tiles
+    // NST LDS stages of x (the tile of step s + NST - 1 is requested during step s): see gemm_wn_mma.hip
+    static_assert(PIECES >= 1 && NQ >= 2 * L && RD % NST == 0 && RD >= 4 && NST >= 2, "tile too small for the slot schedule");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST][STAGE], later the epilogue tiles
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -277,9 +278,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
     auto req_x = [&](int stage, int step, int j) {
         req_lds16(rsX, lds0 + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP));
     };
-    int fbase[2][NS];  // A fragment of (slice g, row block mi): row mi*32 + col, byte kh*128 + g*32 + h*16
+    int fbase[NST][NS];  // A fragment of (slice g, row block mi): row mi*32 + col, byte kh*128 + g*32 + h*16
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < NST; ++st)
 #pragma unroll
         for (int g = 0; g < NS; ++g) {
             const int slot = (kh * KW + g * 32 + h * 16) >> 4;
@@ -298,7 +299,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
 
     // ---- prologue: x of step 0, weights of steps 0 .. PD-1 ------------------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
+    for (int st = 0; st < NST - 1; ++st)
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) req_x(st, st < nsteps ? st : nsteps - 1, j);
 #pragma unroll
     for (int r = 0; r < PD; ++r)
 #pragma unroll
@@ -313,26 +316,26 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
     constexpr int RPS = (NL + NQI - 1) / NQI;
     auto do_step = [&](auto Jc, int step) {
         constexpr int J = decltype(Jc)::value;
-        constexpr int stage = J & 1;
+        constexpr int stage = J % NST, stage_next = (J + 1) % NST, stage_fill = (J + NST - 1) % NST;
         const BStep& bc = ring[J];
         BStep& bl = ring[(J + PD) % RD];
         const int lstep = step + PD < nsteps ? step + PD : nsteps - 1;  // run-ahead repeats the last step (never consumed)
-        const int xstep = step + 1 < nsteps ? step + 1 : step;
+        const int xstep = step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int g = q / MI, mi = q % MI;
             acc[mi] = AC::mma(af[q % L], bc.w[g], acc[mi]);
             if (q == NQI) {
-                wait_vm<NLB>();                      // this step's x DMA has landed
+                wait_vm<(NST - 2) * PIECES + (NST - 1) * NLB>();  // the x DMA of step + 1 has landed
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
             if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
-            else af[q % L] = read_frag(stage ^ 1, q + L - NQ);
+            else af[q % L] = read_frag(stage_next, q + L - NQ);
 #pragma unroll
             for (int it = q * RPS; it < (q + 1) * RPS && it < NL; ++it) {
-                if (it < PIECES) req_x(stage ^ 1, xstep, it);
+                if (it < PIECES) req_x(stage_fill, xstep, it);
                 else req_b(bl, lstep, it - PIECES);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
         for (int j = 0; j < 4; ++j) f[j] = (float)v[j];
         store_out4_any(p.epi, f, m, ncol0 + c4);
     };
+    word4 own[NPASS][UNITS];  // this block's partial tile, kept for the combine (its own slab is not read back)
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         __syncthreads();
@@ -410,8 +414,10 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
         for (int i = 0; i < UNITS; ++i) {
             const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
             const int m = m0 + ps * PASS_ROWS + r;
+            own[ps][i] = (word4){0, 0, 0, 0};
             if (r < PASS_ROWS && m < p.M) {
                 const word4 v = *(const word4*)(ct + r * C_PITCH + c4);
+                own[ps][i] = v;
                 if (p.splitk == 1) finish(v, m, c4);
                 else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
                                                             (slice * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);  // sc1
@@ -421,11 +427,17 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
     if (p.splitk == 1) return;
     __syncthreads();
     if (!splitk_arrive_is_last(p.counters + bid, p.splitk, flag)) return;
+#pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         word4 sum[UNITS];
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) sum[i] = (word4){0, 0, 0, 0};
         for (int sl = 0; sl < p.splitk; ++sl) {
+            if (sl == slice) {  // own partial: from registers (fixed slice order keeps the sum deterministic)
+#pragma unroll
+                for (int i = 0; i < UNITS; ++i) sum[i] += own[ps][i];
+                continue;
+            }
             u32x4 t[UNITS];
 #pragma unroll
             for (int i = 0; i < UNITS; ++i) {
@@ -450,10 +462,10 @@ template <int DT>
 static const void* a8_pick(int mi) {
     a8_kernel_fn f = nullptr;
     switch (mi) {
-        case 8: f = gemm_a8w8_mma_kernel<DT, 8, 4>; break;
-        case 4: f = gemm_a8w8_mma_kernel<DT, 4, 6>; break;
-        case 2: f = gemm_a8w8_mma_kernel<DT, 2, 8>; break;
-        case 1: f = gemm_a8w8_mma_kernel<DT, 1, 8>; break;
+        case 8: f = gemm_a8w8_mma_kernel<DT, 8, 4, 2>; break;
+        case 4: f = gemm_a8w8_mma_kernel<DT, 4, 6, 3>; break;
+        case 2: f = gemm_a8w8_mma_kernel<DT, 2, 8, 4>; break;
+        case 1: f = gemm_a8w8_mma_kernel<DT, 1, 8, 4>; break;
         default: break;
     }
     return (const void*)f;
@@ -507,7 +519,7 @@ bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, Lau
               : (mi == 2 ? "gemm_a8w8_mma_kernel<64x128>" : "gemm_a8w8_mma_kernel<32x128>"));
     lp.grid = dim3((unsigned)tiles, splitk, 1);
     lp.block = dim3(512, 1, 1);
-    const size_t stages = (size_t)2 * bm * 256, xch = (size_t)4 * mi * 64 * 64;
+    const size_t stages = (size_t)(mi == 8 ? 2 : (mi == 4 ? 3 : 4)) * bm * 256, xch = (size_t)4 * mi * 64 * 64;
     const size_t c_b = (size_t)(bm < 128 ? bm : 128) * 132 * 4 + 16;
     lp.lds_bytes = stages > xch ? stages : xch;
     if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;

@@ -152,7 +152,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 }  // namespace mma
 
 // MI 32-row blocks per wave (tile rows = 32 * MI), KSTEP k per step (each wave: KSTEP / 2).
-template <typename Tag, int NBITS, int MI, int KSTEP, int RD>
+template <typename Tag, int NBITS, int MI, int KSTEP, int RD, int NST>
 __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     using namespace mma;
     using TR = F16Traits<Tag>;
@@ -166,8 +166,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     constexpr int L = LOOKAHEAD;
     constexpr int PD = RD - 2;  // weights are requested PD steps ahead (ring of RD steps: short steps need a deep ring —
                                 // an HBM round trip under load is 2-3k cycles, a step of the 32-row tile 512)
-    static_assert(SUB >= 1 && PIECES >= 1 && NQ >= 2 * L && RD % 2 == 0 && RD >= 4, "tile too small for the slot schedule");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][STAGE], later the epilogue tiles
+    // NST LDS stages of x: the tile of step s + NST - 1 is requested during step s.  With two stages the DMA is waited for
+    // in the very step that issued it, which only a long step (256-row tile: ~2k cycles) covers; the shorter steps of the
+    // smaller tiles spent ~40 % of their time in that wait (profiles/r02 PMC: SQ_WAIT_ANY 42 % of wave cycles).
+    static_assert(SUB >= 1 && PIECES >= 1 && NQ >= 2 * L && RD % NST == 0 && RD >= 4 && NST >= 2, "tile too small for the slot schedule");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST][STAGE], later the epilogue tiles
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -261,9 +264,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         req_lds16(rsX, lds0 + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP * 2));
     };
     // A fragment of slot q = (slice g, row block mi): row mi*32 + col, k = kh*KW + (g/4)*64 + k_of(g%4, h)
-    int fbase[2][NS];
+    int fbase[NST][NS];
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < NST; ++st)
 #pragma unroll
         for (int g = 0; g < NS; ++g) {
             const int k = kh * KW + (g >> 2) * 64 + G::k_of(g & 3, h);
@@ -307,7 +310,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
 
     // ---- prologue: x of step 0, weights of steps 0 .. PD-1 ------------------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
+    for (int st = 0; st < NST - 1; ++st)
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) req_x(st, st < nsteps ? st : nsteps - 1, j);
 #pragma unroll
     for (int r = 0; r < PD; ++r)
 #pragma unroll
@@ -331,10 +336,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     constexpr int NL = NLB + PIECES;
     constexpr int NQI = NQ - L;                       // request slots
     constexpr int RPS = (NL + NQI - 1) / NQI;         // requests per slot
-    static_assert(NL <= 48, "vmcnt is a 6-bit counter");
+    static_assert((NST - 2) * PIECES + (NST - 1) * NLB + NL <= 63, "vmcnt is a 6-bit counter");
     auto do_step = [&](auto Jc, int step) {
         constexpr int J = decltype(Jc)::value;
-        constexpr int stage = J & 1;
+        constexpr int stage = J % NST, stage_next = (J + 1) % NST, stage_fill = (J + NST - 1) % NST;
         const BStep& bc = ring[J];
         const BStep& bn = ring[(J + 1) % RD];
         BStep& bl = ring[(J + PD) % RD];
@@ -342,13 +347,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         // access is not range-checked, so "out of range reads zeros" cannot be relied on; and the last step re-requests
         // its own x tile into the idle stage, which keeps the counted waits identical for every step.
         const int lstep = step + PD < nsteps ? step + PD : nsteps - 1;
-        const int xstep = step + 1 < nsteps ? step + 1 : step;
+        const int xstep = step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int g = q / MI, mi = q % MI;
             acc[mi] = mfma32<Tag>(af[q % L], bfrag[g & 1], acc[mi]);
             if (q == NQI) {
-                wait_vm<NLB>();
+                // everything but the requests issued after the DMA of step + 1: (NST - 2) later DMAs, (NST - 1) weight sets
+                wait_vm<(NST - 2) * PIECES + (NST - 1) * NLB>();
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the current stage are complete
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -356,10 +362,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
             if (g + 1 < NS) deq_piece(bc, g + 1, mi, bfrag[(g + 1) & 1]);
             else deq_piece(bn, 0, mi, bfrag[(g + 1) & 1]);  // the next step's first slice
             if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
-            else af[q % L] = read_frag(stage ^ 1, q + L - NQ);
+            else af[q % L] = read_frag(stage_next, q + L - NQ);
 #pragma unroll
             for (int it = q * RPS; it < (q + 1) * RPS && it < NL; ++it) {
-                if (it < PIECES) req_x(stage ^ 1, xstep, it);
+                if (it < PIECES) req_x(stage_fill, xstep, it);
                 else req_b(bl, lstep, it - PIECES);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     const int64_t ncol0 = (int64_t)nt * BN;
     float* slab = p.slabs + ((int64_t)bid * p.splitk) * NOUT;  // wave-uniform base of this tile's slabs
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
+    f32x4 own[NPASS][UNITS];  // this block's partial tile, kept for the combine (its own slab is not read back)
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         __syncthreads();  // the exchange buffer / the previous pass is no longer read
@@ -444,8 +451,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         for (int i = 0; i < UNITS; ++i) {
             const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
             const int m = m0 + ps * PASS_ROWS + r;
+            own[ps][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (r < PASS_ROWS && m < p.M) {
                 const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
+                own[ps][i] = v;
                 if (p.splitk == 1) store_out4_t<Tag>(p.epi, v, m, ncol0 + c4);
                 else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
                                                             (slice * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);  // sc1
@@ -458,12 +467,19 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     const bool last = splitk_arrive_is_last(p.counters + bid, p.splitk, flag);
     stamp(6);
     if (!last) return;
-    // last arriver: slices outer, units inner -> every slice's 16-byte loads are in flight together
+    // last arriver: slices in fixed order (run-to-run deterministic), units inner -> a slice's 16-byte loads are in flight
+    // together; its OWN partial comes from registers, not from its slab
+#pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         f32x4 sum[UNITS];
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) sum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < p.splitk; ++s) {
+            if (s == slice) {
+#pragma unroll
+                for (int i = 0; i < UNITS; ++i) sum[i] += own[ps][i];
+                continue;
+            }
             u32x4 t[UNITS];
 #pragma unroll
             for (int i = 0; i < UNITS; ++i) {
@@ -492,10 +508,10 @@ template <typename Tag, int NBITS>
 static const void* mma_pick_mi(int mi) {
     mma_kernel_fn f = nullptr;  // typed pointer first: a direct cast of the specialisation to void* does not instantiate the host stub
     switch (mi) {
-        case 8: f = gemm_wn_mma_kernel<Tag, NBITS, 8, 128, 4>; break;
-        case 4: f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128, (NBITS == 8 ? 4 : 6)>; break;
-        case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256, (NBITS == 8 ? 4 : 6)>; break;
-        case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256, (NBITS == 8 ? 6 : 8)>; break;
+        case 8: f = gemm_wn_mma_kernel<Tag, NBITS, 8, 128, 4, 2>; break;
+        case 4: f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128, 6, 3>; break;
+        case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256, 6, (NBITS == 8 ? 2 : 3)>; break;
+        case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256, (NBITS == 8 ? 6 : 8), (NBITS == 8 ? 2 : 4)>; break;
         default: break;
     }
     return (const void*)f;
@@ -583,7 +599,8 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     lp.name = names[nbits == 4 ? 0 : (nbits == 2 ? 1 : (nbits == 1 ? 2 : 3))][mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))];
     lp.grid = dim3((unsigned)tiles, splitk, 1);
     lp.block = dim3(512, 1, 1);
-    const size_t stages = (size_t)2 * bm * ks * 2;
+    const int nst = mi == 8 ? 2 : (mi == 4 ? 3 : (nbits == 8 ? 2 : (mi == 2 ? 3 : 4)));  // LDS stages of x (mma_pick_mi)
+    const size_t stages = (size_t)nst * bm * ks * 2;
     const size_t xch = (size_t)4 * mi * 4 * 64 * 16;  // K-half exchange: [cg][mi][e4][lane] float4
     const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * mma::C_PITCH * 4 + 16;
     lp.lds_bytes = stages > xch ? stages : xch;
