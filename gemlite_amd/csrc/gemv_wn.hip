@@ -454,7 +454,9 @@ static const void* pick_bits(int nbits, int mb, int cq, int r, bool xd, int nw =
     }
 }
 
-constexpr bool GEMV_AUTO_8W = false;  // flipped once measured (profiles/r02)
+// measured (profiles/r02/probe_gemv.log): A16W2 16384^2 20.0 -> 17.8 us with 8 waves (16 k per packed word: twice the unpack
+// arithmetic per byte); 4-bit shapes do not gain (16384^2: 24.6 vs 25.8 us, 8192^2: equal) and keep 4 waves
+constexpr bool GEMV_AUTO_8W = true;
 // Decide variant / grid / split-K / LDS for the GEMV kernel.  Returns false if this shape is not covered.
 bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
     const int nbits = a.W_nbits;
@@ -549,7 +551,7 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         // LDS-x path with 8 waves (tuning[2] == 8; auto when every wave still gets >= 4 chunks: the long-K shapes, where
         // one wave per SIMD spends ~2/3 of its time in unpack arithmetic that nothing overlaps with the weight stream)
         if (!xd && r == 4 && cq >= 3 && (nbits == 4 || nbits == 2) &&
-            (a.tuning[2] == 8 || (a.tuning[2] == 0 && GEMV_AUTO_8W && (units / splitk) >= 32)))
+            (a.tuning[2] == 8 || (a.tuning[2] == 0 && GEMV_AUTO_8W && nbits == 2 && (units / splitk) >= 32)))
             nw = 8;
         const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, xd, nw)
                                                            : pick_bits<bf16_tag>(nbits, mb, cq, r, xd, nw);
