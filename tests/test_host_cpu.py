@@ -110,7 +110,7 @@ def test_struct_abi_and_validation():
     (dict(M=256, N=4096, K=11008), "gemm_w4_mma_kernel<64x128>"),
     (dict(M=1, nbits=2), "gemv_wn_kernel<tile16>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
-    (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64>"),
+    (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64,8w>"),   # 2-bit, long K: two waves per SIMD
     (dict(M=16), "gemm_wn_direct_kernel<tile32>"),
     (dict(M=1, mt=4), "gemm_w4_mma_kernel<32x128>"),   # manual GEMM family at M=1 -> the tiled MFMA kernel
     (dict(M=128), "gemm_w4_mma_kernel<64x128>"),
