@@ -298,15 +298,23 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
     u32x4 af[L];
 
     // ---- prologue: x of step 0, weights of steps 0 .. PD-1 ------------------------------------------------------------
+    // x and weights of step 0 first; only the x tile of step 0 is waited for (counted), see gemm_wn_mma.hip
 #pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
+    for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
+#pragma unroll
+    for (int g = 0; g < NS; ++g) req_b(ring[0], 0, g);
+#pragma unroll
+    for (int st = 1; st < NST - 1; ++st)
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) req_x(st, st < nsteps ? st : nsteps - 1, j);
 #pragma unroll
-    for (int r = 0; r < PD; ++r)
+    for (int r = 1; r < PD; ++r)
 #pragma unroll
         for (int g = 0; g < NS; ++g) req_b(ring[r], r < nsteps ? r : nsteps - 1, g);
-    wait_vm<0>();
+    {
+        constexpr int AFTER = (NST - 2) * PIECES + PD * NS;
+        wait_vm<(AFTER < 63 ? AFTER : 63)>();
+    }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int q = 0; q < L; ++q) af[q] = read_frag(0, q);

@@ -152,7 +152,9 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 }  // namespace mma
 
 // MI 32-row blocks per wave (tile rows = 32 * MI), KSTEP k per step (each wave: KSTEP / 2).
-template <typename Tag, int NBITS, int MI, int KSTEP, int RD, int NST>
+// EXP (development builds only, -DGL_MMA_EXPERIMENTS + tuning[3] >> 8): drop parts of the K loop to see what each costs —
+// 1 barrier + counted wait, 2 dequant VALU, 4 A-fragment reads, 8 x DMA requests, 16 weight requests.  Results are wrong.
+template <typename Tag, int NBITS, int MI, int KSTEP, int RD, int NST, int EXP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     using namespace mma;
     using TR = F16Traits<Tag>;
@@ -309,15 +311,25 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     u32x4 bfrag[2];
 
     // ---- prologue: x of step 0, weights of steps 0 .. PD-1 ------------------------------------------------------------
+    // request order = the order things are needed: x and weights of step 0 first.  Only the x tile of step 0 is waited
+    // for (counted: everything issued after it may still be in flight); the compiler waits for the weights of step 0 where
+    // they are first used.
 #pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
+    for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
+#pragma unroll
+    for (int it = 0; it < NLB; ++it) req_b(ring[0], 0, it);
+#pragma unroll
+    for (int st = 1; st < NST - 1; ++st)
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) req_x(st, st < nsteps ? st : nsteps - 1, j);
 #pragma unroll
-    for (int r = 0; r < PD; ++r)
+    for (int r = 1; r < PD; ++r)
 #pragma unroll
         for (int it = 0; it < NLB; ++it) req_b(ring[r], r < nsteps ? r : nsteps - 1, it);
-    wait_vm<0>();  // the DMA (asm); the compiler waits for the weights where they are first used
+    {
+        constexpr int AFTER = (NST - 2) * PIECES + PD * NLB;  // requests issued after the x tile of step 0
+        wait_vm<(AFTER < 63 ? AFTER : 63)>();  // (the counter holds 63: with more issued behind it, the tile has landed anyway)
+    }
     __builtin_amdgcn_s_barrier();
     stamp(1);
 #pragma unroll
@@ -352,21 +364,25 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         for (int q = 0; q < NQ; ++q) {
             const int g = q / MI, mi = q % MI;
             acc[mi] = mfma32<Tag>(af[q % L], bfrag[g & 1], acc[mi]);
-            if (q == NQI) {
+            if (q == NQI && !(EXP & 1)) {
                 // everything but the requests issued after the DMA of step + 1: (NST - 2) later DMAs, (NST - 1) weight sets
                 wait_vm<(NST - 2) * PIECES + (NST - 1) * NLB>();
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the current stage are complete
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
-            if (g + 1 < NS) deq_piece(bc, g + 1, mi, bfrag[(g + 1) & 1]);
-            else deq_piece(bn, 0, mi, bfrag[(g + 1) & 1]);  // the next step's first slice
-            if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
-            else af[q % L] = read_frag(stage_next, q + L - NQ);
+            if (!(EXP & 2)) {
+                if (g + 1 < NS) deq_piece(bc, g + 1, mi, bfrag[(g + 1) & 1]);
+                else deq_piece(bn, 0, mi, bfrag[(g + 1) & 1]);  // the next step's first slice
+            }
+            if (!(EXP & 4)) {
+                if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
+                else af[q % L] = read_frag(stage_next, q + L - NQ);
+            }
 #pragma unroll
             for (int it = q * RPS; it < (q + 1) * RPS && it < NL; ++it) {
-                if (it < PIECES) req_x(stage_fill, xstep, it);
-                else req_b(bl, lstep, it - PIECES);
+                if (it < PIECES) { if (!(EXP & 8)) req_x(stage_fill, xstep, it); }
+                else if (!(EXP & 16)) req_b(bl, lstep, it - PIECES);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -587,6 +603,15 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if ((uint64_t)splitk * bm * mma::BN * 4 >= (1ull << 31)) return false;  // slab buffer descriptor range
     const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
     const void* fn = f16 ? mma_pick<half_tag>(nbits, mi) : mma_pick<bf16_tag>(nbits, mi);
+#ifdef GL_MMA_EXPERIMENTS
+    if (!f16 && nbits == 4 && (mi == 4 || mi == 8)) {
+        mma_kernel_fn f = nullptr;
+#define GL_EXP_CASE(E) case E: f = mi == 4 ? gemm_wn_mma_kernel<bf16_tag, 4, 4, 128, 6, 3, E> : gemm_wn_mma_kernel<bf16_tag, 4, 8, 128, 4, 2, E>; break;
+        switch (a.tuning[3] >> 8) { GL_EXP_CASE(1) GL_EXP_CASE(2) GL_EXP_CASE(4) GL_EXP_CASE(8) GL_EXP_CASE(16) GL_EXP_CASE(3) GL_EXP_CASE(6) GL_EXP_CASE(7) GL_EXP_CASE(31) default: break; }
+#undef GL_EXP_CASE
+        if (f) fn = (const void*)f;
+    }
+#endif
     if (!fn) return false;
     p.splitk = splitk;
     p.rows_per_slice = rows;  // ALL packed rows: the kernel derives each slice's step range itself

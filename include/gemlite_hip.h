@@ -92,7 +92,10 @@ typedef struct gemlite_hip_forward_args {
     const void* w_q;      /* packed: [K/e, N] words of w_pack_bits; unpacked: [K, N] view  */
     const void* scales;   /* [K/group, N] meta_dtype, or [N] channel scales, or NULL       */
     const void* zeros;    /* [K/group, N] meta_dtype, 1-elem int32 (scalar), or NULL       */
-    const void* scales_x; /* [M] fp32 per-token activation scales, or NULL                 */
+    const void* scales_x; /* [M] fp32 per-token activation scales, or NULL.  NULL together with
+                           * channel_scale_mode 2/3, M == 1, 16-bit float x and unpacked int8 / fp8 weights asks for
+                           * the FUSED dynamic quantisation: x is quantised per token inside the matmul kernel
+                           * (same arithmetic as gemlite_hip_scale_activations_per_token, one launch instead of two) */
     void* out;            /* [M, N] output_dtype                                           */
     void* workspace;      /* >= gemlite_hip_workspace_bytes(); zero-filled ONCE by the owner */
     uint64_t workspace_bytes;
@@ -128,12 +131,16 @@ typedef struct gemlite_hip_forward_args {
      * stores — the counterpart of the reference's per-shape Triton autotune configs).  Meaning per kernel family:
      *   packed GEMV (M = 1)        [0] 2/3/4 = 16-/32-/64-column tiles   [1] K slices   [2] 4/8/16 waves per block
      *                              (82 = 8 waves, 2 rows per lane)       [3] & 3: 1 = x through LDS, 2 = x direct
-     *   few rows (2..32, MFMA)     [0] 1/2/4 = 16-/32-/64-column tiles   [1] K slices   [2] 1 = LDS-staged streaming kernel
-     *   tiled (M > 32, MFMA)       [0] 1 = streaming kernel instead      [1] K slices   [2] 4 = one-step-ahead kernel,
-     *                              8 = 256-row tiles (one block per CU)
-     *   unpacked 8-bit (A8W8)      [0] 1 = streaming (one wave per column) kernel instead of the MFMA kernel
-     *   [3] & 4: development timeline stamps (needs a workspace).  A value that does not apply to the shape makes the
-     *   planner fall through to its own choice or to another family; it never produces a wrong result. */
+     *   few rows (2..32, MFMA)     [0] 1/2/4 = 16-/32-/64-column tiles, 3 = the 8-wave tiled kernel instead
+     *                              [1] K slices   [2] 1 = LDS-staged streaming kernel
+     *   tiled (M > 32, MFMA)       [0] 1 = streaming kernel, 2 = the 4-wave tiled kernel of round 1 (4-bit only)
+     *                              [1] K slices (any count <= K steps; slices may be uneven)
+     *                              [2] tile rows / 32: 1/2/4/8 (8-wave kernel); with [0] = 2: 4 = one-step-ahead, 8 = 256 rows
+     *   unpacked 8-bit (A8W8)      [0] 1 = streaming (one wave per column), 2 = the 4-wave MFMA kernel of round 1
+     *                              [1] K slices   [2] tile rows / 32
+     *   [3] & 4: development timeline stamps (needs a workspace)   [3] & 8: XCD-aware (tile, K slice) map (opt-in).
+     *   A value that does not apply to the shape makes the planner fall through to its own choice or to another family;
+     *   it never produces a wrong result. */
     int32_t tuning[4];
 } gemlite_hip_forward_args;
 
