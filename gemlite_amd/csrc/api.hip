@@ -150,6 +150,13 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
             const bool want_tiled = (mt == GEMLITE_MATMUL_GEMM || (mt == GEMLITE_MATMUL_AUTO && a.M > 32));
             if (want_tiled && a.tuning[0] == 0 && plan_gemm_wn_mma(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
             if (want_tiled && a.tuning[0] != 1 && plan_gemm_wn_tiled(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
+            // 17..32 rows over a long K: the 8-wave kernel's LDS-staged x beats the
+            // registers-only kernel, whose blocks each re-read their K range of every row from L2 (M = 32: N 5120 x K 13824
+            // 25.3 vs 39.8 us, 8192 x 28672 51 vs 72, 28672 x 8192 49.5 vs 60; K <= 5120 the other way round —
+            // profiles/r02/autotune_report.json)
+            const bool long_k = mt == GEMLITE_MATMUL_AUTO && a.W_nbits == 4 && a.tuning[0] == 0 && a.tuning[2] == 0 &&
+                                a.M > 16 && a.K >= 8192;
+            if (long_k && plan_gemm_wn_mma(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
             // few rows: registers-only MFMA path (tuning[2] == 1 keeps the LDS-staged streaming kernel)
             if (a.M <= 32 && a.tuning[2] != 1 && a.tuning[0] != 3 && plan_gemm_wn_direct(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
             if (a.tuning[0] != 3 && plan_gemm_wn_stream(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }

@@ -350,8 +350,10 @@ bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         if (!fits(a.tuning[0])) return false;
         v = a.tuning[0];
     } else {
-        for (int cand : {4, 2, 1})  // widest tile that still gives every CU a block without splitting K
-            if (fits(cand) && (a.N / (16 * cand)) * mtiles >= 256) { v = cand; break; }
+        // widest tile that still gives most CUs a block without splitting K (>= 160 of 256: N = 11008 / 13824 / 14336 with
+        // 64-column tiles measured 12-48 % faster than 32-column tiles, profiles/r02/autotune_report.json)
+        for (int cand : {4, 2, 1})
+            if (fits(cand) && (a.N / (16 * cand)) * mtiles >= 160) { v = cand; break; }
         if (!v)
             for (int cand : {1, 2, 4})
                 if (fits(cand)) { v = cand; break; }
@@ -376,7 +378,7 @@ bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         for (int sk = 1; sk <= units; sk *= 2) {
             if (!ok(sk)) continue;
             splitk = sk;
-            if ((int64_t)tiles * mtiles * sk >= 256) break;
+            if ((int64_t)tiles * mtiles * sk >= 160) break;  // a K slice costs a combine: 172 unsplit blocks beat 344 split ones
         }
         if (!splitk) return false;
     }

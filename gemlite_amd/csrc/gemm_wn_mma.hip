@@ -161,7 +161,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     using G = Geo<NBITS>;
     constexpr int BM = 32 * MI, KW = KSTEP / 2, SUB = KW / 64, WPL = G::WPL;
     constexpr int PITCH = KSTEP * 2, STAGE = BM * PITCH;  // bytes per row / per stage of x
-    constexpr int SLOTS_ROW = PITCH / 16;                  // 16-byte slots per row (16 or 32)
     constexpr int PIECES = STAGE / 1024 / 8;               // 1-KiB LDS-DMA pieces per wave and stage
     constexpr int NS = SUB * 4;                            // MFMA slices (k16) per wave and step
     constexpr int NQ = NS * MI;                            // MFMA slots per wave and step
@@ -438,81 +437,101 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     }
 
     stamp(4);
-    // ---- epilogue 2: the tile is transposed through LDS (128 rows per pass) so that slabs and the output move as
-    //      16-byte row segments; C fragment of a 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-    float* ct = (float*)smem;  // [C_ROWS][C_PITCH]
-    constexpr int PASS_ROWS = BM < C_ROWS ? BM : C_ROWS;
-    unsigned* flag = (unsigned*)(smem + PASS_ROWS * C_PITCH * 4);
-    constexpr int NPASS = BM / PASS_ROWS, MIP = PASS_ROWS / 32;
-    constexpr int UNITS = (PASS_ROWS * BN / 4 + 511) / 512;  // float4 units per thread and pass
     constexpr int NOUT = BM * BN;
     const int64_t ncol0 = (int64_t)nt * BN;
-    float* slab = p.slabs + ((int64_t)bid * p.splitk) * NOUT;  // wave-uniform base of this tile's slabs
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
-    f32x4 own[NPASS][UNITS];  // this block's partial tile, kept for the combine (its own slab is not read back)
+    constexpr int PASS_ROWS = BM < C_ROWS ? BM : C_ROWS;
+    unsigned* flag = (unsigned*)(smem + PASS_ROWS * C_PITCH * 4);
+    constexpr int MIH = MI >= 2 ? MI / 2 : MI;  // row blocks per K-half wave in the combine
+    bool split_rows = false;                    // combine done: the two K-half waves of a column group share the rows
+    // ---- epilogue 2 (K split over blocks): the partial tile travels in FRAGMENT order — slabs are private to this
+    //      kernel, so nothing is transposed: waves 0..3 store their registers as 16-byte write-through rows (1 KiB per
+    //      wave instruction), and only the last block to arrive goes on: ALL 8 of its waves load the slices' words back
+    //      into the same lanes (wave (cg, kh) takes row blocks [kh MIH, kh MIH + MIH)), add them in slice order (run-to-run
+    //      deterministic) into the accumulator registers, and hand the sums to the output stage.
+    if (p.splitk > 1) {
+        float* slab = p.slabs + ((int64_t)bid * p.splitk) * NOUT;  // wave-uniform base of this tile's slabs
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
+        const int frag0 = (cg * MI * 4 * 64 + lane) * 4;  // float index of (mi = 0, e4 = 0) of this lane inside a slab
+        if (kh == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const f32x4 v = {acc[mi][4 * e4], acc[mi][4 * e4 + 1], acc[mi][4 * e4 + 2], acc[mi][4 * e4 + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                            (slice * NOUT + frag0 + (mi * 4 + e4) * 256) * 4, 0, 16);  // sc1
+                }
+        }
+        stamp(5);
+        const bool last = splitk_arrive_is_last(p.counters + bid, p.splitk, flag);
+        stamp(6);
+        if (!last) return;
+        auto gather = [&](auto BASEc) {  // row blocks [BASE, BASE + MIH): sum of all slices, in place
+            constexpr int BASE = decltype(BASEc)::value;
+#pragma unroll
+            for (int j = 0; j < MIH; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[BASE + j][e] = 0.f;
+            constexpr int CH = MIH > 2 ? 2 : MIH;  // row blocks per round trip (registers: 16 CH words in flight)
+            for (int s = 0; s < p.splitk; ++s) {
+#pragma unroll
+                for (int c = 0; c < MIH; c += CH) {
+                    u32x4 t[CH][4];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4)
+                            t[j][e4] = __builtin_amdgcn_raw_buffer_load_b128(
+                                rs, (s * NOUT + frag0 + ((BASE + c + j) * 4 + e4) * 256) * 4, 0, 16);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const f32x4 v = __builtin_bit_cast(f32x4, t[j][e4]);
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) acc[BASE + c + j][4 * e4 + tt] += v[tt];
+                        }
+                }
+            }
+        };
+        if (MI >= 2) {
+            split_rows = true;
+            if (kh == 0) gather(std::integral_constant<int, 0>{});
+            else gather(std::integral_constant<int, (MI >= 2 ? MIH : 0)>{});
+        } else if (kh == 0) {
+            gather(std::integral_constant<int, 0>{});
+        }
+        if (tid == 0) splitk_reset(p.counters + bid);
+    }
+
+    // ---- epilogue 3: the complete tile is transposed through LDS, 128 rows per pass, so that the output moves as 16-byte
+    //      row segments; C fragment of a 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    float* ct = (float*)smem;  // [PASS_ROWS][C_PITCH]
+    constexpr int NPASS = BM / PASS_ROWS, MIP = PASS_ROWS / 32;
+    constexpr int UNITS = (PASS_ROWS * BN / 4 + 511) / 512;  // float4 units per thread and pass
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         __syncthreads();  // the exchange buffer / the previous pass is no longer read
-        if (kh == 0) {
 #pragma unroll
-            for (int mi = 0; mi < MIP; ++mi)
+        for (int mi = 0; mi < MIP; ++mi) {
+            const int blk = ps * MIP + mi;  // row block of the tile (static)
+            const bool mine = split_rows ? ((blk >= MIH) == (kh == 1)) : (kh == 0);
+            if (mine) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    ct[r * C_PITCH + cg * 32 + col] = acc[ps * MIP + mi][e];
+                    ct[r * C_PITCH + cg * 32 + col] = acc[blk][e];
                 }
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
             const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
             const int m = m0 + ps * PASS_ROWS + r;
-            own[ps][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (r < PASS_ROWS && m < p.M) {
-                const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
-                own[ps][i] = v;
-                if (p.splitk == 1) store_out4_t<Tag>(p.epi, v, m, ncol0 + c4);
-                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
-                                                            (slice * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);  // sc1
-            }
+            if (r < PASS_ROWS && m < p.M) store_out4_t<Tag>(p.epi, *(const f32x4*)(ct + r * C_PITCH + c4), m, ncol0 + c4);
         }
     }
-    stamp(5);
-    if (p.splitk == 1) return;
-    __syncthreads();
-    const bool last = splitk_arrive_is_last(p.counters + bid, p.splitk, flag);
-    stamp(6);
-    if (!last) return;
-    // last arriver: slices in fixed order (run-to-run deterministic), units inner -> a slice's 16-byte loads are in flight
-    // together; its OWN partial comes from registers, not from its slab
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        f32x4 sum[UNITS];
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) sum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.splitk; ++s) {
-            if (s == slice) {
-#pragma unroll
-                for (int i = 0; i < UNITS; ++i) sum[i] += own[ps][i];
-                continue;
-            }
-            u32x4 t[UNITS];
-#pragma unroll
-            for (int i = 0; i < UNITS; ++i) {
-                const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
-                t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (s * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);
-            }
-#pragma unroll
-            for (int i = 0; i < UNITS; ++i) sum[i] += __builtin_bit_cast(f32x4, t[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
-            const int m = m0 + ps * PASS_ROWS + r;
-            if (r < PASS_ROWS && m < p.M) store_out4_t<Tag>(p.epi, sum[i], m, ncol0 + c4);
-        }
-    }
-    if (tid == 0) splitk_reset(p.counters + bid);
     stamp(7);
 }
 
@@ -556,49 +575,82 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte LDS-DMA pieces
     if (p.group_size % 64 != 0) return false;  // one (scale, zero) pair per column and 64-k sub-block
-    // Tile rows.  A dequantised fragment feeds MI MFMAs, so tall tiles need the least unpack arithmetic — but every K
-    // slice costs slab traffic through memory (the XCD L2s are not coherent) plus a serial tail, and measured
-    // (profiles/r02: probe_mma_v3.log) the second effect wins: cfgA 64-row tiles x 2 slices 18.6 us vs 256 x 8 30.4,
-    // cfgB 128 x 2: 44.8 vs 256 x 4: 48.2.  Rule: the tallest tile (<= what M fills, >= 64 rows) that still yields >= 128
-    // tiles, i.e. at most two K slices; else >= 64 tiles; if none does, the tallest tile M fills.
+    // Tile rows (32 MI) and K slices.  A dequantised fragment feeds MI MFMAs, so tall tiles need the least unpack arithmetic
+    // per MFMA; short tiles and K slices fill the 256 CUs (one 8-wave block each) — but every K slice costs slab traffic
+    // through memory (the XCD L2s are not coherent) plus a serial tail in the last block to arrive, and narrow row tiles
+    // re-read x from L2 once per column tile.  The choice is the minimum of a block-time model fitted to 66 shapes x 24
+    // (MI, slices) pairs measured with HBM-cold weights (scripts/make_tuning_table.py, profiles/r02/autotune_report.json;
+    // mean regret against the measured best 0.9 %, worst 18 %; the rule it replaces: 13 % / 90 %):
+    //   us = rounds * (P + steps * S + [slices > 1] * (Q + slices * R)) + 0.096 * slab_MB + 0.048 * x_through_L2_MB
+    // with rounds = ceil(blocks / 256) and steps = the K steps of the longest slice.
     const int cap = a.M > 128 ? 8 : (a.M > 64 ? 4 : (a.M > 32 ? 2 : 1));
-    auto tiles_of = [&](int c) { return (int64_t)(a.N / mma::BN) * ((a.M + 32 * c - 1) / (32 * c)); };
-    int mi = cap;
-    for (int want = 128; want >= 64; want >>= 1) {  // >= 128 tiles (<= 2 K slices), else >= 64 (<= 4), else the cap
-        int found = 0;
-        for (int c = cap; c >= 2 && !found; c >>= 1)
-            if (a.K % (c >= 4 ? 128 : 256) == 0 && tiles_of(c) >= want) found = c;
-        if (found) { mi = found; break; }
+    auto kstep_of = [](int c) { return c >= 4 ? 128 : 256; };
+    auto cost_us = [&](int c, int sk) -> double {
+        static const double P[4] = {1.46, 1.21, 1.67, 2.82}, S[4] = {0.945, 1.061, 0.695, 1.247};
+        static const double Q[4] = {1.78, 1.20, 1.51, 1.09}, R[4] = {0.0, 0.222, 0.283, 0.516};
+        const int i = c == 1 ? 0 : (c == 2 ? 1 : (c == 4 ? 2 : 3));
+        const int un = (int)(a.K / kstep_of(c));
+        const int steps = (un + sk - 1) / sk;
+        const int64_t mpad = (a.M + 32 * c - 1) / (32 * c) * (32 * c);
+        const int64_t blocks = (a.N / mma::BN) * (mpad / (32 * c)) * sk;
+        const double rounds = (double)((blocks + 255) / 256);
+        const double slab_mb = sk > 1 ? (double)sk * mpad * a.N * 8e-6 : 0.0;
+        const double x_mb = (double)(a.N / mma::BN) * mpad * a.K * 2e-6;
+        return rounds * (P[i] + steps * S[i] + (sk > 1 ? Q[i] + sk * R[i] : 0.0)) + 0.0955 * slab_mb + 0.0484 * x_mb;
+    };
+    int mi = 0, splitk = 0;
+    if (nbits != 4) {
+        // other bit widths (not swept; their unpack arithmetic per weight differs): the rule of thumb the 4-bit model
+        // replaced, measured on config 5 (A16W2 16384^2, M = 256: 256-row tiles x 2 slices, 137 us) — the tallest tile
+        // (>= 64 rows) that still yields >= 128 tiles, else >= 64, else the tallest M fills; then the fewest K slices that
+        // give >= 224 blocks while a slice keeps >= 4 steps.
+        mi = cap;
+        for (int want = 128; want >= 64; want >>= 1) {
+            int found = 0;
+            for (int c = cap; c >= 2 && !found; c >>= 1)
+                if (a.K % kstep_of(c) == 0 && (a.N / mma::BN) * ((a.M + 32 * c - 1) / (32 * c)) >= want) found = c;
+            if (found) { mi = found; break; }
+        }
+        if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4 || a.tuning[2] == 8) mi = a.tuning[2];
+        else if (a.tuning[2] != 0) return false;
+        if (a.K % kstep_of(mi) != 0) {
+            if (a.K % 128 != 0 || a.tuning[2] != 0) return false;
+            mi = mi < 4 ? 4 : mi;  // K = 128 * odd: only the 128-k-step variants apply
+        }
+        const int un = (int)(a.K / kstep_of(mi));
+        const int64_t tl = (int64_t)(a.N / mma::BN) * ((a.M + 32 * mi - 1) / (32 * mi));
+        if (a.tuning[1] > 0) splitk = a.tuning[1];
+        else {
+            for (int sk = 1; sk <= un && sk <= 32; ++sk) {
+                if (un / sk < 4) continue;
+                splitk = sk;
+                if (tl * sk >= 224) break;
+            }
+            if (!splitk) splitk = 1;
+        }
+    } else {
+        double best = 1e30;
+        for (int c = 1; c <= 8; c <<= 1) {
+            if (a.tuning[2] != 0 ? c != a.tuning[2] : c > cap) continue;
+            if (a.K % kstep_of(c) != 0) continue;
+            const int un = (int)(a.K / kstep_of(c));
+            for (int sk = 1; sk <= un && sk <= 16; ++sk) {
+                if (a.tuning[1] > 0 ? sk != a.tuning[1] : (sk > 1 && un / sk < 2)) continue;
+                const double t = cost_us(c, sk);
+                if (t < best) { best = t; mi = c; splitk = sk; }
+            }
+        }
+        if (!mi) return false;  // no tile variant divides K (K % 128 != 0), or an override that does not apply
     }
-    if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4 || a.tuning[2] == 8) mi = a.tuning[2];
-    const int kstep = mi >= 4 ? 128 : 256;
-    if (a.K % kstep != 0) {
-        if (a.K % 128 != 0 || a.tuning[2] != 0) return false;
-        mi = mi < 4 ? 4 : mi;  // K = 128 * odd: only the 128-k-step variants apply
-    }
-    const int ks = mi >= 4 ? 128 : 256;
+    const int ks = kstep_of(mi);
     const int bm = 32 * mi;
     const int rows = (int)(a.K / e), step_rows = ks / e;
     const int units = rows / step_rows;
+    if (splitk > units) return false;
     // buffer descriptors: 32-bit byte offsets
     if ((int64_t)rows * a.stride_wk * 4 >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31)) return false;
     if (((int64_t)(a.K / (p.group_size > 0 ? p.group_size : a.K)) * p.stride_meta_g + a.N) * 2 >= (1ll << 31)) return false;
     const int64_t tiles = (int64_t)(a.N / mma::BN) * ((a.M + bm - 1) / bm);
-    auto ok = [&](int sk) { return sk >= 1 && sk <= units; };  // uneven slices are fine (the kernel deals the steps)
-    int splitk = 0;
-    if (a.tuning[1] > 0) {
-        if (!ok(a.tuning[1])) return false;
-        splitk = a.tuning[1];
-    } else {
-        // one block per CU (8 waves = two per SIMD): the fewest K slices that give every CU a block, as long as a
-        // slice keeps at least 4 steps (prologue + epilogue + combine are paid per block)
-        for (int sk = 1; sk <= units && sk <= 32; ++sk) {
-            if (!ok(sk) || units / sk < 4) continue;
-            splitk = sk;
-            if (tiles * sk >= 224) break;
-        }
-        if (!splitk) splitk = 1;
-    }
     if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
     if ((uint64_t)splitk * bm * mma::BN * 4 >= (1ull << 31)) return false;  // slab buffer descriptor range
     const bool f16 = a.input_dtype == GEMLITE_DT_FP16;

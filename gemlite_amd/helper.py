@@ -309,8 +309,7 @@ _TUNING_CANDIDATES = {
     "few_rows": [(0, 0, 0, 0), (1, 1, 0, 0), (2, 1, 0, 0), (2, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 4, 0, 0), (0, 0, 1, 0),
                  (3, 0, 0, 0), (3, 0, 1, 0), (3, 0, 2, 0)],
     # 8-wave MFMA kernel: tuning[1] = K slices, tuning[2] = tile rows / 32
-    "tiled": [(0, 0, 0, 0), (0, 1, 0, 0), (0, 2, 0, 0), (0, 4, 0, 0), (0, 8, 0, 0), (0, 2, 4, 0), (0, 4, 4, 0), (0, 8, 4, 0),
-              (0, 2, 8, 0), (0, 4, 8, 0), (0, 8, 8, 0), (0, 0, 2, 0), (0, 0, 4, 0), (0, 0, 8, 0)],
+    "tiled": [(0, 0, 0, 0)] + [(0, sk, mi, 0) for mi in (1, 2, 4, 8) for sk in (1, 2, 3, 4, 6, 8)],
 }
 
 
@@ -322,7 +321,7 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
     stored in GEMLITE_HIP_CONFIG_CACHE under the reference's key (`cold=True` rewrites a 512 MiB buffer before every timed
     launch so that the weights come from HBM, as they do inside a model, instead of the 256 MiB Infinity Cache); `GemLiteLinear.cache_config(path)` /
     `load_config(path)` persist and reload the table, and every later launch of that shape uses it.
-    Returns {M: {"tuning": [...], "us": best, "default_us": planner}}."""
+    Returns {M: {"tuning": [...], "us": best, "default_us": planner, "candidates": {tuning: us}}}."""
     from . import core as _core
     from ._hip import GemliteHipError
     from .bench_utils import kernel_device_us
@@ -339,7 +338,7 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
             from .quant_utils import scale_activations_per_token
             x, scales_x = scale_activations_per_token(x, w_dtype=_core.DTYPE_TO_TORCH[layer.input_dtype.value])
         fam = "gemv" if M == 1 else ("few_rows" if M <= 32 else "tiled")
-        best, default_us = None, None
+        best, default_us, timed = None, None, {}
         for cand in (candidates or _TUNING_CANDIDATES[fam]):
             try:  # device time of the kernel itself (per-launch HIP events), not host-bound wall time
                 us = kernel_device_us(lambda: _core._hip_matmul(x, layer.W_q, layer.scales, layer.zeros, scales_x, meta,
@@ -349,6 +348,7 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
                 continue  # this candidate does not apply to the shape
             if us != us:
                 continue
+            timed[str(tuple(cand))] = round(us, 3)
             if cand == (0, 0, 0, 0):
                 default_us = us
             if verbose:
@@ -362,5 +362,5 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
         family = _core.config_family(-1, M, layer.W_nbits)
         entry = {"tuning": list(best[0]), "us": round(best[1], 3)}
         _core.GEMLITE_HIP_CONFIG_CACHE.setdefault(family, {})[key] = entry
-        out[M] = dict(entry, default_us=None if default_us is None else round(default_us, 3))
+        out[M] = dict(entry, default_us=None if default_us is None else round(default_us, 3), candidates=timed)
     return out

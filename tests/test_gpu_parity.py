@@ -757,3 +757,39 @@ def test_fused_activation_quant_at_m1_is_bit_identical_to_the_two_launch_path(ki
     xq, sx = O.scale_activations_per_token(x, O.INT8 if kind == "int8" else O.FP8E4)
     y_or = (xq @ O.to_f64(lin.W_q.data)) * (sx.astype(np.float64) * O.to_f64(lin.scales.data).reshape(1, -1))
     _compare(f"fused-quant/{kind}", lin(x), y_or, 1, abs_gate=5e-3)
+
+
+def test_shipped_tuning_table_autoloads_by_device_and_its_entries_stay_correct():
+    """gemlite_amd/configs/mi355x.json is found from the device (name or ISA), loaded once on the first launch like the
+    reference's configs/<gpu>.json (core.py:634-654), and launches that hit an entry still match the oracle."""
+    import ast, json
+    from gemlite_amd import core
+    path = core.get_default_cache_config(0)
+    assert path is not None and path.endswith("mi355x.json")
+    table = json.load(open(path))
+    saved = {k: dict(v) for k, v in core.GEMLITE_HIP_CONFIG_CACHE.items()}
+    try:
+        core.GemLiteLinear.reset_config()
+        core._AUTOLOAD_DONE = False
+        assert core.autoload_default_config(0) == path
+        assert all(k in core.GEMLITE_HIP_CONFIG_CACHE.get(f, {}) for f, e in table.items() for k in e)
+        done = 0
+        for fam, entries in table.items():
+            for key, e in list(entries.items())[:3]:
+                Mb, N, K, gs, eps, tid = ast.literal_eval(key)
+                if N * K > 5120 * 13824:
+                    continue  # oracle time
+                lin = _make_layer(N, K, 4, gs, torch.float16, seed=70 + done)
+                x = torch.from_numpy(O.gen_x(Mb, K, seed=Mb)).to(DEV)
+                a = core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
+                assert core.lookup_tuning(-1, Mb, a) == tuple(e["tuning"])
+                y = lin(x)
+                torch.cuda.synchronize()
+                cols = slice(0, 256)
+                _compare(f"table/{fam}/{key}", y[:, cols], torch.from_numpy(_oracle_columns(lin, x, cols)), 1,
+                         extra=dict(tuning=e["tuning"]))
+                done += 1
+        assert done >= 3
+    finally:
+        core.GemLiteLinear.reset_config()
+        core.GEMLITE_HIP_CONFIG_CACHE.update(saved)

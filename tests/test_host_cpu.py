@@ -86,12 +86,15 @@ def test_struct_abi_and_validation():
     (dict(M=4), "gemm_wn_direct_kernel<tile16>"),
     (dict(M=8), "gemm_wn_direct_kernel<tile32>"),     # >= 8 rows: 32-column tiles x split-K 2 (less x traffic)
     (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile32>"),
-    (dict(M=24, N=16384, K=16384), "gemm_wn_direct_kernel<tile64>"),
+    (dict(M=16, N=16384, K=16384), "gemm_wn_direct_kernel<tile64>"),
+    (dict(M=24, N=16384, K=16384), "gemm_w4_mma_kernel<32x128>"),   # 17..32 rows over K >= 8192: LDS-staged x wins
     (dict(M=8, tuning=(0, 0, 1, 0)), "gemm_wn_stream_kernel"),  # tuning[2] = 1: LDS-staged streaming kernel
     (dict(M=4, gs=64), "gemm_wn_direct_kernel<tile16>"),   # group size 64: registers-only kernel up to 16 rows
     (dict(M=24, gs=64), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32
     (dict(M=4, gs=32), "gemm_wn_stream_kernel"),
-    (dict(M=48), "gemm_w4_mma_kernel<64x128>"),       # from 33 rows: the 8-wave MFMA kernel, tile rows follow M
+    (dict(M=48), "gemm_w4_mma_kernel<32x128>"),       # from 33 rows: the 8-wave MFMA kernel; 4096^2: 32-row tiles x 4 slices (15.8 us vs 16.4)
+    (dict(M=48, N=11008, K=4096), "gemm_w4_mma_kernel<64x128>"),
+    (dict(M=8, N=11008, K=4096), "gemm_wn_direct_kernel<tile64>"),   # wide N: 64-column tiles, K not split
     (dict(M=48, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK at 33..64 rows: LDS-staged streaming kernel
     (dict(M=48, nbits=2), "gemm_w2_mma_kernel<64x128>"),   # every bit width has the tiled MFMA kernel
     (dict(M=48, nbits=1), "gemm_w1_mma_kernel<64x128>"),
@@ -107,7 +110,7 @@ def test_struct_abi_and_validation():
     (dict(M=32, N=4096, K=11008, gs=64), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=16, N=1536, K=8960), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=64, N=4096, K=11008), "gemm_w4_mma_kernel<64x128>"),
-    (dict(M=256, N=4096, K=11008), "gemm_w4_mma_kernel<64x128>"),
+    (dict(M=256, N=4096, K=11008), "gemm_w4_mma_kernel<128x128>"),   # block-time model: 128 rows x 4 slices (40.5 vs 42.3 us for 64 x 2)
     (dict(M=1, nbits=2), "gemv_wn_kernel<tile16>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64,8w>"),   # 2-bit, long K: two waves per SIMD
@@ -290,6 +293,34 @@ def test_tuning_table_lookup_and_json_round_trip(tmp_path):
     assert core.GemLiteLinear.load_config(path) is not False
     assert core.lookup_tuning(-1, 1, a) == (2, 1, 8, 0)
     core.GemLiteLinear.reset_config()
+
+
+def test_shipped_mi355x_table_is_well_formed_and_every_entry_selects_a_specialised_kernel():
+    """gemlite_amd/configs/mi355x.json (measured on the MI355X by scripts/make_tuning_table.py, autoloaded by device name
+    like the reference's configs/*.json, core.py:634-654): reference-style keys, 4 small ints per entry, and the planner
+    accepts every entry at both ends of its M bucket (an entry it rejected would drop the shape to a slower family)."""
+    import ast, json, os
+    from gemlite_amd import core
+    path = os.path.join(os.path.dirname(core.__file__), "configs", "mi355x.json")
+    table = json.load(open(path))
+    assert table and set(table) <= set(core.GEMLITE_MATMUL_TYPES)
+    lib = _hip.load()
+    n = 0
+    for fam, entries in table.items():
+        for key, e in entries.items():
+            Mb, N, K, gs, eps, tid = ast.literal_eval(key)
+            assert core.get_closest_m(Mb) == Mb and eps == 8 and tid == 104 and gs == 128
+            t = e["tuning"]
+            assert len(t) == 4 and all(isinstance(v, int) and 0 <= v < 256 for v in t) and t[3] & ~0x3 == 0 and e["us"] > 0
+            lo = 1 if Mb == 1 else Mb // 2 + 1
+            for M in (lo, Mb):
+                assert core.config_family(-1, M, 4) == fam
+                a = _args(M=M, N=N, K=K, tuning=tuple(t))
+                assert lib.gemlite_hip_query(C.byref(a)) == 0
+                name = lib.gemlite_hip_kernel_name(C.byref(a)).decode()
+                assert name.startswith(("gemv_wn", "gemm_wn_direct", "gemm_wn_stream", "gemm_w4_mma", "gemm_w4_tiled")), (key, t, M, name)
+            n += 1
+    assert n >= 10
 
 
 def test_helper_processors_select_the_reference_modes():
