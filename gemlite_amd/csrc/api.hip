@@ -124,7 +124,8 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
     const int eff_group = per_group_meta ? a.group_size : (int)a.K;
 
     // ---- specialised packed-weight kernels ---------------------------------------------------------
-    if (packed && a.w_pack_bits == 32 && x16 && a.stride_wn == 1 && a.stride_xk == 1 && a.stride_on == 1 &&
+    const bool x8 = a.input_dtype == GEMLITE_DT_FP8E4 || a.input_dtype == GEMLITE_DT_INT8;  // A8Wn dynamic / BitNet int8
+    if (packed && a.w_pack_bits == 32 && (x16 || x8) && a.stride_wn == 1 && a.stride_xk == 1 && a.stride_on == 1 &&
         (a.stride_meta_n == 1 || !per_group_meta) && (a.K % eff_group == 0)) {
         WnParams p{};
         p.x = a.x; p.w = (const uint32_t*)a.w_q; p.scales = a.scales; p.zeros = a.zeros;
@@ -168,6 +169,9 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         if (want_gemv && mt == GEMLITE_MATMUL_AUTO && plan_gemm_wn_stream(a, p, lp)) {
             r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return;
         }
+        // what none of the above takes at M = 1 — 8-bit activations x packed weights (A8Wn dynamic, BitNet int8), an output
+        // or channel-scale type that differs from the activations' — still has the 8-wave MFMA kernel (32-row tiles)
+        if (want_gemv && plan_gemm_wn_mma(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
     }
 
 coverage:

@@ -21,7 +21,6 @@
 namespace gl {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int a8_slot(int r, int s) { return r * 128 + ((s ^ ((r >> 1) & 7)) << 4); }
 
@@ -182,37 +181,6 @@ __global__ __launch_bounds__(256, 2) void gemm_a8w8_kernel(const GenericParams p
 // v_mfma_i32_32x32x32_i8 — go HBM -> registers with one 16-byte load per lane and 32-k slice, two steps ahead, and feed
 // MI MFMAs each; nothing is dequantised.  Requests come from inline asm with counted waits (gl_async.h); K may be split
 // over gridDim.y (raw int32 / fp32 accumulator words travel through the slabs, so int8 stays exact).
-// ---------------------------------------------------------------------------------------------------------------
-// 4 consecutive outputs of one row from fp32 values: channel scaling (scales of fp32 / fp16 / bf16: one uniform
-// three-way branch, vector loads), cast, one vector store
-__device__ __forceinline__ void store_out4_any(const Epilogue& e, f32x4 v, int64_t m, int64_t n0) {
-    // same operation order as epilogue_scale(): mode 3 multiplies by the PRODUCT s_x[m] * s_w[n] (bit-identical outputs)
-    f32x4 sw = {1.f, 1.f, 1.f, 1.f};
-    if (e.c_mode == 1 || e.c_mode == 3) {
-        if (e.meta_dt == GEMLITE_DT_FP32) sw = *(const f32x4*)((const float*)e.scales_w + n0);
-        else if (e.meta_dt == GEMLITE_DT_FP16) sw = load4_t<half_tag>(e.scales_w, n0);
-        else sw = load4_t<bf16_tag>(e.scales_w, n0);
-    }
-    if (e.c_mode == 2 || e.c_mode == 3) {
-        const float sx = e.scales_x[m * e.stride_sx_m];
-        sw = e.c_mode == 3 ? (f32x4){sx * sw[0], sx * sw[1], sx * sw[2], sx * sw[3]} : (f32x4){sx, sx, sx, sx};
-    }
-    if (e.c_mode != 0) v *= sw;
-    if (e.out_dt == GEMLITE_DT_FP32) {
-        *(f32x4*)((float*)e.out + m * e.stride_om + n0) = v;
-        return;
-    }
-    u32x2 o;
-    if (e.out_dt == GEMLITE_DT_FP16) {
-        o[0] = (uint32_t)F16Traits<half_tag>::from_float(v[0]) | ((uint32_t)F16Traits<half_tag>::from_float(v[1]) << 16);
-        o[1] = (uint32_t)F16Traits<half_tag>::from_float(v[2]) | ((uint32_t)F16Traits<half_tag>::from_float(v[3]) << 16);
-    } else {
-        o[0] = (uint32_t)F16Traits<bf16_tag>::from_float(v[0]) | ((uint32_t)F16Traits<bf16_tag>::from_float(v[1]) << 16);
-        o[1] = (uint32_t)F16Traits<bf16_tag>::from_float(v[2]) | ((uint32_t)F16Traits<bf16_tag>::from_float(v[3]) << 16);
-    }
-    *(u32x2*)((uint16_t*)e.out + m * e.stride_om + n0) = o;
-}
-
 template <int DT, int MI, int RD, int NST>
 __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericParams p) {
     using namespace async;

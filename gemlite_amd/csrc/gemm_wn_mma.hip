@@ -46,6 +46,37 @@ __device__ __forceinline__ f32x16 mfma32<bf16_tag>(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
 }
 
+// ---- activation element type of the MFMA --------------------------------------------------------------------------------
+// XDT = 0: x holds the 16-bit floats of Tag.  XDT = GEMLITE_DT_FP8E4 / GEMLITE_DT_INT8: 8-bit activations (the reference's
+// A8Wn dynamic and BitNet-int8 processors, helper.py:502-615, 1006-1062): the dequantised weight is cast to the activation
+// type, like the reference's `b.to(a.dtype)` before tl.dot (gemm_kernels.py:384), and the product runs on the fp8 / int8
+// MFMA of the same 32x32x16 shape — a lane's fragment is still 8 consecutive k, now 8 bytes instead of 16.
+template <typename Tag, int XDT>
+struct XOps {
+    static constexpr int ES = 2;
+    typedef u32x4 frag_t;
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ f32x16 mfma(frag_t a, frag_t b, f32x16 c) { return mfma32<Tag>(a, b, c); }
+};
+template <typename Tag>
+struct XOps<Tag, GEMLITE_DT_FP8E4> {
+    static constexpr int ES = 1;
+    typedef u32x2 frag_t;
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ f32x16 mfma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
+    }
+};
+template <typename Tag>
+struct XOps<Tag, GEMLITE_DT_INT8> {  // int32 accumulation (converted to fp32 once, after the K loop)
+    static constexpr int ES = 1;
+    typedef u32x2 frag_t;
+    typedef i32x16 acc_t;
+    static __device__ __forceinline__ i32x16 mfma(frag_t a, frag_t b, i32x16 c) {
+        return __builtin_amdgcn_mfma_i32_32x32x16_i8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
+    }
+};
+
 // ---- geometry of one 64-k sub-block by bit width ------------------------------------------------------------------
 // WPL words per lane, packed row of word i for lane half h: rb + RI(i) + HS * h, k offset (inside the sub-block) of
 // MFMA slice u for lane half h: KO(u, h).
@@ -140,6 +171,44 @@ struct Convert<half_tag> {
     }
 };
 
+// ---- codes -> one B fragment in the activation type ----------------------------------------------------------------------
+template <typename Tag, int XDT>
+struct ConvertX {  // 16-bit activations: the converters above, pair j -> register j
+    Convert<Tag> c;
+    __device__ __forceinline__ void set(float s, float z, float u13, float u4) { c.set(s, z, u13, u4); }
+    __device__ __forceinline__ void prep(uint32_t&, uint32_t&) const {}
+    __device__ __forceinline__ void put(u32x4& out, uint32_t ev, uint32_t od, int j) const { out[j] = c.pair(ev, od, j); }
+};
+template <typename Tag>
+struct ConvertX<Tag, GEMLITE_DT_FP8E4> {  // fp32 fma, one rounding to e4m3 (v_cvt_pk_fp8_f32): pair j -> half j & 1 of register j >> 1
+    float A, B;
+    __device__ __forceinline__ void set(float s, float z, float u13, float u4) {
+        A = s;
+        B = z * __builtin_fmaf(-u13, s, u4);
+    }
+    __device__ __forceinline__ void prep(uint32_t&, uint32_t&) const {}
+    __device__ __forceinline__ void put(u32x2& out, uint32_t ev, uint32_t od, int j) const {
+        const float lo = (float)((ev >> (8 * j)) & 0xFFu), hi = (float)((od >> (8 * j)) & 0xFFu);
+        const uint32_t prev = out[j >> 1];
+        const float a = __builtin_fmaf(lo, A, B), b = __builtin_fmaf(hi, A, B);
+        out[j >> 1] = (j & 1) ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)prev, true)
+                              : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)prev, false);
+    }
+};
+template <typename Tag>
+struct ConvertX<Tag, GEMLITE_DT_INT8> {  // integer codes minus an integer zero (W_group_mode 0 / 1 with a scalar zero): exact int8
+    uint32_t zz;  // the zero in every byte
+    __device__ __forceinline__ void set(float, float z, float u13, float) { zz = 0x01010101u * ((uint32_t)(int)(z * u13) & 0xFFu); }
+    // bytewise q - z without borrows between bytes: ((q | 0x80) - z) ^ 0x80  (q <= 127 + z, z <= 127)
+    __device__ __forceinline__ void prep(uint32_t& ev, uint32_t& od) const {
+        ev = ((ev | 0x80808080u) - zz) ^ 0x80808080u;
+        od = ((od | 0x80808080u) - zz) ^ 0x80808080u;
+    }
+    __device__ __forceinline__ void put(u32x2& out, uint32_t ev, uint32_t od, int j) const {
+        if (j & 1) out[j >> 1] = __builtin_amdgcn_perm(od, ev, j == 1 ? 0x05010400u : 0x07030602u);  // {ev[2r], od[2r], ev[2r+1], od[2r+1]}
+    }
+};
+
 // (in a __device__ function: a "v" constraint inside a lambda of the kernel body silently drops the kernel's host stub)
 __device__ __forceinline__ void opaque2(uint32_t& a, uint32_t& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 
@@ -154,13 +223,17 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 // MI 32-row blocks per wave (tile rows = 32 * MI), KSTEP k per step (each wave: KSTEP / 2).
 // EXP (development builds only, -DGL_MMA_EXPERIMENTS + tuning[3] >> 8): drop parts of the K loop to see what each costs —
 // 1 barrier + counted wait, 2 dequant VALU, 4 A-fragment reads, 8 x DMA requests, 16 weight requests.  Results are wrong.
-template <typename Tag, int NBITS, int MI, int KSTEP, int RD, int NST, int EXP = 0>
+template <typename Tag, int NBITS, int MI, int KSTEP, int RD, int NST, int EXP = 0, int XDT = 0>
 __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     using namespace mma;
-    using TR = F16Traits<Tag>;
+    using TR = F16Traits<Tag>;  // output / metadata type; also the activation type when XDT == 0
     using G = Geo<NBITS>;
+    using XO = XOps<Tag, XDT>;
+    typedef typename XO::frag_t frag_t;
+    constexpr int ES = XO::ES;  // bytes per activation
     constexpr int BM = 32 * MI, KW = KSTEP / 2, SUB = KW / 64, WPL = G::WPL;
-    constexpr int PITCH = KSTEP * 2, STAGE = BM * PITCH;  // bytes per row / per stage of x
+    constexpr int PITCH = KSTEP * ES, STAGE = BM * PITCH;  // bytes per row / per stage of x
+    constexpr int SWZ = (PITCH / 16 < 16 ? PITCH / 16 : 16) - 1;  // XOR swizzle of the 16-byte slots inside a row (8 or 16 slots)
     constexpr int PIECES = STAGE / 1024 / 8;               // 1-KiB LDS-DMA pieces per wave and stage
     constexpr int NS = SUB * 4;                            // MFMA slices (k16) per wave and step
     constexpr int NQ = NS * MI;                            // MFMA slots per wave and step
@@ -220,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     const int meta_rows = p.gs_shift >= 31 ? 1 : (p.K >> p.gs_shift);
     const int meta_bytes = ((meta_rows - 1) * ms + p.N) * 2;
     // buffer descriptors (rows >= M and absent metadata read zeros through the range check on the per-lane offset)
-    const srd_t rsX = make_srd(p.x, (uint32_t)(((int64_t)(p.M - 1) * p.stride_xm + p.K) * 2));
+    const srd_t rsX = make_srd(p.x, (uint32_t)(((int64_t)(p.M - 1) * p.stride_xm + p.K) * ES));
 
     // ---- B stream --------------------------------------------------------------------------------------------------
     struct BStep { uint32_t w[SUB][WPL]; uint32_t s[SUB], z[SUB]; };
@@ -251,18 +324,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     };
     // ---- A stream: LDS-DMA pieces.  Piece j of wave w covers LDS bytes [(w * PIECES + j) * 1024, +1024) of a stage;
     //      lane i's 16 bytes land at +16 i, i.e. row (byte / PITCH), physical slot (byte % PITCH) / 16, which holds the
-    //      logical slot  phys ^ (row & 15)  of that row.
+    //      logical slot  phys ^ (row & SWZ)  of that row.
     uint32_t xvoff[PIECES];
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
         const int byte = (wave * PIECES + j) * 1024 + lane * 16;
         const int r = byte / PITCH, phys = (byte % PITCH) / 16;
-        const int logical = phys ^ (r & 15);
-        xvoff[j] = m0 + r < p.M ? (uint32_t)(((int64_t)(m0 + r) * p.stride_xm + k_s0 + logical * 8) * 2) : 0x80000000u;
+        const int logical = phys ^ (r & SWZ);
+        xvoff[j] = m0 + r < p.M ? (uint32_t)(((int64_t)(m0 + r) * p.stride_xm + k_s0) * ES + logical * 16) : 0x80000000u;
     }
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PIECES) * 1024u);
     auto req_x = [&](int stage, int step, int j) {
-        req_lds16(rsX, lds0 + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP * 2));
+        req_lds16(rsX, lds0 + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP * ES));
     };
     // A fragment of slot q = (slice g, row block mi): row mi*32 + col, k = kh*KW + (g/4)*64 + k_of(g%4, h)
     int fbase[NST][NS];
@@ -270,25 +343,25 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     for (int st = 0; st < NST; ++st)
 #pragma unroll
         for (int g = 0; g < NS; ++g) {
-            const int k = kh * KW + (g >> 2) * 64 + G::k_of(g & 3, h);
-            const int slot = k >> 3;
-            fbase[st][g] = st * STAGE + col * PITCH + (((slot & ~15) | ((slot ^ col) & 15)) << 4);
+            const int kb = (kh * KW + (g >> 2) * 64 + G::k_of(g & 3, h)) * ES;  // byte offset inside the row
+            const int slot = kb >> 4;
+            fbase[st][g] = st * STAGE + col * PITCH + (((slot & ~SWZ) | ((slot ^ col) & SWZ)) << 4) + (kb & 15);
         }
-    auto read_frag = [&](int stage, int q) -> u32x4 {
-        return *(const u32x4*)(smem + fbase[stage][q / MI] + (q % MI) * 32 * PITCH);
+    auto read_frag = [&](int stage, int q) -> frag_t {
+        return *(const frag_t*)(smem + fbase[stage][q / MI] + (q % MI) * 32 * PITCH);
     };
 
-    f32x16 acc[MI];
+    typename XO::acc_t accm[MI];  // fp32, or int32 for int8 activations
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int e = 0; e < 16; ++e) accm[i][e] = 0;
 
-    Convert<Tag> cv;
+    ConvertX<Tag, XDT> cv;
     uint32_t ev = 0, od = 0;  // codes of the slice being dequantised
     // Dequantisation of one slice (-> 4 registers of a B fragment) is cut into pieces that hide behind the MI MFMAs of
     // the slice before it: piece 0 = (scale, zero) of the sub-block + code extraction, then the 4 pairs.
-    auto deq_piece = [&](const BStep& b, int g, int mi, u32x4& out) {
+    auto deq_piece = [&](const BStep& b, int g, int mi, frag_t& out) {
         const int sb = g >> 2, u = g & 3;
         if (mi == 0) {
             if (u == 0) {  // (scale, zero) of the sub-block; slices 1..3 reuse them
@@ -297,17 +370,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
                 cv.set(sc, zr, u13, u4);
             }
             Extract<NBITS>::run(b.w[sb], u, ev, od);
+            cv.prep(ev, od);
             // opaque to the optimiser: otherwise byte i becomes v_bfe_u32 + v_cvt_f32_ubyte0 instead of one v_cvt_f32_ubyte<i>
             opaque2(ev, od);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if ((MI == 8 ? j + 1 : (j * MI) / 4) == mi) out[j] = cv.pair(ev, od, j);
+            if ((MI == 8 ? j + 1 : (j * MI) / 4) == mi) cv.put(out, ev, od, j);
     };
 
     BStep ring[RD];
-    u32x4 af[L];
-    u32x4 bfrag[2];
+    frag_t af[L];
+    frag_t bfrag[2];
 
     // ---- prologue: x of step 0, weights of steps 0 .. PD-1 ------------------------------------------------------------
     // request order = the order things are needed: x and weights of step 0 first.  Only the x tile of step 0 is waited
@@ -362,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int g = q / MI, mi = q % MI;
-            acc[mi] = mfma32<Tag>(af[q % L], bfrag[g & 1], acc[mi]);
+            accm[mi] = XO::mfma(af[q % L], bfrag[g & 1], accm[mi]);
             if (q == NQI && !(EXP & 1)) {
                 // everything but the requests issued after the DMA of step + 1: (NST - 2) later DMAs, (NST - 1) weight sets
                 wait_vm<(NST - 2) * PIECES + (NST - 1) * NLB>();
@@ -386,31 +460,28 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    for (int s0 = 0; s0 < nsteps; s0 += RD) {  // unrolled by the ring depth: every ring / stage index is static
-        do_step(std::integral_constant<int, 0>{}, s0);
-        if (s0 == 0) stamp(2);
-        if (s0 + 1 >= nsteps) break;
-        do_step(std::integral_constant<int, 1>{}, s0 + 1);
-        if (s0 + 2 >= nsteps) break;
-        do_step(std::integral_constant<int, 2>{}, s0 + 2);
-        if (s0 + 3 >= nsteps) break;
-        do_step(std::integral_constant<int, 3>{}, s0 + 3);
-        if constexpr (RD > 4) {
-            if (s0 + 4 >= nsteps) break;
-            do_step(std::integral_constant<int, 4 % RD>{}, s0 + 4);
-            if (s0 + 5 >= nsteps) break;
-            do_step(std::integral_constant<int, 5 % RD>{}, s0 + 5);
+    // unrolled by the ring depth: every ring / stage index is static.  Nested ifs, not breaks: the loop has ONE exit, so the
+    // accumulators reach the epilogue through one set of registers (with a break per step the int32 accumulators of the
+    // int8 variant got a copy per exit edge and spilled)
+    auto chain = [&](auto self, auto Jc, int s0) -> void {
+        constexpr int J = decltype(Jc)::value;
+        do_step(std::integral_constant<int, J % RD>{}, s0 + J);
+        if constexpr (J == 0) {
+            if (s0 == 0) stamp(2);
         }
-        if constexpr (RD > 6) {
-            if (s0 + 6 >= nsteps) break;
-            do_step(std::integral_constant<int, 6 % RD>{}, s0 + 6);
-            if (s0 + 7 >= nsteps) break;
-            do_step(std::integral_constant<int, 7 % RD>{}, s0 + 7);
+        if constexpr (J + 1 < RD) {
+            if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
         }
-    }
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += RD) chain(chain, std::integral_constant<int, 0>{}, s0);
     // retire every outstanding request (the last step's run-ahead DMA) before the LDS is reused
     wait_vm<0>();
     stamp(3);
+    f32x16 acc[MI];  // int32 sums -> fp32 (exact below 2^24)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][e] = (float)accm[mi][e];
 
     // ---- epilogue 1: add the two K halves (waves 4..7 hand their accumulators to waves 0..3 through LDS) ------------
     __syncthreads();
@@ -507,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     // ---- epilogue 3: the complete tile is transposed through LDS, 128 rows per pass, so that the output moves as 16-byte
     //      row segments; C fragment of a 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     float* ct = (float*)smem;  // [PASS_ROWS][C_PITCH]
+    const bool typed_out = p.epi.out_dt == TR::DT && (p.epi.meta_dt == TR::DT || p.epi.c_mode == 0 || p.epi.c_mode == 2);
     constexpr int NPASS = BM / PASS_ROWS, MIP = PASS_ROWS / 32;
     constexpr int UNITS = (PASS_ROWS * BN / 4 + 511) / 512;  // float4 units per thread and pass
 #pragma unroll
@@ -529,7 +601,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         for (int i = 0; i < UNITS; ++i) {
             const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
             const int m = m0 + ps * PASS_ROWS + r;
-            if (r < PASS_ROWS && m < p.M) store_out4_t<Tag>(p.epi, *(const f32x4*)(ct + r * C_PITCH + c4), m, ncol0 + c4);
+            if (r < PASS_ROWS && m < p.M) {
+                const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
+                if (typed_out) store_out4_t<Tag>(p.epi, v, m, ncol0 + c4);
+                else store_out4_any(p.epi, v, m, ncol0 + c4);  // output / channel-scale dtype differs from Tag
+            }
         }
     }
     stamp(7);
@@ -539,25 +615,35 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
 // host-side planning.  tuning[1]: 0 auto | n force split-K n;  tuning[2]: 0 auto | 1/2/4/8 force MI (tile rows / 32)
 // ---------------------------------------------------------------------------------------------------------------
 typedef void (*mma_kernel_fn)(const WnParams);
-template <typename Tag, int NBITS>
+template <typename Tag, int NBITS, int XDT>
 static const void* mma_pick_mi(int mi) {
     mma_kernel_fn f = nullptr;  // typed pointer first: a direct cast of the specialisation to void* does not instantiate the host stub
     switch (mi) {
-        case 8: f = gemm_wn_mma_kernel<Tag, NBITS, 8, 128, 4, 2>; break;
-        case 4: f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128, 6, 3>; break;
-        case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256, 6, (NBITS == 8 ? 2 : 3)>; break;
-        case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256, (NBITS == 8 ? 6 : 8), (NBITS == 8 ? 2 : 4)>; break;
+        case 8: f = gemm_wn_mma_kernel<Tag, NBITS, 8, 128, 4, 2, 0, XDT>; break;
+        case 4: f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128, 6, 3, 0, XDT>; break;
+        case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256, 6, (NBITS == 8 ? 2 : 3), 0, XDT>; break;
+        case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256, (NBITS == 8 ? 6 : 8), (NBITS == 8 ? 2 : 4), 0, XDT>; break;
         default: break;
     }
     return (const void*)f;
 }
 template <typename Tag>
-static const void* mma_pick(int nbits, int mi) {
+static const void* mma_pick(int nbits, int mi, int xdt) {
+    if (xdt == GEMLITE_DT_FP8E4) {  // 8-bit activations: the bit widths the reference's A8Wn / BitNet processors produce
+        if (nbits == 4) return mma_pick_mi<Tag, 4, GEMLITE_DT_FP8E4>(mi);
+        if (nbits == 2) return mma_pick_mi<Tag, 2, GEMLITE_DT_FP8E4>(mi);
+        return nullptr;
+    }
+    if (xdt == GEMLITE_DT_INT8) {
+        if (nbits == 4) return mma_pick_mi<Tag, 4, GEMLITE_DT_INT8>(mi);
+        if (nbits == 2) return mma_pick_mi<Tag, 2, GEMLITE_DT_INT8>(mi);
+        return nullptr;
+    }
     switch (nbits) {
-        case 4: return mma_pick_mi<Tag, 4>(mi);
-        case 2: return mma_pick_mi<Tag, 2>(mi);
-        case 1: return mma_pick_mi<Tag, 1>(mi);
-        case 8: return mma_pick_mi<Tag, 8>(mi);
+        case 4: return mma_pick_mi<Tag, 4, 0>(mi);
+        case 2: return mma_pick_mi<Tag, 2, 0>(mi);
+        case 1: return mma_pick_mi<Tag, 1, 0>(mi);
+        case 8: return mma_pick_mi<Tag, 8, 0>(mi);
         default: return nullptr;
     }
 }
@@ -567,13 +653,26 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if (nbits != 4 && nbits != 2 && nbits != 1 && nbits != 8) return false;
     const int e = 32 / nbits;
     if (a.N % mma::BN != 0) return false;
-    if (a.output_dtype != a.input_dtype) return false;
-    const bool uses_s = a.W_group_mode >= 2 || a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    // Activation type: the 16-bit float of the kernel's Tag, or 8 bits (fp8 e4m3 / int8: A8Wn dynamic, BitNet int8) with a
+    // 16-bit output.  Tag = the type of the metadata read in the K loop = the output type (any of fp16 / bf16 / fp32 output
+    // and fp32 channel scales go through the untyped epilogue store).
+    const bool x16 = a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_BF16;
+    const int xdt = x16 ? 0 : a.input_dtype;
+    if (!x16 && a.input_dtype != GEMLITE_DT_FP8E4 && a.input_dtype != GEMLITE_DT_INT8) return false;
+    if (!x16 && a.output_dtype != GEMLITE_DT_FP16 && a.output_dtype != GEMLITE_DT_BF16) return false;
+    const int tag_dt = x16 ? a.input_dtype : a.output_dtype;
+    const bool loop_s = a.W_group_mode >= 2, post_s = a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
     const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
-    if (uses_s && a.meta_dtype != a.input_dtype) return false;
-    if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
+    if (loop_s && a.meta_dtype != tag_dt) return false;
+    if (post_s && !loop_s && a.meta_dtype != GEMLITE_DT_FP32 && a.meta_dtype != GEMLITE_DT_FP16 && a.meta_dtype != GEMLITE_DT_BF16) return false;
+    if (post_s && ((uintptr_t)a.scales % (a.meta_dtype == GEMLITE_DT_FP32 ? 16 : 8)) != 0) return false;  // vector loads of the channel scales
+    if (has_z && !a.zero_is_scalar && a.zeros_dtype != tag_dt) return false;
     if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
-    if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte LDS-DMA pieces
+    if (xdt == GEMLITE_DT_INT8 && (a.W_group_mode >= 2 || (has_z && !a.zero_is_scalar))) return false;  // integer codes only
+    const int es = x16 ? 2 : 1;
+    if ((a.stride_xm * es) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte LDS-DMA pieces
+    const int oal = a.output_dtype == GEMLITE_DT_FP32 ? 16 : 8;  // 4 outputs per store
+    if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
     if (p.group_size % 64 != 0) return false;  // one (scale, zero) pair per column and 64-k sub-block
     // Tile rows (32 MI) and K slices.  A dequantised fragment feeds MI MFMAs, so tall tiles need the least unpack arithmetic
     // per MFMA; short tiles and K slices fill the 256 CUs (one 8-wave block each) — but every K slice costs slab traffic
@@ -648,15 +747,15 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     const int units = rows / step_rows;
     if (splitk > units) return false;
     // buffer descriptors: 32-bit byte offsets
-    if ((int64_t)rows * a.stride_wk * 4 >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31)) return false;
+    if ((int64_t)rows * a.stride_wk * 4 >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * es >= (1ll << 31)) return false;
     if (((int64_t)(a.K / (p.group_size > 0 ? p.group_size : a.K)) * p.stride_meta_g + a.N) * 2 >= (1ll << 31)) return false;
     const int64_t tiles = (int64_t)(a.N / mma::BN) * ((a.M + bm - 1) / bm);
     if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
     if ((uint64_t)splitk * bm * mma::BN * 4 >= (1ull << 31)) return false;  // slab buffer descriptor range
-    const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
-    const void* fn = f16 ? mma_pick<half_tag>(nbits, mi) : mma_pick<bf16_tag>(nbits, mi);
+    const bool f16 = tag_dt == GEMLITE_DT_FP16;
+    const void* fn = f16 ? mma_pick<half_tag>(nbits, mi, xdt) : mma_pick<bf16_tag>(nbits, mi, xdt);
 #ifdef GL_MMA_EXPERIMENTS
-    if (!f16 && nbits == 4 && (mi == 4 || mi == 8)) {
+    if (!f16 && xdt == 0 && nbits == 4 && (mi == 4 || mi == 8)) {
         mma_kernel_fn f = nullptr;
 #define GL_EXP_CASE(E) case E: f = mi == 4 ? gemm_wn_mma_kernel<bf16_tag, 4, 4, 128, 6, 3, E> : gemm_wn_mma_kernel<bf16_tag, 4, 8, 128, 4, 2, E>; break;
         switch (a.tuning[3] >> 8) { GL_EXP_CASE(1) GL_EXP_CASE(2) GL_EXP_CASE(4) GL_EXP_CASE(8) GL_EXP_CASE(16) GL_EXP_CASE(3) GL_EXP_CASE(6) GL_EXP_CASE(7) GL_EXP_CASE(31) default: break; }
@@ -673,11 +772,15 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         {"gemm_w2_mma_kernel<32x128>", "gemm_w2_mma_kernel<64x128>", "gemm_w2_mma_kernel<128x128>", "gemm_w2_mma_kernel<256x128>"},
         {"gemm_w1_mma_kernel<32x128>", "gemm_w1_mma_kernel<64x128>", "gemm_w1_mma_kernel<128x128>", "gemm_w1_mma_kernel<256x128>"},
         {"gemm_w8_mma_kernel<32x128>", "gemm_w8_mma_kernel<64x128>", "gemm_w8_mma_kernel<128x128>", "gemm_w8_mma_kernel<256x128>"}};
-    lp.name = names[nbits == 4 ? 0 : (nbits == 2 ? 1 : (nbits == 1 ? 2 : 3))][mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))];
+    static const char* names8[2][4] = {
+        {"gemm_a8w4_mma_kernel<32x128>", "gemm_a8w4_mma_kernel<64x128>", "gemm_a8w4_mma_kernel<128x128>", "gemm_a8w4_mma_kernel<256x128>"},
+        {"gemm_a8w2_mma_kernel<32x128>", "gemm_a8w2_mma_kernel<64x128>", "gemm_a8w2_mma_kernel<128x128>", "gemm_a8w2_mma_kernel<256x128>"}};
+    const int mix = mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3));
+    lp.name = xdt ? names8[nbits == 4 ? 0 : 1][mix] : names[nbits == 4 ? 0 : (nbits == 2 ? 1 : (nbits == 1 ? 2 : 3))][mix];
     lp.grid = dim3((unsigned)tiles, splitk, 1);
     lp.block = dim3(512, 1, 1);
     const int nst = mi == 8 ? 2 : (mi == 4 ? 3 : (nbits == 8 ? 2 : (mi == 2 ? 3 : 4)));  // LDS stages of x (mma_pick_mi)
-    const size_t stages = (size_t)nst * bm * ks * 2;
+    const size_t stages = (size_t)nst * bm * ks * es;
     const size_t xch = (size_t)4 * mi * 4 * 64 * 16;  // K-half exchange: [cg][mi][e4][lane] float4
     const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * mma::C_PITCH * 4 + 16;
     lp.lds_bytes = stages > xch ? stages : xch;

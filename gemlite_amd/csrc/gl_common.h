@@ -22,6 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 struct half_tag {};
 struct bf16_tag {};
@@ -248,6 +249,37 @@ __device__ __forceinline__ void store_out4_t(const Epilogue& e, f32x4 v, int64_t
     o[1] = (uint32_t)TR::from_float(v[2]) | ((uint32_t)TR::from_float(v[3]) << 16);
     *(u32x2*)((uint16_t*)e.out + m * e.stride_om + n0) = o;
 }
+
+// 4 consecutive outputs of one row from fp32 values: channel scaling (scales of fp32 / fp16 / bf16: one uniform
+// three-way branch, vector loads), cast, one vector store
+__device__ __forceinline__ void store_out4_any(const Epilogue& e, f32x4 v, int64_t m, int64_t n0) {
+    // same operation order as epilogue_scale(): mode 3 multiplies by the PRODUCT s_x[m] * s_w[n] (bit-identical outputs)
+    f32x4 sw = {1.f, 1.f, 1.f, 1.f};
+    if (e.c_mode == 1 || e.c_mode == 3) {
+        if (e.meta_dt == GEMLITE_DT_FP32) sw = *(const f32x4*)((const float*)e.scales_w + n0);
+        else if (e.meta_dt == GEMLITE_DT_FP16) sw = load4_t<half_tag>(e.scales_w, n0);
+        else sw = load4_t<bf16_tag>(e.scales_w, n0);
+    }
+    if (e.c_mode == 2 || e.c_mode == 3) {
+        const float sx = e.scales_x[m * e.stride_sx_m];
+        sw = e.c_mode == 3 ? (f32x4){sx * sw[0], sx * sw[1], sx * sw[2], sx * sw[3]} : (f32x4){sx, sx, sx, sx};
+    }
+    if (e.c_mode != 0) v *= sw;
+    if (e.out_dt == GEMLITE_DT_FP32) {
+        *(f32x4*)((float*)e.out + m * e.stride_om + n0) = v;
+        return;
+    }
+    u32x2 o;
+    if (e.out_dt == GEMLITE_DT_FP16) {
+        o[0] = (uint32_t)F16Traits<half_tag>::from_float(v[0]) | ((uint32_t)F16Traits<half_tag>::from_float(v[1]) << 16);
+        o[1] = (uint32_t)F16Traits<half_tag>::from_float(v[2]) | ((uint32_t)F16Traits<half_tag>::from_float(v[3]) << 16);
+    } else {
+        o[0] = (uint32_t)F16Traits<bf16_tag>::from_float(v[0]) | ((uint32_t)F16Traits<bf16_tag>::from_float(v[1]) << 16);
+        o[1] = (uint32_t)F16Traits<bf16_tag>::from_float(v[2]) | ((uint32_t)F16Traits<bf16_tag>::from_float(v[3]) << 16);
+    }
+    *(u32x2*)((uint16_t*)e.out + m * e.stride_om + n0) = o;
+}
+
 
 // dequant of an integer code q (as float) for W_group_mode (triton_kernels/utils.py:73-87),
 // evaluated in fp32 on the stored scale / zero

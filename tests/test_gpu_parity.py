@@ -594,10 +594,13 @@ def test_remaining_helper_processors_against_the_oracle(M):
                                 if lin.zeros.numel() == 1 else O.to_f64(lin.zeros.data), W_nbits=lin.W_nbits, group_size=lin.group_size,
                                 W_group_mode=lin.W_group_mode, channel_scale_mode=lin.channel_scale_mode, scales_x=sx,
                                 zero_is_scalar=lin.zeros.numel() == 1, weight_cast_code=code if code == O.FP8E4 else None)
-        _compare(f"helpers/{name}/M{M}", y, y_or, 1, abs_gate=5e-3)
+        kname = _kernel_name(lin, x)
+        assert kname == ("gemm_a8w4_mma_kernel<32x128>" if code == O.FP8E4 else "gemm_a8w2_mma_kernel<32x128>"), kname
+        _compare(f"helpers/{name}/M{M}", y, y_or, 1, abs_gate=5e-3, extra=dict(kernel=kname))
     lin = H.A16W158_INT(device=DEV).from_weights(Wt, torch.tensor(0.02))
     y = lin(x)
     torch.cuda.synchronize()
+    assert _kernel_name(lin, x) == "gemm_w2_mma_kernel<32x128>", _kernel_name(lin, x)  # fp32 channel scale: untyped epilogue
     _compare(f"helpers/a16w158/M{M}", y, _oracle_from_layer(lin, x), 1, extra=dict(kernel=_kernel_name(lin, x)))
 
 
@@ -793,3 +796,67 @@ def test_shipped_tuning_table_autoloads_by_device_and_its_entries_stay_correct()
     finally:
         core.GemLiteLinear.reset_config()
         core.GEMLITE_HIP_CONFIG_CACHE.update(saved)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_a8wn_fp8_activations_on_the_mfma_kernel(nbits, tdt):
+    """A8Wn dynamic (helper.py:502-615): fp8 e4m3 activations (per-token scales) x packed 4- / 2-bit grouped weights.  The
+    dequantised weight is rounded to e4m3 before the dot like the reference's `b.to(a.dtype)` (gemm_kernels.py:384) and the
+    product runs on v_mfma_f32_32x32x16_fp8_fp8: every tile height, ragged M, uneven K slices, grouped (3, 2) and
+    channel-wise post-scale (1, 3) modes, against the float64 oracle on the same fp8-rounded operands."""
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    N, K = 256, 1280
+    out_code = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+    for gs, post in ((128, False), (K, True), (K, False)):
+        W_q, sc, zr = O.gen_data(N, K, nbits, gs, seed=80 + nbits)
+        lin = H.A8Wn_HQQ_INT_dynamic(device=DEV, dtype=tdt, post_scale=post, W_nbits=nbits).from_weights(
+            torch.from_numpy(W_q), torch.from_numpy(sc).to(tdt), torch.from_numpy(zr).to(tdt))
+        assert (lin.W_group_mode, lin.channel_scale_mode) == ((3, 2) if gs == 128 or not post else (1, 3))
+        for mi, M in ((1, 1), (1, 29), (2, 64), (4, 100), (8, 300)):
+            x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
+            xq_t, sx_t = scale_activations_per_token(x, w_dtype=torch.float8_e4m3fn)
+            xq, sx = O.scale_activations_per_token(x, O.FP8E4)
+            assert np.array_equal(xq_t.float().cpu().numpy().astype(np.float64), xq)  # activation quant is bit-exact
+            z = O.to_f64(lin.zeros.data)
+            y_or = O.forward_packed(xq, lin.W_q.data.cpu().numpy(), O.to_f64(lin.scales.data), z, W_nbits=nbits,
+                                    group_size=lin.group_size, W_group_mode=lin.W_group_mode,
+                                    channel_scale_mode=lin.channel_scale_mode, scales_x=sx, weight_cast_code=O.FP8E4)
+            for sk in (0, 3):
+                tuning = (0, sk, mi, 0)
+                y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1, tuning)
+                torch.cuda.synchronize()
+                # which kernel ran: ask with the same tuning
+                a = gemlite_amd.core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
+                a.matmul_type, a.M, a.x, a.out, a.scales_x = -1, M, 0x1000, 0x1000, 0x1000
+                a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = K, 1, N, 1
+                a.input_dtype = lin.input_dtype.value
+                for i in range(4):
+                    a.tuning[i] = tuning[i]
+                name = _hip.load().gemlite_hip_kernel_name(_hip.C.byref(a)).decode()
+                assert name == f"gemm_a8w{nbits}_mma_kernel<{32 * mi}x128>", name
+                _compare(f"a8wn/w{nbits}/{str(tdt)[6:]}/g{gs}/post{int(post)}/M{M}/sk{sk}", y, y_or, out_code, abs_gate=None,
+                         extra=dict(kernel=name))
+
+
+@pytest.mark.parametrize("M", [1, 7, 200])
+def test_bitnet_int8_activations_on_the_int8_mfma_are_exact(M):
+    """A8W158_INT_dynamic (helper.py:1006-1062): int8 activations x ternary 2-bit codes with a scalar zero of 1, fp32
+    per-tensor scale, modes (1, 3).  (q - 1) is exact int8, v_mfma_i32_32x32x16_i8 accumulates exact int32: the result must
+    equal fp16(int_dot * s_x * s_w) computed in fp32 — bit for bit."""
+    H = gemlite_amd.helper
+    N, K = 512, 2560
+    torch.manual_seed(M)
+    Wt = torch.randint(-1, 2, (N, K)).half()
+    lin = H.A8W158_INT_dynamic(device=DEV).from_weights(Wt, torch.tensor(0.02))
+    x = (torch.randn(M, K) / 10).half().to(DEV)
+    y = lin(x)
+    torch.cuda.synchronize()
+    assert _kernel_name(lin, x).startswith("gemm_a8w2_mma_kernel<"), _kernel_name(lin, x)
+    xq, sx = scale_activations_per_token(x, w_dtype=torch.int8)
+    dot = (xq.cpu().to(torch.int64) @ Wt.to(torch.int64).t())  # exact
+    assert int(dot.abs().max()) < (1 << 24)
+    sw = lin.scales.data.float().cpu().reshape(1, -1)
+    ref = (dot.float() * (sx.cpu().float() * sw)).half()  # the epilogue's operation order (epilogue_scale)
+    assert torch.equal(y.cpu(), ref)

@@ -44,6 +44,11 @@ def _args(M=1, N=4096, K=4096, nbits=4, gs=128, in_dt=1, w_mode=4, c_mode=0, e=N
     a.output_dtype = kw.get("out_dt", in_dt if in_dt in (0, 1, 2) else 1)
     if in_dt in (3, 4, 8):  # 8-bit activations: the per-channel weight scales are fp32 (helper.py:474-475)
         a.meta_dtype = kw.get("meta_dt", 0)
+    elif "meta_dt" in kw:
+        a.meta_dtype = kw["meta_dt"]
+    if "zeros_dt" in kw:
+        a.zeros_dtype = kw["zeros_dt"]
+    a.zero_is_scalar = int(kw.get("zero_scalar", 0))
     a.channel_scale_mode, a.W_group_mode = c_mode, w_mode
     a.stride_xm, a.stride_xk = K, 1
     a.stride_wk, a.stride_wn = (N, 1) if e > 1 else (1, K)
@@ -137,7 +142,19 @@ def test_struct_abi_and_validation():
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "kmajor_w8a16_kernel"),   # A16W8 int8, pre-scale
     (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "kmajor_w8a16_kernel"),  # fp8 W, bf16 x
     (dict(M=1, N=1000), "generic_matmul_kernel"),    # N not a multiple of 64
-    (dict(M=1, in_dt=4, w_mode=1, c_mode=1, out_dt=0), "generic_matmul_kernel"),  # int8 x W4
+    (dict(M=1, in_dt=4, w_mode=1, c_mode=1, out_dt=0), "generic_matmul_kernel"),  # int8 x W4 with tensor zeros, fp32 out
+    # 8-bit activations x packed weights (A8Wn fp8 dynamic, BitNet int8: helper.py:502-615, 1006-1062): fp8 / int8 MFMA
+    (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "gemm_a8w4_mma_kernel<32x128>"),
+    (dict(M=8, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "gemm_a8w4_mma_kernel<32x128>"),
+    (dict(M=512, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, N=8192, K=8192), "gemm_a8w4_mma_kernel<128x128>"),
+    (dict(M=16, nbits=2, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "gemm_a8w2_mma_kernel<32x128>"),
+    (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w4_mma_kernel<32x128>"),  # channel-wise, post-scale
+    (dict(M=1, nbits=2, in_dt=4, out_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w2_mma_kernel<32x128>"),  # BitNet int8, fp32 scale
+    (dict(M=300, nbits=2, in_dt=4, out_dt=2, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w2_mma_kernel<64x128>"),
+    (dict(M=1, in_dt=8, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "generic_matmul_kernel"),   # e5m2 activations: coverage kernel
+    # 16-bit activations whose output / channel-scale type differs (BitNet A16W158 with its fp32 scale; fp32 output)
+    (dict(M=1, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_w2_mma_kernel<32x128>"),
+    (dict(M=64, in_dt=1, out_dt=0), "gemm_w4_mma_kernel<32x128>"),
 ])
 def test_kernel_selection(kw, kernel):
     lib = _hip.load()
