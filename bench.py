@@ -60,7 +60,13 @@ WORKLOADS = {
     "a8w8_4096_m1": (4096, 4096, 8, 4096, 1, "int8", 16, "hbm"),
     "a8w8_4096_m16": (4096, 4096, 8, 4096, 16, "int8", 16, "hbm"),
     "a8w8_4096_m256": (4096, 4096, 8, 4096, 256, "int8", 16, "mfma"),
+    # A8Wn dynamic (helper.py:502-615): fp8 e4m3 activations (pre-quantised per token) x 4-bit g128 weights, fp16 out
+    "a8w4_4096_m1": (4096, 4096, 4, 128, 1, "fp8", 32, "hbm"),
+    "a8w4_4096_m16": (4096, 4096, 4, 128, 16, "fp8", 32, "hbm"),
+    "a8w4_4096_m256": (4096, 4096, 4, 128, 256, "fp8", 32, "mfma"),
+    "a8w4_8192_m256": (8192, 8192, 4, 128, 256, "fp8", 8, "mfma"),
 }
+PREQUANT = ("int8", "fp8")  # workloads whose x is quantised once, outside the timed matmul
 
 
 def algorithmic_bytes(M, N, K, nbits, group, esize=2):
@@ -73,6 +79,8 @@ def work_per_launch(name):
     nbytes = algorithmic_bytes(M, N, K, nbits, group)
     if dt == "int8":  # int8 W + fp32 channel scales + int8 x + fp32 token scales + fp16 out
         nbytes = K * N + N * 4 + M * K + M * 4 + M * N * 2
+    if dt == "fp8":  # packed W + fp16 group metadata + fp8 x + fp32 token scales + fp16 out
+        nbytes = K * N * nbits // 8 + 2 * (K // group) * N * 2 + M * K + M * 4 + M * N * 2
     return nbytes, 2 * M * N * K
 
 
@@ -90,6 +98,19 @@ def build_layers(name, device, layers=None):
         mods = [proc.from_weights((torch.randn(N, K, generator=g) / 30).half()) for _ in range(layers)]
         x = (torch.randn(M, K, generator=g) / 10).half().to(device)
         return mods, scale_activations_per_token(x, torch.int8)  # (x_q int8 [M, K], scales_x fp32 [M, 1])
+    if dt == "fp8":
+        from gemlite_amd.helper import A8Wn_HQQ_INT_dynamic
+        from gemlite_amd.quant_utils import scale_activations_per_token
+        g = torch.Generator(device=device).manual_seed(0)
+        proc = A8Wn_HQQ_INT_dynamic(device=device, dtype=torch.float16, W_nbits=nbits)
+        mods = []
+        for _ in range(layers):
+            W_q = torch.randint(0, 2 ** nbits, (N, K), generator=g, dtype=torch.int32, device=device).to(torch.uint8)
+            scales = (torch.rand(N * K // group, 1, generator=g, device=device) * 0.01 + 0.001).half()
+            zeros = (torch.rand(N * K // group, 1, generator=g, device=device) * (2 ** nbits - 1)).half()
+            mods.append(proc.from_weights(W_q, scales, zeros))
+        x = (torch.randn(M, K, generator=g, device=device) / 10).half()
+        return mods, scale_activations_per_token(x, torch.float8_e4m3fn)
     tdt = torch.float16 if dt == "fp16" else torch.bfloat16
     code = TORCH_TO_DTYPE[tdt]
     g = torch.Generator(device=device).manual_seed(0)  # seeded device RNG: the 16384^2 layers would take seconds on the host
@@ -129,7 +150,7 @@ class Runner:
                 self.step_eager()
 
     def call(self, lin):
-        if self.dt == "int8":  # the matmul alone: x was quantised once in build_layers
+        if self.dt in PREQUANT:  # the matmul alone: x was quantised once in build_layers
             from gemlite_amd.core import _hip_matmul
             return _hip_matmul(self.x[0], lin.W_q, lin.scales, lin.zeros, self.x[1], lin.get_meta_args(), -1)
         return lin.forward_manual(self.x, self.matmul_type) if self.matmul_type else lin(self.x)
@@ -161,6 +182,21 @@ class Runner:
         el = time.perf_counter() - t0
         return el / (steps * self.layers) * 1e6, steps, el
 
+    def eager_us_per_call(self, calls=2000):
+        """Host cost of the product path: wall time per eager `layer(x)` call (Python -> ctypes -> one C call -> launch),
+        back to back on the side stream with the GPU kept busy, so it is max(host time per call, device time per launch)."""
+        with torch.cuda.stream(self.stream):
+            for i in range(64):
+                self.call(self.mods[i % self.layers])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(calls):
+                self.call(self.mods[i % self.layers])
+            t_host = time.perf_counter() - t0  # all calls ISSUED
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+        return t_host / calls * 1e6, t_all / calls * 1e6
+
     def kernel_us(self, samples):
         """Mean device duration of ONE launch from HIP events attached to individual launches (eager, same rotation)."""
         from gemlite_amd.bench_utils import HipEvents
@@ -182,14 +218,14 @@ class Runner:
         from gemlite_amd.core import _static_args
         lin = self.mods[0]
         a = _static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
-        x = self.x[0] if self.dt == "int8" else self.x
+        x = self.x[0] if self.dt in PREQUANT else self.x
         a.matmul_type = -1
         a.x = a.out = 0x1000
         a.M = x.shape[0]
         from gemlite_amd.dtypes import TORCH_TO_DTYPE
         a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
         a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = x.stride(0), x.stride(1), a.N, 1
-        if self.dt == "int8":
+        if self.dt in PREQUANT:
             a.scales_x = 0x1000
         import gemlite_amd.core as core
         t = core.TUNING_OVERRIDE or core.lookup_tuning(-1, a.M, a)
@@ -209,13 +245,22 @@ class Runner:
         if self.bound == "hbm":
             peak, unit, work = HBM_PEAK_GBS, "GB/s", self.bytes / 1e9
         else:
-            peak, unit, work = (INT8_MFMA_PEAK_TOPS if self.dt == "int8" else MFMA_PEAK_TFLOPS), "TFLOP/s", self.flops / 1e12
+            peak, unit, work = (INT8_MFMA_PEAK_TOPS if self.dt in PREQUANT else MFMA_PEAK_TFLOPS), "TFLOP/s", self.flops / 1e12
         ach = work / (t * 1e-6)
         out.update({"achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "algorithmic_bytes_per_launch": self.bytes, "flops_per_launch": self.flops})
         if chained:
             out["gap_inclusive"] = round(work / (out["us_per_launch_chained"] * 1e-6), 3)
         return out
+
+
+def _traffic(name):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), or None."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(tpath)).get(name)
+    except Exception:
+        return None
 
 
 def event_clock_floor_us(lib, stream, samples=64):
@@ -281,7 +326,7 @@ def main():
         print(f"[bench] per-kernel event timing unavailable: {e}", file=sys.stderr)
     work = main_run.bytes / 1e9 if bound == "hbm" else main_run.flops / 1e12
     unit = "GB/s" if bound == "hbm" else "TFLOP/s"
-    peak = HBM_PEAK_GBS if bound == "hbm" else (INT8_MFMA_PEAK_TOPS if dt == "int8" else MFMA_PEAK_TFLOPS)
+    peak = HBM_PEAK_GBS if bound == "hbm" else (INT8_MFMA_PEAK_TOPS if dt in PREQUANT else MFMA_PEAK_TFLOPS)
     value = whole_job_rate(layers * work, args.steps, world, elapsed)
     if roof.get("kernel_us") is None:  # fall back to the gap-inclusive figure
         roof.update({"bound": bound, "achieved": round(work / (gap_us * 1e-6), 3), "peak": peak, "unit": unit,
@@ -290,14 +335,7 @@ def main():
     roof["us_per_launch_in_timed_region"] = round(gap_us, 3)
     if bound == "hbm":
         roof["frac_vs_measured_copy_6290"] = round(roof["achieved"] / 6290.0, 4)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(name)
-        except Exception:
-            traffic = None
-    roof["traffic"] = traffic
+    roof["traffic"] = _traffic(name)
     roof.pop("workload", None)
 
     metric = ("HBM GB/s (algorithmic bytes) vs roofline at M=1 [value], TFLOP/s vs bf16 MFMA roofline at M=256 [roofline_m256]; "
@@ -306,7 +344,7 @@ def main():
         "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dt, "data": "synthetic (seeded random W_q/scales/zeros/x, random-init)",
-        "config": {"workload": f"A{8 if dt == 'int8' else 16}W{nbits} gs={group} {N}x{K} M={M} {dt}; step = {layers} distinct layers "
+        "config": {"workload": f"A{8 if dt in PREQUANT else 16}W{nbits} gs={group} {N}x{K} M={M} {dt}; step = {layers} distinct layers "
                                f"(cache-cold rotation), {'hipGraph replay' if main_run.graph is not None else 'eager'}",
                    "layers_per_step": layers, "launches_per_step": layers, "replicas": world,
                    **({"tuning": args.tuning} if args.tuning else {}),
@@ -317,6 +355,9 @@ def main():
     extras = name == "a16w4_4096_m1" and not args.single and not args.tuning and not args.matmul_type
     if extras:
         try:
+            h_us, e_us = main_run.eager_us_per_call()
+            line["eager"] = {"host_us_per_call": round(h_us, 3), "us_per_call_incl_device": round(e_us, 3), "calls": 2000,
+                             "what": "layer(x) eager, no graph: Python + ctypes + gemlite_hip_forward per call"}
             # >= 1 s of back-to-back replays of the headline step
             us, steps, el = main_run.chained_us_per_launch(min_seconds=1.2, min_steps=50)
             line["sustained"] = {"seconds": round(el, 3), "replays": steps, "value": round(main_run.bytes / 1e9 / (us * 1e-6), 3),
@@ -326,6 +367,7 @@ def main():
             for key, wname, nl in (("cfgA_4096", "a16w4_4096_m256", 32), ("cfgB_8192", "a16w4_8192_m256", 8)):
                 r = Runner(wname, device, lib, layers=nl, use_graph=not args.no_graph)
                 m256[key] = r.roofline(min(args.kernel_samples, 128))
+                m256[key]["traffic"] = _traffic(wname)
                 del r
                 torch.cuda.empty_cache()
             line["roofline_m256"] = m256

@@ -223,7 +223,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 // MI 32-row blocks per wave (tile rows = 32 * MI), KSTEP k per step (each wave: KSTEP / 2).
 // EXP (development builds only, -DGL_MMA_EXPERIMENTS + tuning[3] >> 8): drop parts of the K loop to see what each costs —
 // 1 barrier + counted wait, 2 dequant VALU, 4 A-fragment reads, 8 x DMA requests, 16 weight requests.  Results are wrong.
-template <typename Tag, int NBITS, int MI, int KSTEP, int RD, int NST, int EXP = 0, int XDT = 0>
+template <typename Tag, int NBITS, int MI, int KSTEP, int RD, int NST, int EXP = 0, int XDT = 0, bool PP = false>
 __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     using namespace mma;
     using TR = F16Traits<Tag>;  // output / metadata type; also the activation type when XDT == 0
@@ -380,100 +380,189 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     };
 
     BStep ring[RD];
-    frag_t af[L];
-    frag_t bfrag[2];
-
-    // ---- prologue: x of step 0, weights of steps 0 .. PD-1 ------------------------------------------------------------
-    // request order = the order things are needed: x and weights of step 0 first.  Only the x tile of step 0 is waited
-    // for (counted: everything issued after it may still be in flight); the compiler waits for the weights of step 0 where
-    // they are first used.
+    if constexpr (PP) {
+        // ---- ping-pong schedule -----------------------------------------------------------------------------------------
+        // The two waves of a SIMD (kh = 0 / 1: same columns, the two K halves) never run the same kind of work at the same
+        // time: while one is in its M segment (the step's NQ MFMAs + the fragment reads, nothing else), the other is in its V
+        // segment (the NEXT step's requests, the dequantisation of all its fragments, the first fragment reads).  Measured
+        // (scripts/ubench/mfma_pair.hip): beside a saturated matrix pipe the MFMA-issuing wave gets ~4 other instructions
+        // per MFMA for free and pays ~7 cycles for every further one, while its SIMD PARTNER issues a plain VALU every 4.2
+        // cycles without slowing the pipe at all.  Phase p (s_barrier between phases; kh = 1 idles in phase 0):
+        //     kh = 0:  V(0) | M(0) | V(1) | M(1) | ...          kh = 1:  -  | V(0) | M(0) | V(1) | ...
+        // x stages: the tile of step t must be complete at the end of phase 2t - 1 (kh = 0 reads its first fragments at the
+        // end of V(t) = phase 2t) and is last read in phase 2t + 2 (M(t) of kh = 1).  kh = 0 fills step s + 1 during V(s)
+        // (phase 2s) and waits for it at the end of M(s); kh = 1 fills step s + 2 during V(s) (phase 2s + 1: the tile of step
+        // s - 1 it overwrites was last read in phase 2s) and waits for it at the end of V(s + 1): three stages.
+        static_assert(NST >= 3 && EXP == 0, "the ping-pong schedule needs three x stages");
+        frag_t af[L];
+        frag_t bf[NS];
+        uint32_t fill_off[NST];  // LDS offset of the stage filled during V(step), by step % NST
 #pragma unroll
-    for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
+        for (int j = 0; j < NST; ++j) fill_off[j] = (uint32_t)__builtin_amdgcn_readfirstlane(((j + 1 + kh) % NST) * STAGE);
+        // prologue: x of step 0 (kh = 1: and of step 1), weights of steps 0 .. PD-1; everything x is waited for here
 #pragma unroll
-    for (int it = 0; it < NLB; ++it) req_b(ring[0], 0, it);
+        for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
 #pragma unroll
-    for (int st = 1; st < NST - 1; ++st)
+        for (int it = 0; it < NLB; ++it) req_b(ring[0], 0, it);
+        if (kh == 1) {
 #pragma unroll
-        for (int j = 0; j < PIECES; ++j) req_x(st, st < nsteps ? st : nsteps - 1, j);
+            for (int j = 0; j < PIECES; ++j) req_x(1, nsteps > 1 ? 1 : 0, j);
+        }
 #pragma unroll
-    for (int r = 1; r < PD; ++r)
+        for (int r = 1; r < PD; ++r)
 #pragma unroll
-        for (int it = 0; it < NLB; ++it) req_b(ring[r], r < nsteps ? r : nsteps - 1, it);
-    {
-        constexpr int AFTER = (NST - 2) * PIECES + PD * NLB;  // requests issued after the x tile of step 0
-        wait_vm<(AFTER < 63 ? AFTER : 63)>();  // (the counter holds 63: with more issued behind it, the tile has landed anyway)
-    }
-    __builtin_amdgcn_s_barrier();
-    stamp(1);
+            for (int it = 0; it < NLB; ++it) req_b(ring[r], r < nsteps ? r : nsteps - 1, it);
+        wait_vm<((PD - 1) * NLB < 63 ? (PD - 1) * NLB : 63)>();
+        __builtin_amdgcn_s_barrier();
+        stamp(1);
+        if (kh == 1) __builtin_amdgcn_s_barrier();  // phase 0
+        auto seg_v = [&](auto Jc, int step) {
+            constexpr int J = decltype(Jc)::value;
+            const BStep& bc = ring[J];
+            BStep& bl = ring[(J + PD) % RD];
+            const int lstep = step + PD < nsteps ? step + PD : nsteps - 1;
+            const int xs = step + 1 + kh;
+            const int xstep = xs < nsteps ? xs : nsteps - 1;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) deq_piece(ring[0], 0, mi, bfrag[0]);
+            for (int j = 0; j < PIECES; ++j)
+                req_lds16(rsX, lds0 + fill_off[J % NST] + (uint32_t)(j * 1024), xvoff[j],
+                          (uint32_t)__builtin_amdgcn_readfirstlane(xstep * KSTEP * ES));
 #pragma unroll
-    for (int q = 0; q < L; ++q) af[q] = read_frag(0, q);
-    __builtin_amdgcn_sched_barrier(0);
-
-    // One K step; J = step & 3 selects the ring slot / stage statically.  The step is written as NQ MFMA "slots"; slot q
-    // issues MFMA q, one piece of the next slice's dequantisation, the A fragment needed L slots later and — in the first
-    // slots — the step's memory requests: x of step + 1 FIRST (LDS-DMA), then the weights of step + 2.  The order is
-    // pinned with sched_barrier (left alone, the machine scheduler pulls every ds_read back to just before its MFMA and
-    // groups the requests).  Waits are counted: at slot NQ - L "all but the NLB newest requests" = this step's DMA has
-    // landed (the weights just requested stay in flight for another step), then the block barrier: every wave's part of
-    // the next stage is in LDS and every wave has finished reading the current stage.
-    constexpr int NL = NLB + PIECES;
-    constexpr int NQI = NQ - L;                       // request slots
-    constexpr int RPS = (NL + NQI - 1) / NQI;         // requests per slot
-    static_assert((NST - 2) * PIECES + (NST - 1) * NLB + NL <= 63, "vmcnt is a 6-bit counter");
-    auto do_step = [&](auto Jc, int step) {
-        constexpr int J = decltype(Jc)::value;
-        constexpr int stage = J % NST, stage_next = (J + 1) % NST, stage_fill = (J + NST - 1) % NST;
-        const BStep& bc = ring[J];
-        const BStep& bn = ring[(J + 1) % RD];
-        BStep& bl = ring[(J + PD) % RD];
-        // Past the end of the slice the requests repeat the last step (never consumed): the SGPR offset of a buffer
-        // access is not range-checked, so "out of range reads zeros" cannot be relied on; and the last step re-requests
-        // its own x tile into the idle stage, which keeps the counted waits identical for every step.
-        const int lstep = step + PD < nsteps ? step + PD : nsteps - 1;
-        const int xstep = step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int g = q / MI, mi = q % MI;
-            accm[mi] = XO::mfma(af[q % L], bfrag[g & 1], accm[mi]);
-            if (q == NQI && !(EXP & 1)) {
-                // everything but the requests issued after the DMA of step + 1: (NST - 2) later DMAs, (NST - 1) weight sets
-                wait_vm<(NST - 2) * PIECES + (NST - 1) * NLB>();
-                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the current stage are complete
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-            if (!(EXP & 2)) {
-                if (g + 1 < NS) deq_piece(bc, g + 1, mi, bfrag[(g + 1) & 1]);
-                else deq_piece(bn, 0, mi, bfrag[(g + 1) & 1]);  // the next step's first slice
-            }
-            if (!(EXP & 4)) {
-                if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
-                else af[q % L] = read_frag(stage_next, q + L - NQ);
-            }
-#pragma unroll
-            for (int it = q * RPS; it < (q + 1) * RPS && it < NL; ++it) {
-                if (it < PIECES) { if (!(EXP & 8)) req_x(stage_fill, xstep, it); }
-                else if (!(EXP & 16)) req_b(bl, lstep, it - PIECES);
-            }
+            for (int it = 0; it < NLB; ++it) req_b(bl, lstep, it);
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NS; ++g)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) deq_piece(bc, g, mi, bf[g]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kh == 1) wait_vm<PIECES + 2 * NLB>();  // its pieces of step + 1 (requested one V segment ago) have landed
+#pragma unroll
+            for (int q = 0; q < L; ++q) af[q] = read_frag(J % NST, q);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto seg_m = [&](auto Jc) {
+            constexpr int J = decltype(Jc)::value;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                accm[q % MI] = XO::mfma(af[q % L], bf[q / MI], accm[q % MI]);
+                if (q + L < NQ) af[q % L] = read_frag(J % NST, q + L);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kh == 0) wait_vm<NLB>();  // its pieces of step + 1 (requested in this step's V segment) have landed
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        };
+        auto chain = [&](auto self, auto Jc, int s0) -> void {
+            constexpr int J = decltype(Jc)::value;
+            seg_v(std::integral_constant<int, J % RD>{}, s0 + J);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            seg_m(std::integral_constant<int, J % RD>{});
+            if (!(kh == 1 && s0 + J + 1 >= nsteps)) __builtin_amdgcn_s_barrier();  // (kh = 1 runs one phase behind)
+            asm volatile("" ::: "memory");
+            if constexpr (J == 0) {
+                if (s0 == 0) stamp(2);
+            }
+            if constexpr (J + 1 < RD) {
+                if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
+            }
+        };
+        for (int s0 = 0; s0 < nsteps; s0 += RD) chain(chain, std::integral_constant<int, 0>{}, s0);
+    } else {
+        frag_t af[L];
+        frag_t bfrag[2];
+
+        // ---- prologue: x of step 0, weights of steps 0 .. PD-1 ------------------------------------------------------------
+        // request order = the order things are needed: x and weights of step 0 first.  Only the x tile of step 0 is waited
+        // for (counted: everything issued after it may still be in flight); the compiler waits for the weights of step 0 where
+        // they are first used.
+    #pragma unroll
+        for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
+    #pragma unroll
+        for (int it = 0; it < NLB; ++it) req_b(ring[0], 0, it);
+    #pragma unroll
+        for (int st = 1; st < NST - 1; ++st)
+    #pragma unroll
+            for (int j = 0; j < PIECES; ++j) req_x(st, st < nsteps ? st : nsteps - 1, j);
+    #pragma unroll
+        for (int r = 1; r < PD; ++r)
+    #pragma unroll
+            for (int it = 0; it < NLB; ++it) req_b(ring[r], r < nsteps ? r : nsteps - 1, it);
+        {
+            constexpr int AFTER = (NST - 2) * PIECES + PD * NLB;  // requests issued after the x tile of step 0
+            wait_vm<(AFTER < 63 ? AFTER : 63)>();  // (the counter holds 63: with more issued behind it, the tile has landed anyway)
         }
-    };
-    // unrolled by the ring depth: every ring / stage index is static.  Nested ifs, not breaks: the loop has ONE exit, so the
-    // accumulators reach the epilogue through one set of registers (with a break per step the int32 accumulators of the
-    // int8 variant got a copy per exit edge and spilled)
-    auto chain = [&](auto self, auto Jc, int s0) -> void {
-        constexpr int J = decltype(Jc)::value;
-        do_step(std::integral_constant<int, J % RD>{}, s0 + J);
-        if constexpr (J == 0) {
-            if (s0 == 0) stamp(2);
-        }
-        if constexpr (J + 1 < RD) {
-            if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
-        }
-    };
-    for (int s0 = 0; s0 < nsteps; s0 += RD) chain(chain, std::integral_constant<int, 0>{}, s0);
+        __builtin_amdgcn_s_barrier();
+        stamp(1);
+    #pragma unroll
+        for (int mi = 0; mi < MI; ++mi) deq_piece(ring[0], 0, mi, bfrag[0]);
+    #pragma unroll
+        for (int q = 0; q < L; ++q) af[q] = read_frag(0, q);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // One K step; J = step & 3 selects the ring slot / stage statically.  The step is written as NQ MFMA "slots"; slot q
+        // issues MFMA q, one piece of the next slice's dequantisation, the A fragment needed L slots later and — in the first
+        // slots — the step's memory requests: x of step + 1 FIRST (LDS-DMA), then the weights of step + 2.  The order is
+        // pinned with sched_barrier (left alone, the machine scheduler pulls every ds_read back to just before its MFMA and
+        // groups the requests).  Waits are counted: at slot NQ - L "all but the NLB newest requests" = this step's DMA has
+        // landed (the weights just requested stay in flight for another step), then the block barrier: every wave's part of
+        // the next stage is in LDS and every wave has finished reading the current stage.
+        constexpr int NL = NLB + PIECES;
+        constexpr int NQI = NQ - L;                       // request slots
+        constexpr int RPS = (NL + NQI - 1) / NQI;         // requests per slot
+        static_assert((NST - 2) * PIECES + (NST - 1) * NLB + NL <= 63, "vmcnt is a 6-bit counter");
+        auto do_step = [&](auto Jc, int step) {
+            constexpr int J = decltype(Jc)::value;
+            constexpr int stage = J % NST, stage_next = (J + 1) % NST, stage_fill = (J + NST - 1) % NST;
+            const BStep& bc = ring[J];
+            const BStep& bn = ring[(J + 1) % RD];
+            BStep& bl = ring[(J + PD) % RD];
+            // Past the end of the slice the requests repeat the last step (never consumed): the SGPR offset of a buffer
+            // access is not range-checked, so "out of range reads zeros" cannot be relied on; and the last step re-requests
+            // its own x tile into the idle stage, which keeps the counted waits identical for every step.
+            const int lstep = step + PD < nsteps ? step + PD : nsteps - 1;
+            const int xstep = step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1;
+    #pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int g = q / MI, mi = q % MI;
+                accm[mi] = XO::mfma(af[q % L], bfrag[g & 1], accm[mi]);
+                if (q == NQI && !(EXP & 1)) {
+                    // everything but the requests issued after the DMA of step + 1: (NST - 2) later DMAs, (NST - 1) weight sets
+                    wait_vm<(NST - 2) * PIECES + (NST - 1) * NLB>();
+                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the current stage are complete
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                if (!(EXP & 2)) {
+                    if (g + 1 < NS) deq_piece(bc, g + 1, mi, bfrag[(g + 1) & 1]);
+                    else deq_piece(bn, 0, mi, bfrag[(g + 1) & 1]);  // the next step's first slice
+                }
+                if (!(EXP & 4)) {
+                    if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
+                    else af[q % L] = read_frag(stage_next, q + L - NQ);
+                }
+    #pragma unroll
+                for (int it = q * RPS; it < (q + 1) * RPS && it < NL; ++it) {
+                    if (it < PIECES) { if (!(EXP & 8)) req_x(stage_fill, xstep, it); }
+                    else if (!(EXP & 16)) req_b(bl, lstep, it - PIECES);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // unrolled by the ring depth: every ring / stage index is static.  Nested ifs, not breaks: the loop has ONE exit, so the
+        // accumulators reach the epilogue through one set of registers (with a break per step the int32 accumulators of the
+        // int8 variant got a copy per exit edge and spilled)
+        auto chain = [&](auto self, auto Jc, int s0) -> void {
+            constexpr int J = decltype(Jc)::value;
+            do_step(std::integral_constant<int, J % RD>{}, s0 + J);
+            if constexpr (J == 0) {
+                if (s0 == 0) stamp(2);
+            }
+            if constexpr (J + 1 < RD) {
+                if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
+            }
+        };
+        for (int s0 = 0; s0 < nsteps; s0 += RD) chain(chain, std::integral_constant<int, 0>{}, s0);
+    }
     // retire every outstanding request (the last step's run-ahead DMA) before the LDS is reused
     wait_vm<0>();
     stamp(3);
@@ -616,11 +705,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 typedef void (*mma_kernel_fn)(const WnParams);
 template <typename Tag, int NBITS, int XDT>
-static const void* mma_pick_mi(int mi) {
+static const void* mma_pick_mi(int mi, bool pingpong) {
     mma_kernel_fn f = nullptr;  // typed pointer first: a direct cast of the specialisation to void* does not instantiate the host stub
     switch (mi) {
         case 8: f = gemm_wn_mma_kernel<Tag, NBITS, 8, 128, 4, 2, 0, XDT>; break;
-        case 4: f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128, 6, 3, 0, XDT>; break;
+        case 4:
+            if (pingpong) f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128, 6, 3, 0, XDT, true>;
+            else f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128, 6, 3, 0, XDT>;
+            break;
         case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256, 6, (NBITS == 8 ? 2 : 3), 0, XDT>; break;
         case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256, (NBITS == 8 ? 6 : 8), (NBITS == 8 ? 2 : 4), 0, XDT>; break;
         default: break;
@@ -628,22 +720,22 @@ static const void* mma_pick_mi(int mi) {
     return (const void*)f;
 }
 template <typename Tag>
-static const void* mma_pick(int nbits, int mi, int xdt) {
+static const void* mma_pick(int nbits, int mi, int xdt, bool pp) {
     if (xdt == GEMLITE_DT_FP8E4) {  // 8-bit activations: the bit widths the reference's A8Wn / BitNet processors produce
-        if (nbits == 4) return mma_pick_mi<Tag, 4, GEMLITE_DT_FP8E4>(mi);
-        if (nbits == 2) return mma_pick_mi<Tag, 2, GEMLITE_DT_FP8E4>(mi);
+        if (nbits == 4) return mma_pick_mi<Tag, 4, GEMLITE_DT_FP8E4>(mi, pp);
+        if (nbits == 2) return mma_pick_mi<Tag, 2, GEMLITE_DT_FP8E4>(mi, pp);
         return nullptr;
     }
     if (xdt == GEMLITE_DT_INT8) {
-        if (nbits == 4) return mma_pick_mi<Tag, 4, GEMLITE_DT_INT8>(mi);
-        if (nbits == 2) return mma_pick_mi<Tag, 2, GEMLITE_DT_INT8>(mi);
+        if (nbits == 4) return mma_pick_mi<Tag, 4, GEMLITE_DT_INT8>(mi, pp);
+        if (nbits == 2) return mma_pick_mi<Tag, 2, GEMLITE_DT_INT8>(mi, pp);
         return nullptr;
     }
     switch (nbits) {
-        case 4: return mma_pick_mi<Tag, 4, 0>(mi);
-        case 2: return mma_pick_mi<Tag, 2, 0>(mi);
-        case 1: return mma_pick_mi<Tag, 1, 0>(mi);
-        case 8: return mma_pick_mi<Tag, 8, 0>(mi);
+        case 4: return mma_pick_mi<Tag, 4, 0>(mi, pp);
+        case 2: return mma_pick_mi<Tag, 2, 0>(mi, pp);
+        case 1: return mma_pick_mi<Tag, 1, 0>(mi, pp);
+        case 8: return mma_pick_mi<Tag, 8, 0>(mi, pp);
         default: return nullptr;
     }
 }
@@ -753,7 +845,8 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
     if ((uint64_t)splitk * bm * mma::BN * 4 >= (1ull << 31)) return false;  // slab buffer descriptor range
     const bool f16 = tag_dt == GEMLITE_DT_FP16;
-    const void* fn = f16 ? mma_pick<half_tag>(nbits, mi, xdt) : mma_pick<bf16_tag>(nbits, mi, xdt);
+    const bool pp = !(a.tuning[3] & 16);  // tuning[3] & 16: the interleaved schedule (A/B runs)
+    const void* fn = f16 ? mma_pick<half_tag>(nbits, mi, xdt, pp) : mma_pick<bf16_tag>(nbits, mi, xdt, pp);
 #ifdef GL_MMA_EXPERIMENTS
     if (!f16 && xdt == 0 && nbits == 4 && (mi == 4 || mi == 8)) {
         mma_kernel_fn f = nullptr;
