@@ -252,7 +252,19 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
             guard.__exit__(None, None, None)
     if rc != 0:
         _hip.raise_for_status(rc, "gemlite_hip_forward")
+    # a shape that only the coverage kernel takes is correct but orders of magnitude slower: say so, once per shape
+    wkey = (a.N, a.K, a.W_nbits, a.group_size, a.input_dtype, a.output_dtype, get_closest_m(M), matmul_type)
+    if wkey not in _COVERAGE_CHECKED:
+        _COVERAGE_CHECKED.add(wkey)
+        name = lib.gemlite_hip_kernel_name(_hip.C.byref(a))
+        if name and name.startswith(b"generic_matmul_kernel"):
+            logger.warning(f"gemlite_amd: no specialised MI355X kernel for N={a.N} K={a.K} W_nbits={a.W_nbits} "
+                           f"group_size={a.group_size} input_dtype={DType(a.input_dtype).name} M={M}: running on the coverage "
+                           "kernel (correct, slow).  Group sizes that are a power of two and N % 64 == 0 avoid it.")
     return out
+
+
+_COVERAGE_CHECKED = set()
 
 
 def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], meta_args: List[int],

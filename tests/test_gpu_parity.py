@@ -860,3 +860,23 @@ def test_bitnet_int8_activations_on_the_int8_mfma_are_exact(M):
     sw = lin.scales.data.float().cpu().reshape(1, -1)
     ref = (dot.float() * (sx.cpu().float() * sw)).half()  # the epilogue's operation order (epilogue_scale)
     assert torch.equal(y.cpu(), ref)
+
+
+def test_coverage_kernel_is_correct_and_announced_once(caplog):
+    """A shape no specialised kernel takes (N % 64 != 0) still runs — on the coverage kernel — and the host says so once
+    per shape ('orders of magnitude slower with no warning')."""
+    import logging
+    from gemlite_amd import core
+    N, K = 200, 512
+    lin = _make_layer(N, K, 4, 128, torch.float16, seed=90)
+    x = torch.from_numpy(O.gen_x(3, K, seed=3)).to(DEV)
+    assert _kernel_name(lin, x) == "generic_matmul_kernel"
+    core._COVERAGE_CHECKED.clear()
+    with caplog.at_level(logging.WARNING, logger=core.logger.name):
+        y = lin(x)
+        y2 = lin(x)
+    torch.cuda.synchronize()
+    hits = [r for r in caplog.records if "coverage kernel" in r.getMessage()]
+    assert len(hits) == 1 and "N=200" in hits[0].getMessage()
+    assert torch.equal(y, y2)
+    _compare("coverage/200x512/M3", y, _oracle_from_layer(lin, x), 1)
