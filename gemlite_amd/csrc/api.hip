@@ -16,6 +16,7 @@
 namespace gl {
 // planners (defined next to their kernels)
 bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
@@ -144,6 +145,11 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
                                 mt == GEMLITE_MATMUL_GEMV_SPLITK || (mt == GEMLITE_MATMUL_AUTO && a.M <= 1));
         LaunchPlan lp{};
         if (p.gs_shift < 0) goto coverage;  // group size not a power of two
+        // decode sizes of 8-bit activations x packed weights (A8Wn fp8 dynamic, BitNet int8): per-weight cast to the activation type
+        if (x8 && a.M <= 4 && (want_gemv || mt == GEMLITE_MATMUL_AUTO) && a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 &&
+            plan_gemv_a8wn(a, p, lp)) {
+            r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
+        }
         if (want_gemv && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }
         if (!want_gemv) {
             // Many rows: the 8-wave MFMA kernel (all bit widths) from 33 rows.  tuning[0]: 1 = LDS-staged streaming kernel,

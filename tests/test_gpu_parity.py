@@ -595,7 +595,9 @@ def test_remaining_helper_processors_against_the_oracle(M):
                                 W_group_mode=lin.W_group_mode, channel_scale_mode=lin.channel_scale_mode, scales_x=sx,
                                 zero_is_scalar=lin.zeros.numel() == 1, weight_cast_code=code if code == O.FP8E4 else None)
         kname = _kernel_name(lin, x)
-        assert kname == ("gemm_a8w4_mma_kernel<32x128>" if code == O.FP8E4 else "gemm_a8w2_mma_kernel<32x128>"), kname
+        want = {(O.FP8E4, 1): "gemv_a8w4_kernel<tile16,16w>", (O.FP8E4, 8): "gemm_a8w4_mma_kernel<32x128>",
+                (O.INT8, 1): "gemv_a8w2_kernel<tile16,16w>", (O.INT8, 8): "gemm_a8w2_mma_kernel<32x128>"}[(code, M)]
+        assert kname == want, kname
         _compare(f"helpers/{name}/M{M}", y, y_or, 1, abs_gate=5e-3, extra=dict(kernel=kname))
     lin = H.A16W158_INT(device=DEV).from_weights(Wt, torch.tensor(0.02))
     y = lin(x)
@@ -807,14 +809,14 @@ def test_a8wn_fp8_activations_on_the_mfma_kernel(nbits, tdt):
     channel-wise post-scale (1, 3) modes, against the float64 oracle on the same fp8-rounded operands."""
     from gemlite_amd.core import _hip_matmul
     H = gemlite_amd.helper
-    N, K = 256, 1280
+    N, K = 1024, 1280   # (N / 16 >= 64 blocks: the decode kernel applies)
     out_code = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
     for gs, post in ((128, False), (K, True), (K, False)):
         W_q, sc, zr = O.gen_data(N, K, nbits, gs, seed=80 + nbits)
         lin = H.A8Wn_HQQ_INT_dynamic(device=DEV, dtype=tdt, post_scale=post, W_nbits=nbits).from_weights(
             torch.from_numpy(W_q), torch.from_numpy(sc).to(tdt), torch.from_numpy(zr).to(tdt))
         assert (lin.W_group_mode, lin.channel_scale_mode) == ((3, 2) if gs == 128 or not post else (1, 3))
-        for mi, M in ((1, 1), (1, 29), (2, 64), (4, 100), (8, 300)):
+        for mi, M in ((1, 1), (1, 2), (1, 3), (1, 29), (2, 64), (4, 100), (8, 300)):
             x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
             xq_t, sx_t = scale_activations_per_token(x, w_dtype=torch.float8_e4m3fn)
             xq, sx = O.scale_activations_per_token(x, O.FP8E4)
@@ -823,6 +825,10 @@ def test_a8wn_fp8_activations_on_the_mfma_kernel(nbits, tdt):
             y_or = O.forward_packed(xq, lin.W_q.data.cpu().numpy(), O.to_f64(lin.scales.data), z, W_nbits=nbits,
                                     group_size=lin.group_size, W_group_mode=lin.W_group_mode,
                                     channel_scale_mode=lin.channel_scale_mode, scales_x=sx, weight_cast_code=O.FP8E4)
+            if M <= 4:  # decode sizes: the GEMV-class kernel (per-weight cast to e4m3, K not split across blocks)
+                y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1)
+                torch.cuda.synchronize()
+                _compare(f"a8wn/w{nbits}/{str(tdt)[6:]}/g{gs}/post{int(post)}/M{M}/gemv", y, y_or, out_code, abs_gate=None)
             for sk in (0, 3):
                 tuning = (0, sk, mi, 0)
                 y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1, tuning)
@@ -840,20 +846,20 @@ def test_a8wn_fp8_activations_on_the_mfma_kernel(nbits, tdt):
                          extra=dict(kernel=name))
 
 
-@pytest.mark.parametrize("M", [1, 7, 200])
+@pytest.mark.parametrize("M", [1, 2, 4, 7, 200])
 def test_bitnet_int8_activations_on_the_int8_mfma_are_exact(M):
     """A8W158_INT_dynamic (helper.py:1006-1062): int8 activations x ternary 2-bit codes with a scalar zero of 1, fp32
     per-tensor scale, modes (1, 3).  (q - 1) is exact int8, v_mfma_i32_32x32x16_i8 accumulates exact int32: the result must
     equal fp16(int_dot * s_x * s_w) computed in fp32 — bit for bit."""
     H = gemlite_amd.helper
-    N, K = 512, 2560
+    N, K = 1024, 2560
     torch.manual_seed(M)
     Wt = torch.randint(-1, 2, (N, K)).half()
     lin = H.A8W158_INT_dynamic(device=DEV).from_weights(Wt, torch.tensor(0.02))
     x = (torch.randn(M, K) / 10).half().to(DEV)
     y = lin(x)
     torch.cuda.synchronize()
-    assert _kernel_name(lin, x).startswith("gemm_a8w2_mma_kernel<"), _kernel_name(lin, x)
+    assert _kernel_name(lin, x).startswith("gemv_a8w2_kernel<" if M <= 4 else "gemm_a8w2_mma_kernel<"), _kernel_name(lin, x)
     xq, sx = scale_activations_per_token(x, w_dtype=torch.int8)
     dot = (xq.cpu().to(torch.int64) @ Wt.to(torch.int64).t())  # exact
     assert int(dot.abs().max()) < (1 << 24)

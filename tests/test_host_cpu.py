@@ -144,12 +144,16 @@ def test_struct_abi_and_validation():
     (dict(M=1, N=1000), "generic_matmul_kernel"),    # N not a multiple of 64
     (dict(M=1, in_dt=4, w_mode=1, c_mode=1, out_dt=0), "generic_matmul_kernel"),  # int8 x W4 with tensor zeros, fp32 out
     # 8-bit activations x packed weights (A8Wn fp8 dynamic, BitNet int8: helper.py:502-615, 1006-1062): fp8 / int8 MFMA
-    (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "gemm_a8w4_mma_kernel<32x128>"),
+    (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "gemv_a8w4_kernel<tile16,16w>"),   # decode: per-weight cast, no K split
+    (dict(M=4, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=3, c_mode=2), "gemv_a8w4_kernel<tile16,16w>"),
+    (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, tuning=(0, 0, 1, 0)), "gemm_a8w4_mma_kernel<32x128>"),
+    (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, mt=4), "gemm_a8w4_mma_kernel<32x128>"),  # manual GEMM
     (dict(M=8, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "gemm_a8w4_mma_kernel<32x128>"),
     (dict(M=512, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, N=8192, K=8192), "gemm_a8w4_mma_kernel<128x128>"),
     (dict(M=16, nbits=2, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "gemm_a8w2_mma_kernel<32x128>"),
-    (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w4_mma_kernel<32x128>"),  # channel-wise, post-scale
-    (dict(M=1, nbits=2, in_dt=4, out_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w2_mma_kernel<32x128>"),  # BitNet int8, fp32 scale
+    (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=1, c_mode=3, gs=4096), "gemv_a8w4_kernel<tile16,16w>"),  # channel-wise, post-scale
+    (dict(M=1, nbits=2, in_dt=4, out_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemv_a8w2_kernel<tile16,16w>"),  # BitNet int8, fp32 scale
+    (dict(M=8, nbits=2, in_dt=4, out_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w2_mma_kernel<32x128>"),
     (dict(M=300, nbits=2, in_dt=4, out_dt=2, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w2_mma_kernel<64x128>"),
     (dict(M=1, in_dt=8, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "generic_matmul_kernel"),   # e5m2 activations: coverage kernel
     # 16-bit activations whose output / channel-scale type differs (BitNet A16W158 with its fp32 scale; fp32 output)
