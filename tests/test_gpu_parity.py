@@ -886,3 +886,42 @@ def test_coverage_kernel_is_correct_and_announced_once(caplog):
     assert len(hits) == 1 and "N=200" in hits[0].getMessage()
     assert torch.equal(y, y2)
     _compare("coverage/200x512/M3", y, _oracle_from_layer(lin, x), 1)
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        nbits = int(rng.choice([4, 4, 4, 2, 2, 8, 1]))
+        K = int(rng.choice([256, 384, 512, 640, 896, 1024, 1280, 1536, 2048, 2816]))
+        N = int(rng.choice([64, 128, 192, 256, 384, 512, 640, 1024, 1408]))
+        gs = int(rng.choice([64, 128, 128, 128, 256, K]))
+        if K % gs:
+            gs = 128
+        M = int(rng.choice([1, 1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 129, 200, 256, 300, 513]))
+        tdt = torch.float16 if rng.random() < 0.5 else torch.bfloat16
+        zk = str(rng.choice(["tensor", "tensor", "tensor", "none", "int"]))
+        fma = bool(rng.random() < 0.7)
+        out.append((i, nbits, N, K, gs, M, tdt, zk, fma))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(72, seed=2024), ids=lambda c: f"r{c[0]}-w{c[1]}-{c[2]}x{c[3]}-g{c[4]}-M{c[5]}-{str(c[6])[6:]}-{c[7]}-{'fma' if c[8] else 'sub'}")
+def test_random_shapes_dtypes_and_modes_against_the_oracle(case):
+    """Seeded random sweep over bit width x (N, K) (including K = 128 * odd and N = 64 * odd) x group size x M (all kernel
+    families and their thresholds) x dtype x zero kind x dequant mode: whatever kernel the planners pick — their choices
+    come from a fitted cost model, so odd shapes reach (tile, K-slice) pairs no hand-written test names — the result
+    matches the float64 oracle on the tensors the layer holds."""
+    i, nbits, N, K, gs, M, tdt, zk, fma = case
+    try:
+        lin = _make_layer(N, K, nbits, gs, tdt, seed=1000 + i, zeros_kind=zk, fma=fma)
+    except (NotImplementedError, ValueError) as e:  # a combination the reference's constructor / pack() rejects as well
+        pytest.skip(f"rejected at construction: {e}")
+    x = torch.from_numpy(O.gen_x(M, K, seed=i).astype(np.float32)).to(tdt).to(DEV)
+    name = _kernel_name(lin, x)
+    y = lin(x)
+    torch.cuda.synchronize()
+    assert y.shape == (M, N)
+    # 8-bit codes and shift-only modes give |y| >> 1: the absolute gate of the 4-bit fixtures does not apply
+    _compare(f"random/{i}", y, _oracle_from_layer(lin, x), lin.output_dtype.value, abs_gate=None,
+             extra=dict(kernel=name, case=[nbits, N, K, gs, M, str(tdt), zk, fma]))
