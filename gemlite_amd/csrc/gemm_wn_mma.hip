@@ -730,16 +730,19 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         }
     } else {
         double best = 1e30;
-        for (int c = 1; c <= 8; c <<= 1) {
-            if (a.tuning[2] != 0 ? c != a.tuning[2] : c > cap) continue;
-            if (a.K % kstep_of(c) != 0) continue;
-            const int un = (int)(a.K / kstep_of(c));
-            for (int sk = 1; sk <= un && sk <= 16; ++sk) {
-                if (a.tuning[1] > 0 ? sk != a.tuning[1] : (sk > 1 && un / sk < 2)) continue;
-                const double t = cost_us(c, sk);
-                if (t < best) { best = t; mi = c; splitk = sk; }
+        // second pass: K = 128 * odd (896, 640, ...) divides only the 128-k steps of the 128- / 256-row tiles — those then
+        // apply whatever M is (rows >= M are never loaded nor stored)
+        for (int pass = 0; pass < 2 && !mi; ++pass)
+            for (int c = 1; c <= 8; c <<= 1) {
+                if (a.tuning[2] != 0 ? c != a.tuning[2] : (pass == 0 ? c > cap : c != 4)) continue;
+                if (a.K % kstep_of(c) != 0) continue;
+                const int un = (int)(a.K / kstep_of(c));
+                for (int sk = 1; sk <= un && sk <= 16; ++sk) {
+                    if (a.tuning[1] > 0 ? sk != a.tuning[1] : (sk > 1 && un / sk < 2)) continue;
+                    const double t = cost_us(c, sk);
+                    if (t < best) { best = t; mi = c; splitk = sk; }
+                }
             }
-        }
         if (!mi) return false;  // no tile variant divides K (K % 128 != 0), or an override that does not apply
     }
     const int ks = kstep_of(mi);

@@ -630,10 +630,10 @@ def test_mma_kernel_bit_widths_tiles_and_splits(nbits, tdt):
 
 
 @pytest.mark.parametrize("gs", [128, 64])
-@pytest.mark.parametrize("N,K", [(1024, 11008), (1536, 8960)])
+@pytest.mark.parametrize("N,K", [(1024, 11008), (1536, 8960), (1024, 896)])
 def test_llm_shapes_with_odd_k_never_hit_the_coverage_kernel(N, K, gs):
-    """K = 11008 (Llama-2-7B down_proj) / 8960 (Qwen2.5-1.5B): K / 128 is odd, which the power-of-two chunking of the
-    round-1 kernels rejected (they fell to generic_matmul_kernel)."""
+    """K = 11008 (Llama-2-7B down_proj) / 8960 (Qwen2.5-1.5B) / 896 (Qwen2.5-0.5B: 128 * 7): shapes the power-of-two
+    chunking of the round-1 kernels rejected (they fell to generic_matmul_kernel)."""
     lin = _make_layer(N, K, 4, gs, torch.float16, seed=50)
     for M in (1, 5, 32, 64, 200):
         x = torch.from_numpy(O.gen_x(M, K, seed=M)).to(DEV)

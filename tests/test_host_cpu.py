@@ -115,6 +115,8 @@ def test_struct_abi_and_validation():
     (dict(M=32, N=4096, K=11008, gs=64), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=16, N=1536, K=8960), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=64, N=4096, K=11008), "gemm_w4_mma_kernel<64x128>"),
+    (dict(M=8, N=4864, K=896), "gemm_w4_mma_kernel<128x128>"),   # K = 128 * 7 (Qwen2.5-0.5B): only the 128-k-step tiles divide it
+    (dict(M=1, N=1024, K=896), "gemv_wn_kernel<tile64,xdirect>"),
     (dict(M=256, N=4096, K=11008), "gemm_w4_mma_kernel<128x128>"),   # block-time model: 128 rows x 4 slices (40.5 vs 42.3 us for 64 x 2)
     (dict(M=1, nbits=2), "gemv_wn_kernel<tile16>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
