@@ -62,11 +62,11 @@ if "w2" in which:
 if "oddk" in which:
     for M in (1, 8, 32, 64):
         run(f"K=11008 fp16 M={M}", 4096, 11008, 4, M, hf, [(0, 0, 0, 0)], nl=12)
-if "a8" in which:
+if "a8" in which or "a8s" in which:
     from gemlite_amd.helper import A8W8_int8_dynamic, A8W8_fp8_dynamic
     from gemlite_amd.quant_utils import scale_activations_per_token
     for tag, proc_cls, qdt, N, K, nl in (("A8W8 int8 4096", A8W8_int8_dynamic, torch.int8, 4096, 4096, 16),
-                                         ("FP8 16384", A8W8_fp8_dynamic, torch.float8_e4m3fn, 16384, 16384, 2)):
+                                         ("FP8 16384", A8W8_fp8_dynamic, torch.float8_e4m3fn, 16384, 16384, 2))[:1 if "a8s" in which else 2]:
         gg = torch.Generator().manual_seed(1)
         proc = proc_cls(device=DEV, dtype=torch.float16)
         mods = [proc.from_weights((torch.randn(N, K, generator=gg) / 30).half()) for _ in range(nl)]
@@ -74,7 +74,7 @@ if "a8" in which:
             x = (torch.randn(M, K, generator=g, device=DEV) / 10).half()
             xq, sx = scale_activations_per_token(x, qdt)
             ops = 2.0 * M * N * K
-            tun = [(0, 0, 0, 0), (2, 0, 0, 0)] + ([(1, 0, 0, 0)] if M <= 16 else []) + ([(0, 2, 2, 0), (0, 2, 4, 0), (0, 4, 8, 0), (0, 4, 4, 0), (0, 1, 1, 0)] if M == 256 else [])
+            tun = [(0, 0, 0, 0), (0, 0, 0, 32), (2, 0, 0, 0)] + ([(1, 0, 0, 0)] if M <= 16 else []) + ([(0, 2, 2, 0), (0, 2, 4, 0), (0, 4, 8, 0), (0, 4, 4, 0), (0, 1, 1, 0)] if M == 256 else [])
             for t in tun:
                 i = [0]
 
