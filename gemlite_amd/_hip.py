@@ -108,6 +108,11 @@ def load():
         lib.gemlite_hip_scale_activations_per_token.restype = C.c_int
         lib.gemlite_hip_scale_activations_per_token.argtypes = [
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+        for name in ("gemlite_hip_scale_activations_mxfp8", "gemlite_hip_scale_activations_mxfp4",
+                     "gemlite_hip_scale_activations_nvfp4"):
+            getattr(lib, name).restype = C.c_int
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                           C.c_void_p]
         lib.gemlite_hip_pack_over_cols.restype = C.c_int
         lib.gemlite_hip_pack_over_cols.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
@@ -123,7 +128,9 @@ def load():
 EXPORTED_SYMBOLS = (
     "gemlite_hip_abi_version", "gemlite_hip_build_info", "gemlite_hip_status_string", "gemlite_hip_last_hip_error",
     "gemlite_hip_query", "gemlite_hip_workspace_bytes", "gemlite_hip_forward", "gemlite_hip_kernel_name",
-    "gemlite_hip_set_profile_events", "gemlite_hip_launch_noop", "gemlite_hip_scale_activations_per_token", "gemlite_hip_pack_over_cols",
+    "gemlite_hip_set_profile_events", "gemlite_hip_launch_noop", "gemlite_hip_scale_activations_per_token",
+    "gemlite_hip_scale_activations_mxfp8", "gemlite_hip_scale_activations_mxfp4", "gemlite_hip_scale_activations_nvfp4",
+    "gemlite_hip_pack_over_cols",
     "gemlite_hip_unpack_over_cols",
 )
 

@@ -24,7 +24,8 @@ from . import _hip
 from .bitpack import pack_weights_over_cols
 from .config import AUTOTUNE, KERNEL, MATMUL_DTYPES, set_autotune, set_kernel_caching  # noqa: F401 (re-exported)
 from .dtypes import (DTYPE_TO_TORCH, FP8_INT8_DTYPES, TORCH_TO_DTYPE, DType, is_mx_dtype)
-from .quant_utils import scale_activations_per_token
+from .quant_utils import (scale_activations_mxfp4, scale_activations_mxfp8, scale_activations_nvfp4,
+                          scale_activations_per_token)
 
 logger = logging.getLogger(__name__)
 
@@ -142,16 +143,19 @@ def _build_template(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> by
     a.W_nbits, a.group_size, a.unpack_mask, a.elements_per_sample = W_nbits, group_size, unpack_mask, e
     a.w_pack_bits = W_q.element_size() * 8 if e > 1 else 0
     a.w_dtype = TORCH_TO_DTYPE[W_q.dtype].value
-    a.input_dtype, a.output_dtype, a.acc_dtype = in_dt, out_dt, acc_dt
+    # the output's storage type: MXFP16 / MXBF16 in the output slot (weight-only MX layers) mean fp16 / bf16
+    a.input_dtype, a.output_dtype, a.acc_dtype = in_dt, TORCH_TO_DTYPE[DTYPE_TO_TORCH[out_dt]].value, acc_dt
     a.meta_dtype = TORCH_TO_DTYPE[scales.dtype].value if scales.numel() > 0 else meta_dt
     a.zeros_dtype = TORCH_TO_DTYPE[zeros.dtype].value if zeros.numel() > 0 else meta_dt
     a.channel_scale_mode, a.W_group_mode = c_mode, w_mode
     a.zero_is_scalar = int(zeros.numel() == 1)
     a.data_contiguous = int(contiguous)
-    base_in = DType.FP16.value if in_dt == DType.BF16.value else in_dt
+    base_in = DType.FP16.value if in_dt == DType.BF16.value else (DType.MXFP16.value if in_dt == DType.MXBF16.value else in_dt)
     a.type_id = base_in * 100 + W_nbits
     a.stride_wk, a.stride_wn = W_q.stride(0), W_q.stride(1)
-    if scales.dim() == 2 and scales.numel() > 0:
+    if is_mx_dtype(in_dt):  # block scales travel as the [N, K/g] transpose of the [K/g, N] buffer (core.py:489-497)
+        a.stride_meta_n, a.stride_meta_g = scales.stride(0), scales.stride(1)
+    elif scales.dim() == 2 and scales.numel() > 0:
         a.stride_meta_g, a.stride_meta_n = scales.stride(0), scales.stride(1)
     elif zeros.dim() == 2 and zeros.numel() > 1:
         a.stride_meta_g, a.stride_meta_n = zeros.stride(0), zeros.stride(1)
@@ -178,9 +182,9 @@ def config_key(M: int, N: int, K: int, group_size: int, elements_per_sample: int
     return str((get_closest_m(int(M)), int(N), int(K), int(group_size), int(elements_per_sample), int(type_id)))
 
 
-def config_family(matmul_type: int, M: int, W_nbits: int) -> str:
+def config_family(matmul_type: int, M: int, W_nbits: int, mx: bool = False) -> str:
     """Family name a table entry is filed under: the forced family, or what the reference would pick for M."""
-    return GEMLITE_MATMUL_TYPES[matmul_type] if matmul_type >= 0 else get_matmul_type(M, W_nbits)
+    return GEMLITE_MATMUL_TYPES[matmul_type] if matmul_type >= 0 else get_matmul_type(M, W_nbits, mx)
 
 
 _TUNING_MASK = (0xFF, 0xFF, 0xFF, 0x3)  # tuning[3]: only the documented x-path bits; development bits are not loadable
@@ -192,7 +196,7 @@ def lookup_tuning(matmul_type: int, M: int, a) -> Optional[tuple]:
     {"tuning": [t0, t1, t2, t3], "us": 4.5}."""
     if not GEMLITE_HIP_CONFIG_CACHE:
         return None
-    fam = GEMLITE_HIP_CONFIG_CACHE.get(config_family(matmul_type, M, a.W_nbits))
+    fam = GEMLITE_HIP_CONFIG_CACHE.get(config_family(matmul_type, M, a.W_nbits, bool(is_mx_dtype(int(a.input_dtype)))))
     if not fam:
         return None
     entry = fam.get(config_key(M, a.N, a.K, a.group_size, a.elements_per_sample, a.type_id))
@@ -216,12 +220,20 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
         raise _hip.GemliteHipError(f"x is on {x.device}, the packed weight on {W_q.device}")
     a = _static_args(W_q, scales, zeros, meta_args)
     M, K = x.shape
+    mx = is_mx_dtype(meta_args[5])
+    if mx and x.dtype == torch.uint8:
+        K *= 2  # e2m1 codes, two per byte
     if K != a.K:
         raise ValueError(f"x has {K} input features, the packed weight expects {a.K}")
     out = torch.empty((M, a.N), dtype=DTYPE_TO_TORCH[a.output_dtype], device=x.device)
     a.matmul_type = matmul_type
     a.x, a.out, a.M = x.data_ptr(), out.data_ptr(), M
-    a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
+    if mx:  # the layer's format pair names what x holds (include/gemlite_hip.h "Block-scaled formats")
+        if x.dtype != DTYPE_TO_TORCH[meta_args[5]]:
+            raise _hip.GemliteHipError(f"{DType(meta_args[5]).name} layer called with {x.dtype} activations")
+        a.input_dtype = meta_args[5]
+    else:
+        a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
     a.stride_xm, a.stride_xk = x.stride(0), x.stride(1)
     a.stride_om, a.stride_on = out.stride(0), out.stride(1)
     if scales_x is not None:
@@ -276,10 +288,21 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
         x = x.contiguous()
     out_shape = x.shape[:-1] + (out_features,)
     in_code = meta_args[5]
-    if is_mx_dtype(in_code):
-        raise NotImplementedError("MX / NV block-scaled dtypes are outside this build's scope")
     scales_x = None
-    if bool(meta_args[0]) and DType(in_code) in FP8_INT8_DTYPES:
+    if bool(meta_args[0]) and is_mx_dtype(in_code):
+        # block-scaled activations (core.py:165-175): microscales (channel_scale_mode 4) or one fp32 scale per token (2)
+        c_mode = meta_args[9]
+        if in_code == DType.MXFP8.value and c_mode == 4:
+            x, scales_x = scale_activations_mxfp8(x, w_dtype=torch.float8_e4m3fn)
+        elif in_code == DType.MXFP8.value and c_mode == 2:
+            x, scales_x = scale_activations_per_token(x, w_dtype=torch.float8_e4m3fn)
+        elif in_code == DType.MXFP4.value and c_mode == 4:
+            x, scales_x = scale_activations_mxfp4(x)
+        elif in_code == DType.NVFP4.value and c_mode == 4:
+            x, scales_x = scale_activations_nvfp4(x)
+        else:
+            raise NotImplementedError(f"no activation quantiser for {DType(in_code).name} with channel_scale_mode {c_mode}")
+    elif bool(meta_args[0]) and DType(in_code) in FP8_INT8_DTYPES:
         # dynamic per-token activation quantisation (core.py:155-175).  One row of 16-bit activations against unpacked
         # 8-bit weights (decode): the library quantises x inside the matmul kernel's prologue — one launch, not two.
         fused = (FUSE_ACT_QUANT_M1 and x.numel() == x.shape[-1] and meta_args[4] == 1 and meta_args[10] == 0 and
@@ -339,10 +362,10 @@ def select_modes(*, has_scales: bool, channelwise: bool, zeros_kind: str, scaled
 
 class GemLiteLinearHIP(torch.nn.Module):
     SUPPORTED_BITS_TRITON = [1, 2, 4, 8, 16]
-    SUPPORTED_DTYPES = [DType.FP16, DType.BF16, DType.FP32, DType.FP8, DType.FP8e4, DType.FP8e5, DType.INT8]
-    # accepted by the constructor for API parity, rejected at forward time (not gfx950 formats / out of scope)
-    _DEFERRED_DTYPES = [DType.FP8e4nuz, DType.FP8e5nuz, DType.MXFP16, DType.MXBF16, DType.MXFP8, DType.MXFP4,
-                        DType.NVFP4]
+    SUPPORTED_DTYPES = [DType.FP16, DType.BF16, DType.FP32, DType.FP8, DType.FP8e4, DType.FP8e5, DType.INT8,
+                        DType.MXFP16, DType.MXBF16, DType.MXFP8, DType.MXFP4, DType.NVFP4]
+    # accepted by the constructor for API parity, rejected at forward time (MI300X formats, not gfx950's)
+    _DEFERRED_DTYPES = [DType.FP8e4nuz, DType.FP8e5nuz]
     MIN_SIZE = 32
     PACKING_BITWIDTH = 32
 
@@ -386,16 +409,24 @@ class GemLiteLinearHIP(torch.nn.Module):
             fractional = isinstance(zeros, float) or (isinstance(zeros, Tensor) and bool((zeros != zeros.round()).any()))
             if fractional:
                 raise Exception("INT8 inputs is not compatible with floating-point zeros.")
-        if is_mx_dtype(self.input_dtype):
-            raise NotImplementedError("MX / NV block-scaled formats are outside this build's scope")
         if packing_bitwidth is None:
             packing_bitwidth = GemLiteLinearHIP.PACKING_BITWIDTH
+        mx = bool(is_mx_dtype(self.input_dtype))
+        if mx:
+            packing_bitwidth = 8  # microscaling: e2m1 codes two per byte, fp8 unpacked (core.py:363-365)
+            if scales is None or zeros is not None:
+                raise NotImplementedError("block-scaled formats take (W_q, scales) and no zeros")
 
         packed = W_q.dtype == torch.uint8
         if packed:
-            self.W_q, self.elements_per_sample = pack_weights_over_cols(
-                W_q.view(self.orig_shape), W_nbits=self.W_nbits, packing_bitwidth=packing_bitwidth, transpose=True)
-            want_contiguous = True if contiguous is None else bool(contiguous)
+            if mx:  # [N, K/2] bytes, handed on as the [K/2, N] view: K-contiguous per output column
+                pk, self.elements_per_sample = pack_weights_over_cols(
+                    W_q.view(self.orig_shape), W_nbits=self.W_nbits, packing_bitwidth=packing_bitwidth, transpose=False)
+                self.W_q = pk.t()
+            else:
+                self.W_q, self.elements_per_sample = pack_weights_over_cols(
+                    W_q.view(self.orig_shape), W_nbits=self.W_nbits, packing_bitwidth=packing_bitwidth, transpose=True)
+            want_contiguous = (not mx) if contiguous is None else bool(contiguous)  # MX: K-contiguous per column (core.py:395-396)
         elif W_q.dtype == torch.int8 or W_q.is_floating_point():
             expect = {torch.float32: 32, torch.float16: 16, torch.bfloat16: 16}.get(W_q.dtype, 8)
             assert self.W_nbits == expect, f"Invalid {expect}-bit weights."
@@ -442,6 +473,15 @@ class GemLiteLinearHIP(torch.nn.Module):
             self.W_q = self.W_q.contiguous()
         self.scales = self.scales.contiguous()
         self.zeros = self.zeros.contiguous()
+        if mx:
+            # one byte per block: e8m0 exponents (NVFP4: e4m3), stored [K/g, N] and handed on as its [N, K/g] transpose;
+            # the block scales are part of the contraction, not a group / channel mode (core.py:489-497)
+            if self.input_dtype == DType.NVFP4:
+                self.scales = self.scales.to(torch.float8_e4m3fn)
+            elif self.scales.dtype != torch.uint8:  # uint8 = e8m0 bytes already
+                self.scales = self.scales.to(torch.float8_e8m0fnu).view(torch.uint8)
+            self.scales = self.scales.T
+            self.W_group_mode, self.channel_scale_mode = 2, 0
         self.meta_dtype = TORCH_TO_DTYPE[self.scales.dtype]
 
         as_param = lambda t: torch.nn.Parameter(t, requires_grad=False)  # noqa: E731

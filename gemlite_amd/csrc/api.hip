@@ -23,6 +23,9 @@ bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
+const void* mx_generic_kernel_fn();
+const void* act_quant_mx_kernel_fn(int mode);
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
 const void* kmajor_w8a16_kernel_fn(int mb);
@@ -82,17 +85,40 @@ static bool wants_fused_quant(const gemlite_hip_forward_args* a) {
            (a->w_dtype == GEMLITE_DT_INT8 || a->w_dtype == GEMLITE_DT_FP8E4 || a->w_dtype == GEMLITE_DT_FP8E5);
 }
 
+static bool is_mx_input(int dt) { return dt >= GEMLITE_DT_MXFP16 && dt <= GEMLITE_DT_NVFP4; }
+
+// block-scaled formats (see the header): what must hold before any kernel is chosen
+static int validate_mx(const gemlite_hip_forward_args* a) {
+    const bool nv = a->input_dtype == GEMLITE_DT_NVFP4;
+    if (a->group_size != (nv ? 16 : 32)) return GEMLITE_ERR_UNSUPPORTED;
+    if (a->K % 32 != 0) return GEMLITE_ERR_BAD_SHAPE;
+    if (!a->scales) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (!(a->output_dtype == GEMLITE_DT_FP32 || a->output_dtype == GEMLITE_DT_FP16 || a->output_dtype == GEMLITE_DT_BF16))
+        return GEMLITE_ERR_UNSUPPORTED;
+    const bool w8 = a->W_nbits == 8 && a->elements_per_sample == 1 && a->w_dtype == GEMLITE_DT_FP8E4;
+    const bool w4 = a->W_nbits == 4 && a->elements_per_sample == 2 && a->w_pack_bits == 8;
+    if (!w8 && !w4) return GEMLITE_ERR_UNSUPPORTED;
+    const bool x16 = a->input_dtype == GEMLITE_DT_MXFP16 || a->input_dtype == GEMLITE_DT_MXBF16;
+    if ((a->input_dtype == GEMLITE_DT_MXFP4 || nv) && !w4) return GEMLITE_ERR_UNSUPPORTED;
+    if (x16 ? a->channel_scale_mode != 0 : !(a->channel_scale_mode == 4 || (a->channel_scale_mode == 2 && !nv))) return GEMLITE_ERR_UNSUPPORTED;
+    if (!x16 && !a->scales_x) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (a->stride_xk != 1) return GEMLITE_ERR_UNSUPPORTED;
+    if (a->M > 65535 && a->M > 0x7FFFFFFF) return GEMLITE_ERR_BAD_SHAPE;
+    return GEMLITE_OK;
+}
+
 static int validate(const gemlite_hip_forward_args* a) {
     if (!a || a->struct_size != sizeof(gemlite_hip_forward_args)) return GEMLITE_ERR_BAD_ARGUMENT;
     if (!a->x || !a->w_q || !a->out) return GEMLITE_ERR_BAD_ARGUMENT;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return GEMLITE_ERR_BAD_ARGUMENT;
     if (a->M > 0x7FFFFFFF || a->N > 0x7FFFFFFF || a->K > 0x7FFFFFFF) return GEMLITE_ERR_BAD_SHAPE;
+    if (is_mx_input(a->input_dtype)) return validate_mx(a);
     if (a->W_group_mode < 0 || a->W_group_mode > 4) return GEMLITE_ERR_UNSUPPORTED;
-    if (a->channel_scale_mode < 0 || a->channel_scale_mode > 3) return GEMLITE_ERR_UNSUPPORTED;  // 4 = MX
+    if (a->channel_scale_mode < 0 || a->channel_scale_mode > 3) return GEMLITE_ERR_UNSUPPORTED;  // 4: block-scaled inputs only
     if (a->elements_per_sample < 1) return GEMLITE_ERR_BAD_ARGUMENT;
     if (a->K % a->elements_per_sample != 0) return GEMLITE_ERR_BAD_SHAPE;
     if (a->input_dtype == GEMLITE_DT_FP8E4NUZ || a->input_dtype == GEMLITE_DT_FP8E5NUZ) return GEMLITE_ERR_UNSUPPORTED;
-    if (a->input_dtype > GEMLITE_DT_FP8E5NUZ) return GEMLITE_ERR_UNSUPPORTED;  // MX / NV formats: out of scope
+    if (a->input_dtype > GEMLITE_DT_FP8E5NUZ) return GEMLITE_ERR_UNSUPPORTED;
     if (dtype_size(a->input_dtype) == 0) return GEMLITE_ERR_UNSUPPORTED;
     if (!(a->output_dtype == GEMLITE_DT_FP32 || a->output_dtype == GEMLITE_DT_FP16 || a->output_dtype == GEMLITE_DT_BF16))
         return GEMLITE_ERR_UNSUPPORTED;
@@ -114,9 +140,40 @@ static int validate(const gemlite_hip_forward_args* a) {
     return GEMLITE_OK;
 }
 
+// Block-scaled formats: the scaled-MFMA kernel for 8 / 4-bit activations, the coverage kernel for everything else
+// (16-bit activations x MX weights, NVFP4, layouts that are not K-contiguous).  tuning[0] = 1 forces the coverage kernel.
+static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
+    GenericParams g{};
+    g.x = a.x; g.w = a.w_q; g.scales = a.scales; g.zeros = nullptr;
+    g.epi = make_epilogue(a);
+    if (a.channel_scale_mode == 4) g.epi.c_mode = 0;  // block scales are applied inside the contraction
+    g.M = (int)a.M; g.N = (int)a.N; g.K = (int)a.K;
+    g.nbits = a.W_nbits; g.e = a.elements_per_sample; g.pack_bits = a.w_pack_bits;
+    g.w_dt = a.w_dtype; g.x_dt = a.input_dtype;
+    g.group_size = a.group_size;
+    g.stride_xm = a.stride_xm; g.stride_xk = a.stride_xk; g.stride_wk = a.stride_wk; g.stride_wn = a.stride_wn;
+    g.stride_meta_g = a.stride_meta_g; g.stride_meta_n = a.stride_meta_n;
+    g.mx_x = a.input_dtype == GEMLITE_DT_MXFP16 ? MX_F16 : (a.input_dtype == GEMLITE_DT_MXBF16 ? MX_BF16 : (a.input_dtype == GEMLITE_DT_MXFP8 ? MX_FP8 : MX_FP4));
+    g.mx_w = a.W_nbits == 8 ? MX_FP8 : MX_FP4;
+    g.mx_scale_e4m3 = a.input_dtype == GEMLITE_DT_NVFP4 ? 1 : 0;
+    g.sx_blocks = a.channel_scale_mode == 4 ? a.scales_x : nullptr;
+    g.stride_sx_blk_m = a.stride_sx_m;
+    g.mx_post = a.input_dtype == GEMLITE_DT_NVFP4 ? 0.0025f : 1.0f;  // meta_scale_norm = 0.05 ** 2 (gemm_kernels.py:461, 530-531)
+    g.splitk = 1;
+    r.gp = g;
+    if (a.tuning[0] == 0 && plan_gemm_mx_mma(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
+    if (a.M > 65535) { r.status = GEMLITE_ERR_BAD_SHAPE; return; }
+    r.kind = K_GENERIC;
+    r.lp.fn = mx_generic_kernel_fn();
+    r.lp.name = "mx_generic_kernel";
+    r.lp.grid = dim3((unsigned)((a.N + 255) / 256), (unsigned)a.M, 1);
+    r.lp.block = dim3(256, 1, 1);
+}
+
 static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
     r.status = validate(&a);
     if (r.status != GEMLITE_OK) return;
+    if (is_mx_input(a.input_dtype)) { resolve_mx(a, r); return; }
     const bool packed = a.elements_per_sample > 1;
     const bool x16 = a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_BF16;
     // metadata rows actually indexed by K: channel-wise / scalar metadata behaves like one K-long group
@@ -305,8 +362,8 @@ extern "C" {
 int gemlite_hip_abi_version(void) { return GEMLITE_HIP_ABI_VERSION; }
 
 const char* gemlite_hip_build_info(void) {
-    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_direct, gemm_wn_stream, gemm_wn_mma, gemm_wn_tiled, gemm_a8w8, kmajor, generic, "
-           "act_quant_per_token, pack/unpack_over_cols";
+    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_direct, gemm_wn_stream, gemm_wn_mma, gemm_wn_tiled, gemm_a8w8, gemm_mx, kmajor, generic, "
+           "act_quant_per_token, act_quant_mx, pack/unpack_over_cols";
 }
 
 const char* gemlite_hip_status_string(int status) {
@@ -406,6 +463,34 @@ int gemlite_hip_scale_activations_per_token(const void* x, void* y, float* scale
     int in_dt = in_dtype, out_dt = out_dtype;
     void* kargs[] = {(void*)&x, (void*)&y, (void*)&scales, (void*)&K, (void*)&stride_xm, (void*)&in_dt, (void*)&out_dt};
     return launch(act_quant_kernel_fn(), dim3((unsigned)M, 1, 1), dim3(256, 1, 1), kargs, 0, (hipStream_t)stream);
+}
+
+static int scale_activations_mx(int mode, const void* x, void* y, uint8_t* scales, int64_t M, int64_t K, int64_t stride_xm,
+                                int32_t in_dtype, void* stream) {
+    const int64_t G = mode == 2 ? 16 : 32;
+    if (!x || !y || !scales || M <= 0 || K <= 0) return GEMLITE_ERR_BAD_ARGUMENT;
+    if (!(in_dtype == GEMLITE_DT_FP16 || in_dtype == GEMLITE_DT_BF16 || in_dtype == GEMLITE_DT_FP32)) return GEMLITE_ERR_UNSUPPORTED;
+    if (K % 32 != 0) return GEMLITE_ERR_BAD_SHAPE;  // 16-byte output pieces; the formats' own block is 32 (16) k
+    if (((uintptr_t)y % 16) != 0) return GEMLITE_ERR_BAD_ARGUMENT;
+    int64_t m_pad = (M + G - 1) / G * G;
+    const int64_t total = m_pad * (K / G);
+    if (total > 0x7FFFFFFFll * 256) return GEMLITE_ERR_BAD_SHAPE;
+    int in_dt = in_dtype;
+    void* kargs[] = {(void*)&x, (void*)&y, (void*)&scales, (void*)&M, (void*)&m_pad, (void*)&K, (void*)&stride_xm, (void*)&in_dt};
+    return launch(act_quant_mx_kernel_fn(mode), dim3((unsigned)((total + 255) / 256), 1, 1), dim3(256, 1, 1), kargs, 0, (hipStream_t)stream);
+}
+
+int gemlite_hip_scale_activations_mxfp8(const void* x, void* y, uint8_t* scales, int64_t M, int64_t K, int64_t stride_xm,
+                                        int32_t in_dtype, void* stream) {
+    return scale_activations_mx(0, x, y, scales, M, K, stride_xm, in_dtype, stream);
+}
+int gemlite_hip_scale_activations_mxfp4(const void* x, uint8_t* y, uint8_t* scales, int64_t M, int64_t K, int64_t stride_xm,
+                                        int32_t in_dtype, void* stream) {
+    return scale_activations_mx(1, x, y, scales, M, K, stride_xm, in_dtype, stream);
+}
+int gemlite_hip_scale_activations_nvfp4(const void* x, uint8_t* y, uint8_t* scales, int64_t M, int64_t K, int64_t stride_xm,
+                                        int32_t in_dtype, void* stream) {
+    return scale_activations_mx(2, x, y, scales, M, K, stride_xm, in_dtype, stream);
 }
 
 static int check_pack(int64_t N, int64_t K, int32_t nbits, int32_t pack_bits) {

@@ -1,0 +1,547 @@
+// gemm_mx.hip — block-scaled ("microscaling") formats: MXFP8 / MXFP4 weights and activations with one e8m0 scale per
+// 32 k, NVFP4 (e4m3 scale per 16 k).  Replaces gemm_MX_kernel (gemlite/triton_kernels/gemm_kernels.py:422-547),
+// gemm_splitK_MX_kernel (gemm_splitK_kernels.py:458-593) and the activation quantisers
+// scale_activations_{mxfp8,mxfp4,nvfp4}_triton_v2 (gemlite/quant_utils.py:502-590, 769-855, 859-954).
+//
+// tl.dot_scaled(a, sa, fmt_a, b, sb, fmt_b, acc) is, on gfx950, ONE instruction: v_mfma_scale_f32_32x32x64_f8f6f4 multiplies a
+// 32 x 64 by a 64 x 32 tile of fp8 / fp4 elements, each 32-k block of every row / column carrying its own e8m0 scale.
+// Operand layout (measured: scripts/ubench/probe_mx.hip, probe_mx2.hip; profiles/r02/mx/):
+//   fp4: lane l = row / column (l & 31); its 32 nibbles (4 dwords, low nibble first) are k = 32 (l >> 5) + e;
+//        the lane's own scale register (byte 0) scales them;
+//   fp8: lane l = row / column (l & 31); byte b of its 8 dwords is k = 32 (b >> 4) + 16 (l >> 5) + (b & 15): a lane holds
+//        16 bytes of EACH of the two 32-k blocks; block s takes its scale from the lane with (l >> 5) == s;
+//   D:   col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), like every 32x32 MFMA.
+// Memory layout fixed by the reference's pack() (core.py:363-398, 489-497): weights K-CONTIGUOUS per output column — fp8
+// [N][K] bytes, fp4 [N][K/2] bytes (k even in the low nibble) — weight scales [K/32][N] bytes; activations row-major in
+// the same element formats with scales [M_pad][K/32].  Both operands are therefore read as 16-byte pieces of rows and
+// NOTHING is unpacked or dequantised in the K loop.
+//
+//   gemm_mx_mma_kernel   8 waves, tile (32 MI) x 128, the skeleton of gemm_a8w8_mma_kernel: x by LDS-DMA (XOR-swizzled
+//                        through the source address), weights + both scale streams HBM -> registers, counted waits,
+//                        split-K slabs.  fp8 / fp4 activations (A8W8 / A8W4 / A4W4 MXFP dynamic).
+//   mx_generic_kernel    coverage: lane = output column, any strides, 16-bit activations x MX weights, and NVFP4 (an
+//                        e4m3-scaled 16-k format the gfx950 matrix core has no instruction for).
+//   act_quant_mx_kernel  the three activation quantisers, bit-exact restatements (thread = one block of 32 / 16 k).
+#include <type_traits>
+
+#include "gl_common.h"
+#include "gl_async.h"
+
+namespace gl {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float fp4_to_float(uint32_t c) {  // e2m1: 0, 0.5, 1, 1.5, 2, 3, 4, 6; bit 3 = sign
+    const uint32_t m = c & 7u;
+    const float a = m < 2u ? 0.5f * (float)m : __builtin_bit_cast(float, ((126u + (m >> 1)) << 23) | ((m & 1u) << 22));
+    return (c & 8u) ? -a : a;
+}
+__device__ __forceinline__ float e8m0_to_float(uint32_t b) {  // 2^(b - 127); 0 -> 2^-127 (an fp32 subnormal)
+    return b == 0 ? __builtin_bit_cast(float, 0x00400000u) : __builtin_bit_cast(float, b << 23);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// activation quantisers.  MODE 0: MXFP8 (e4m3 elements), 1: MXFP4 (e2m1 codes, two per byte), 2: NVFP4 (e2m1 codes, e4m3
+// scale per 16 k, meta scale 0.05).  Arithmetic of the reference kernels, operation by operation:
+//   MX:  s = 2^ceil(log2(amax / qmax)) through the exponent bits (next_power_of_2_bitwise_triton, quant_utils.py:383-392),
+//        exponent clamped to [127 - 30, 254];  q = x / s  (clamped to +-448 and rounded to nearest even for fp8)
+//   fp4: code = #{thresholds 0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5, 7 below |q|}, + 8 when q < 0  (quant_utils.py:800-802)
+//   NV:  s8 = e4m3(min(amax / (6 * 0.05), 448));  q = x / max(float(s8) * 0.05, 1e-6)       (quant_utils.py:893-900)
+// Rows M .. M_pad - 1 of the scale tensor (the reference pads M to a multiple of the group size and its programs store
+// the scale of an all-zero block there) are written with that value; no element output exists for them.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void act_quant_mx_kernel(const void* x, uint8_t* y, uint8_t* scales, int64_t M, int64_t M_pad,
+                                                          int64_t K, int64_t stride_xm, int in_dt) {
+    constexpr int G = MODE == 2 ? 16 : 32;
+    const int64_t gpr = K / G;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M_pad * gpr) return;
+    const int64_t m = idx / gpr, g = idx - m * gpr;
+    float v[G];
+    float amax = 0.f;
+    if (m < M) {
+        const int64_t base = m * stride_xm + g * G;
+        const bool vec = (in_dt == GEMLITE_DT_FP16 || in_dt == GEMLITE_DT_BF16) && ((((uintptr_t)x) | (uintptr_t)(stride_xm * 2)) % 16 == 0);
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < G / 8; ++q) {
+                const u32x4 d = *(const u32x4*)((const uint16_t*)x + base + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint16_t hb = (uint16_t)(d[e >> 1] >> (16 * (e & 1)));
+                    v[8 * q + e] = in_dt == GEMLITE_DT_FP16 ? F16Traits<half_tag>::to_float(hb) : F16Traits<bf16_tag>::to_float(hb);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < G; ++e) v[e] = load_as_float(x, base + e, in_dt);
+        }
+#pragma unroll
+        for (int e = 0; e < G; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < G; ++e) v[e] = 0.f;
+    }
+    float s;
+    if (MODE == 2) {
+        const float s32 = fminf(__fdiv_rn(amax, 0.3f), 448.f);  // 6 * 0.05 folded to the fp32 constant 0.3f
+        const uint8_t s8 = float_to_fp8e4m3(s32);
+        scales[idx] = s8;
+        s = fmaxf(fp8e4m3_to_float(s8) * 0.05f, 1e-6f);
+    } else {
+        const uint32_t xi = __builtin_bit_cast(uint32_t, __fdiv_rn(amax, MODE == 0 ? 448.f : 6.f));
+        int ex = (int)((xi >> 23) & 0xFFu) + ((xi & 0x7FFFFFu) != 0u ? 1 : 0);
+        ex = ex > 254 ? 254 : (ex < 97 ? 97 : ex);
+        scales[idx] = (uint8_t)ex;
+        s = __builtin_bit_cast(float, (uint32_t)ex << 23);
+    }
+    if (m >= M) return;
+    if (MODE == 0) {
+        uint32_t o[8];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const float q = fminf(fmaxf(__fdiv_rn(v[e], s), -448.f), 448.f);
+            const uint32_t b = float_to_fp8e4m3(q);
+            if ((e & 3) == 0) o[e >> 2] = b;
+            else o[e >> 2] |= b << (8 * (e & 3));
+        }
+        u32x4* dst = (u32x4*)(y + m * K + g * 32);
+        dst[0] = (u32x4){o[0], o[1], o[2], o[3]};
+        dst[1] = (u32x4){o[4], o[5], o[6], o[7]};
+    } else {
+        uint32_t o[G / 8];
+#pragma unroll
+        for (int e = 0; e < G; ++e) {
+            const float q = __fdiv_rn(v[e], s), a = fabsf(q);
+            uint32_t c = (a > 0.25f) + (a > 0.75f) + (a > 1.25f) + (a > 1.75f) + (a > 2.5f) + (a > 3.5f) + (a > 5.0f) + (a > 7.0f);
+            if (!(q >= 0.f)) c += 8u;
+            c &= 0xFFu;
+            if ((e & 7) == 0) o[e >> 3] = c;
+            else o[e >> 3] += c << (4 * (e & 7));  // += : a code of 16 (|q| > 7 and negative) carries like lo | (hi << 4) on uint8 pairs
+        }
+        uint8_t* dst = y + m * (K / 2) + g * (G / 2);
+        if (G == 32) *(u32x4*)dst = (u32x4){o[0], o[1], o[2], o[3]};
+        else *(u32x2*)dst = (u32x2){o[0], o[1]};
+    }
+}
+const void* act_quant_mx_kernel_fn(int mode) {
+    return mode == 0 ? (const void*)act_quant_mx_kernel<0> : (mode == 1 ? (const void*)act_quant_mx_kernel<1> : (const void*)act_quant_mx_kernel<2>);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// coverage kernel: lane = output column, one row m per blockIdx.y; walks K block by block.  Any strides.
+//   out[m, n] = post * sum_blocks  sx(m, blk) * sw(blk, n) * sum_{k in blk} x[m, k] * w[k, n]      (fp32 accumulation)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mx_elem(const void* base, int64_t row_off_bytes, int64_t k, int fmt) {
+    if (fmt == MX_FP4) {
+        const uint8_t b = ((const uint8_t*)base)[row_off_bytes + (k >> 1)];
+        return fp4_to_float((k & 1) ? (b >> 4) : (b & 15));
+    }
+    if (fmt == MX_FP8) return fp8e4m3_to_float(((const uint8_t*)base)[row_off_bytes + k]);
+    const uint16_t hbits = *(const uint16_t*)((const uint8_t*)base + row_off_bytes + 2 * k);
+    return fmt == MX_F16 ? F16Traits<half_tag>::to_float(hbits) : F16Traits<bf16_tag>::to_float(hbits);
+}
+
+__global__ __launch_bounds__(256) void mx_generic_kernel(const GenericParams p) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t m = blockIdx.y;
+    if (n >= p.N) return;
+    const int G = p.group_size;
+    // weights: element (k, n) at k * stride_wk + n * stride_wn (fp8) or byte (k / e) * stride_wk + n * stride_wn (fp4, e = 2)
+    const bool w_kmajor = p.stride_wk == 1;
+    const int xbytes = (p.mx_x == MX_F16 || p.mx_x == MX_BF16) ? 2 : 1;
+    const int64_t xrow = m * p.stride_xm * xbytes;  // stride in elements of x's own dtype (fp4: bytes)
+    float acc = 0.f;
+    for (int64_t k0 = 0; k0 < p.K; k0 += G) {
+        const int64_t blk = k0 / G;
+        const uint8_t sb = ((const uint8_t*)p.scales)[blk * p.stride_meta_g + n * p.stride_meta_n];
+        float s = p.mx_scale_e4m3 ? fp8e4m3_to_float(sb) : e8m0_to_float(sb);
+        if (p.sx_blocks) {
+            const uint8_t sa = ((const uint8_t*)p.sx_blocks)[m * p.stride_sx_blk_m + blk];
+            s *= p.mx_scale_e4m3 ? fp8e4m3_to_float(sa) : e8m0_to_float(sa);
+        }
+        float part = 0.f;
+        for (int k = 0; k < G; ++k) {
+            const int64_t kk = k0 + k;
+            float w;
+            if (p.mx_w == MX_FP4) {
+                const uint8_t b = ((const uint8_t*)p.w)[(kk >> 1) * p.stride_wk + n * p.stride_wn];
+                w = fp4_to_float((kk & 1) ? (b >> 4) : (b & 15));
+            } else {
+                w = fp8e4m3_to_float(((const uint8_t*)p.w)[kk * p.stride_wk + n * p.stride_wn]);
+            }
+            part = __builtin_fmaf(mx_elem(p.x, xrow, kk, p.mx_x), w, part);
+        }
+        acc = __builtin_fmaf(part, s, acc);
+    }
+    (void)w_kmajor;
+    epilogue_store(p.epi, acc * p.mx_post, m, n);
+}
+const void* mx_generic_kernel_fn() { return (const void*)mx_generic_kernel; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// scaled-MFMA kernel.  AF / BF: element format of x / w as the instruction's cbsz / blgp code (0 = fp8 e4m3, 4 = fp4 e2m1).
+// A K step moves 256 BYTES of every x row (256 k of fp8, 512 k of fp4); wave (cg, kh) owns all rows x 32 columns x the
+// kh-th half of the step = NS slices of 64 k.  Per slice and lane: A fragment = 16 (fp4) or 2 x 16 (fp8) bytes read from
+// the LDS stage, B fragment = the same amount straight from the weight row (tracked buffer loads, PD steps ahead), one
+// weight-scale byte, and per row block one dword of activation scales (4 blocks; shifted so that this lane's block is
+// byte 0).  c_mode 2 (per-token fp32 scale applied in the epilogue): the activation block scale is the constant 127.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int AF, int BF, int MI, int RD, int NST>
+__global__ __launch_bounds__(512, 2) void gemm_mx_mma_kernel(const GenericParams p) {
+    using namespace async;
+    constexpr int AV = AF == 0 ? 2 : 1, BV = BF == 0 ? 2 : 1;      // 16-byte pieces per fragment
+    constexpr int BM = 32 * MI, BN = 128;
+    constexpr int PITCH = 256, STAGE = BM * PITCH;                 // bytes of x per row and step / per stage
+    constexpr int KSTEP = AF == 0 ? 256 : 512, KW = KSTEP / 2;     // k per step / per wave half
+    constexpr int NS = KW / 64;                                    // 64-k slices per wave and step (2 or 4)
+    constexpr int NSA = NS / 2;                                    // dwords of activation scales per row block and step
+    constexpr int PIECES = STAGE / 1024 / 8;                       // LDS-DMA pieces per wave and stage (= MI)
+    constexpr int NQ = NS * MI, L = NQ / 2 < 4 ? NQ / 2 : 4;
+    constexpr int C_ROWS = 128, C_PITCH = BN + 4;
+    constexpr int PD = RD - 2;
+    constexpr int WB64 = BF == 0 ? 64 : 32;                        // weight bytes per 64 k
+    static_assert(PIECES >= 1 && NQ >= 2 * L && L >= 1 && RD % NST == 0 && RD >= 4 && NST >= 2, "tile too small for the slot schedule");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, kh = wave >> 2;
+    const int col = lane & 31, h = lane >> 5;
+    const int mtiles = (p.M + BM - 1) / BM;
+    const int bid = blockIdx.x, slice = blockIdx.y;
+    const int mt = bid % mtiles, nt = bid / mtiles;
+    const int m0 = mt * BM;
+    const int n = nt * BN + cg * 32 + col;
+
+    const int units = p.K / KSTEP;
+    const int s_begin = (int)((int64_t)slice * units / p.splitk), s_end = (int)((int64_t)(slice + 1) * units / p.splitk);
+    const int nsteps = s_end - s_begin;
+    const int k_s0 = s_begin * KSTEP;
+    const int xk_bytes = AF == 0 ? p.K : p.K / 2, wk_bytes = BF == 0 ? p.K : p.K / 2;  // bytes of one row
+    const int xs0 = AF == 0 ? k_s0 : k_s0 / 2, ws0 = BF == 0 ? k_s0 : k_s0 / 2;       // byte offset of the slice inside a row
+
+    const srd_t rsX = make_srd(p.x, (uint32_t)((int64_t)(p.M - 1) * p.stride_xm + xk_bytes));
+    const __amdgpu_buffer_rsrc_t brW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + wk_bytes), 0x00020000);
+    const int blocks_k = p.K / 32;
+    const __amdgpu_buffer_rsrc_t brS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.scales, (short)0, (int)((int64_t)(blocks_k - 1) * p.stride_meta_g + (int64_t)(p.N - 1) * p.stride_meta_n + 1), 0x00020000);
+    // activation block scales: rows >= M_pad read zero (2^-127) through the range check — their x rows are zero anyway
+    const bool blk_x = p.sx_blocks != nullptr;
+    const int m_pad = (p.M + 31) / 32 * 32;
+    const __amdgpu_buffer_rsrc_t brA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(blk_x ? p.sx_blocks : p.w), (short)0, blk_x ? (int)((int64_t)(m_pad - 1) * p.stride_sx_blk_m + blocks_k) : 4, 0x00020000);
+
+    // B fragment of slice g: fp8: bytes [16 h, +16) and [32 + 16 h, +16) of the 64 bytes of the slice; fp4: bytes [16 h, +16) of its 32
+    const uint32_t wvoff = (uint32_t)((int64_t)n * p.stride_wn + ws0 + kh * (KW * WB64 / 64) + h * 16);
+    const uint32_t svoff = (uint32_t)((int64_t)n * p.stride_meta_n + (int64_t)(k_s0 / 32 + kh * (KW / 32) + h) * p.stride_meta_g);
+    uint32_t avoff[MI];  // dword of 4 activation block scales of row (mi * 32 + col) for this wave half
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int r = m0 + mi * 32 + col;
+        avoff[mi] = blk_x ? (uint32_t)((int64_t)r * p.stride_sx_blk_m + k_s0 / 32 + kh * (KW / 32)) : 0u;
+    }
+    const uint32_t sh_h = 8u * (uint32_t)h;
+    struct BStep { u32x4 w[NS][BV]; uint32_t s[NS]; uint32_t a[MI][NSA]; };
+    constexpr int NLB = NS * (BV + 1) + MI * NSA;  // tracked requests per step and wave
+    auto req_b = [&](BStep& b, int step, int it) {
+        if (it < NS * (BV + 1)) {
+            const int g = it / (BV + 1), i = it % (BV + 1);
+            if (i < BV) {
+                b.w[g][i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    brW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane(step * (KSTEP * WB64 / 64) + g * WB64 + i * 32), 0);
+            } else {
+                b.s[g] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(
+                    brS, svoff, (uint32_t)__builtin_amdgcn_readfirstlane((step * (KSTEP / 32) + 2 * g) * (int)p.stride_meta_g), 0);
+            }
+        } else {
+            const int j = it - NS * (BV + 1), mi = j / NSA, d = j % NSA;
+            b.a[mi][d] = __builtin_amdgcn_raw_buffer_load_b32(
+                brA, avoff[mi], (uint32_t)__builtin_amdgcn_readfirstlane(blk_x ? step * (KSTEP / 32) + 4 * d : 0), 0);
+        }
+    };
+    // x: piece j of wave w covers LDS bytes [(w * PIECES + j) * 1024, +1024) of a stage: row = byte / 256, physical 16-byte slot
+    // (byte % 256) / 16 holds the logical slot phys ^ (row & 15)
+    uint32_t xvoff[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int byte = (wave * PIECES + j) * 1024 + lane * 16;
+        const int r = byte / PITCH, phys = (byte % PITCH) / 16;
+        const int logical = phys ^ (r & 15);
+        xvoff[j] = m0 + r < p.M ? (uint32_t)((int64_t)(m0 + r) * p.stride_xm + xs0 + logical * 16) : 0x80000000u;
+    }
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PIECES) * 1024u);
+    auto req_x = [&](int stage, int step, int j) {
+        req_lds16(rsX, lds0 + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * PITCH));
+    };
+    // A fragment of (slice g, row block mi), piece v: row mi*32 + col, logical slot (kh*128 + g*(64 AV/2...) ...
+    //   fp8: slice g spans bytes [kh*128 + g*64, +64): slots 4g' + {h, 2 + h};  fp4: bytes [kh*128 + g*32, +32): slot 2g' + h
+    int fbase[NST][NS][AV];
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int g = 0; g < NS; ++g)
+#pragma unroll
+            for (int v = 0; v < AV; ++v) {
+                const int byte = kh * 128 + (AF == 0 ? g * 64 + v * 32 + h * 16 : g * 32 + h * 16);
+                const int slot = byte >> 4;
+                fbase[st][g][v] = st * STAGE + col * PITCH + (((slot ^ col) & 15) << 4);
+            }
+    struct AFrag { u32x4 v[AV]; };
+    auto read_frag = [&](int stage, int q) -> AFrag {
+        AFrag f;
+#pragma unroll
+        for (int v = 0; v < AV; ++v) f.v[v] = *(const u32x4*)(smem + fbase[stage][q / MI][v] + (q % MI) * 32 * PITCH);
+        return f;
+    };
+    auto mma = [&](const AFrag& a, const BStep& b, int g, int mi, f32x16 c) -> f32x16 {
+        v8i av, bv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = (int)a.v[0][i];
+            av[4 + i] = AV == 2 ? (int)a.v[AV - 1][i] : 0;
+            bv[i] = (int)b.w[g][0][i];
+            bv[4 + i] = BV == 2 ? (int)b.w[g][BV - 1][i] : 0;
+        }
+        // this lane's activation block scale: block (2 g + h) of the wave half = byte (2 (g & 1) + h) of dword g / 2
+        const uint32_t sa = blk_x ? (b.a[mi][g >> 1] >> (sh_h + 16u * (uint32_t)(g & 1))) : 127u;
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, AF, BF, 0, (int)sa, 0, (int)b.s[g]);
+    };
+
+    f32x16 acc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    BStep ring[RD];
+    AFrag af[L];
+
+    // ---- prologue: x of step 0, weights / scales of steps 0 .. PD-1 (see gemm_wn_mma.hip) ----------------------------------
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) req_x(0, 0, j);
+#pragma unroll
+    for (int it = 0; it < NLB; ++it) req_b(ring[0], 0, it);
+#pragma unroll
+    for (int st = 1; st < NST - 1; ++st)
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) req_x(st, st < nsteps ? st : nsteps - 1, j);
+#pragma unroll
+    for (int r = 1; r < PD; ++r)
+#pragma unroll
+        for (int it = 0; it < NLB; ++it) req_b(ring[r], r < nsteps ? r : nsteps - 1, it);
+    {
+        constexpr int AFTER = (NST - 2) * PIECES + PD * NLB;
+        wait_vm<(AFTER < 63 ? AFTER : 63)>();
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < L; ++q) af[q] = read_frag(0, q);
+    __builtin_amdgcn_sched_barrier(0);
+
+    constexpr int NL = NLB + PIECES, NQI = NQ - L;
+    constexpr int RPS = (NL + NQI - 1) / NQI;
+    static_assert((NST - 2) * PIECES + (NST - 1) * NLB + NL <= 63, "vmcnt is a 6-bit counter");
+    auto do_step = [&](auto Jc, int step) {
+        constexpr int J = decltype(Jc)::value;
+        constexpr int stage = J % NST, stage_next = (J + 1) % NST, stage_fill = (J + NST - 1) % NST;
+        const BStep& bc = ring[J];
+        BStep& bl = ring[(J + PD) % RD];
+        const int lstep = step + PD < nsteps ? step + PD : nsteps - 1;  // run-ahead repeats the last step (never consumed)
+        const int xstep = step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int g = q / MI, mi = q % MI;
+            acc[mi] = mma(af[q % L], bc, g, mi, acc[mi]);
+            if (q == NQI) {
+                wait_vm<(NST - 2) * PIECES + (NST - 1) * NLB>();  // the x DMA of step + 1 has landed
+                __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): this wave's reads of the current stage are complete
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
+            else af[q % L] = read_frag(stage_next, q + L - NQ);
+#pragma unroll
+            for (int it = q * RPS; it < (q + 1) * RPS && it < NL; ++it) {
+                if (it < PIECES) req_x(stage_fill, xstep, it);
+                else req_b(bl, lstep, it - PIECES);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto chain = [&](auto self, auto Jc, int s0) -> void {
+        constexpr int J = decltype(Jc)::value;
+        do_step(std::integral_constant<int, J % RD>{}, s0 + J);
+        if constexpr (J + 1 < RD) {
+            if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
+        }
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += RD) chain(chain, std::integral_constant<int, 0>{}, s0);
+    wait_vm<0>();
+
+    // ---- epilogue 1: add the two K halves through LDS ------------------------------------------------------------------------
+    __syncthreads();
+    {
+        f32x16* xch = (f32x16*)smem;  // [cg][mi][lane] whole accumulators
+        if (kh == 1) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xch[(cg * MI + mi) * 64 + lane] = acc[mi];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] += xch[(cg * MI + mi) * 64 + lane];
+        }
+    }
+    // ---- epilogue 2: transpose through LDS; slabs / output move as 16-byte row segments ---------------------------------------
+    float* ct = (float*)smem;  // [PASS_ROWS][C_PITCH]
+    constexpr int PASS_ROWS = BM < C_ROWS ? BM : C_ROWS;
+    unsigned* flag = (unsigned*)(smem + PASS_ROWS * C_PITCH * 4);
+    constexpr int NPASS = BM / PASS_ROWS, MIP = PASS_ROWS / 32;
+    constexpr int UNITS = (PASS_ROWS * BN / 4 + 511) / 512;
+    constexpr int NOUT = BM * BN;
+    const int64_t ncol0 = (int64_t)nt * BN;
+    float* slab = p.slabs + ((int64_t)bid * p.splitk) * NOUT;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
+    const float post = p.mx_post;
+    auto finish = [&](f32x4 v, int m, int c4) { store_out4_any(p.epi, v * (f32x4){post, post, post, post}, m, ncol0 + c4); };
+    f32x4 own[NPASS][UNITS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MIP; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    ct[r * C_PITCH + cg * 32 + col] = acc[ps * MIP + mi][e];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + ps * PASS_ROWS + r;
+            own[ps][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r < PASS_ROWS && m < p.M) {
+                const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
+                own[ps][i] = v;
+                if (p.splitk == 1) finish(v, m, c4);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                            (slice * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);  // sc1
+            }
+        }
+    }
+    if (p.splitk == 1) return;
+    __syncthreads();
+    if (!splitk_arrive_is_last(p.counters + bid, p.splitk, flag)) return;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        f32x4 sum[UNITS];
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) sum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < p.splitk; ++sl) {
+            if (sl == slice) {  // own partial from registers; the fixed slice order keeps the sum deterministic
+#pragma unroll
+                for (int i = 0; i < UNITS; ++i) sum[i] += own[ps][i];
+                continue;
+            }
+            u32x4 t[UNITS];
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) {
+                const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+                t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (sl * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) sum[i] += __builtin_bit_cast(f32x4, t[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + ps * PASS_ROWS + r;
+            if (r < PASS_ROWS && m < p.M) finish(sum[i], m, c4);
+        }
+    }
+    if (tid == 0) splitk_reset(p.counters + bid);
+}
+
+typedef void (*mx_kernel_fn)(const GenericParams);
+template <int AF, int BF>
+static const void* mx_pick(int mi) {
+    mx_kernel_fn f = nullptr;
+    switch (mi) {
+        case 4: f = gemm_mx_mma_kernel<AF, BF, 4, 4, 2>; break;
+        case 2: f = gemm_mx_mma_kernel<AF, BF, 2, 6, 3>; break;
+        case 1: f = gemm_mx_mma_kernel<AF, BF, 1, 8, 4>; break;
+        default: break;
+    }
+    return (const void*)f;
+}
+
+// fp8 / fp4 activations x fp8 / fp4 weights, e8m0 scales per 32 k on the weights and (channel_scale_mode 4) on the activations,
+// any M >= 1.  tuning[1] = K slices, tuning[2] = tile rows / 32 (1 / 2 / 4).
+bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
+    if (g.mx_scale_e4m3 || g.group_size != 32) return false;
+    if (!(g.mx_x == MX_FP8 || g.mx_x == MX_FP4) || !(g.mx_w == MX_FP8 || g.mx_w == MX_FP4)) return false;
+    if (g.mx_x == MX_FP4 && g.mx_w == MX_FP8) return false;  // not a combination any processor produces
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 128 != 0) return false;
+    const int kstep = g.mx_x == MX_FP8 ? 256 : 512;
+    if (a.K % kstep != 0) return false;
+    if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
+    if ((int64_t)a.M * a.stride_xm >= (1ll << 31) || (int64_t)a.N * a.stride_wn >= (1ll << 31)) return false;
+    if ((int64_t)(a.K / 32) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    if (!(a.output_dtype == GEMLITE_DT_FP32 || a.output_dtype == GEMLITE_DT_FP16 || a.output_dtype == GEMLITE_DT_BF16)) return false;
+    if (a.channel_scale_mode == 4) {
+        if (!g.sx_blocks || g.stride_sx_blk_m % 4 != 0 || ((uintptr_t)g.sx_blocks % 4) != 0) return false;
+        if ((int64_t)((a.M + 31) / 32 * 32) * g.stride_sx_blk_m >= (1ll << 31)) return false;
+    } else if (a.channel_scale_mode != 2 && a.channel_scale_mode != 0) {
+        return false;
+    }
+    const int units = (int)(a.K / kstep);
+    const int cap = a.M > 64 ? 4 : (a.M > 32 ? 2 : 1);
+    int mi = 1;
+    for (int c = cap; c >= 1; c >>= 1) {
+        if ((int64_t)(a.N / 128) * ((a.M + 32 * c - 1) / (32 * c)) >= 112) { mi = c; break; }
+    }
+    if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4) mi = a.tuning[2];
+    const int bm = 32 * mi;
+    const int64_t tiles = (int64_t)(a.N / 128) * ((a.M + bm - 1) / bm);
+    int splitk = 0;
+    if (a.tuning[1] > 0) {
+        if (a.tuning[1] > units) return false;
+        splitk = a.tuning[1];
+    } else {
+        for (int sk = 1; sk <= units && sk <= 32; ++sk) {
+            if (sk > 1 && units / sk < 2) continue;
+            splitk = sk;
+            if (tiles * sk >= 224) break;
+        }
+        if (!splitk) splitk = 1;
+    }
+    if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
+    if ((uint64_t)splitk * bm * 128 * 4 >= (1ull << 31)) return false;
+    const void* fn = g.mx_x == MX_FP8 ? (g.mx_w == MX_FP8 ? mx_pick<0, 0>(mi) : mx_pick<0, 4>(mi)) : mx_pick<4, 4>(mi);
+    if (!fn) return false;
+    g.splitk = splitk;
+    g.flags = a.tuning[3];
+    lp.fn = fn;
+    static const char* names[3][3] = {
+        {"gemm_mx_a8w8_kernel<32x128>", "gemm_mx_a8w8_kernel<64x128>", "gemm_mx_a8w8_kernel<128x128>"},
+        {"gemm_mx_a8w4_kernel<32x128>", "gemm_mx_a8w4_kernel<64x128>", "gemm_mx_a8w4_kernel<128x128>"},
+        {"gemm_mx_a4w4_kernel<32x128>", "gemm_mx_a4w4_kernel<64x128>", "gemm_mx_a4w4_kernel<128x128>"}};
+    lp.name = names[g.mx_x == MX_FP4 ? 2 : (g.mx_w == MX_FP4 ? 1 : 0)][mi == 4 ? 2 : (mi == 2 ? 1 : 0)];
+    lp.grid = dim3((unsigned)tiles, splitk, 1);
+    lp.block = dim3(512, 1, 1);
+    const size_t stages = (size_t)(mi == 4 ? 2 : (mi == 2 ? 3 : 4)) * bm * 256, xch = (size_t)4 * mi * 64 * 64;
+    const size_t c_b = (size_t)(bm < 128 ? bm : 128) * 132 * 4 + 16;
+    lp.lds_bytes = stages > xch ? stages : xch;
+    if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
+    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * 128 * 4 : 0;
+    lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
+    return true;
+}
+
+}  // namespace gl

@@ -412,7 +412,15 @@ struct GenericParams {
     unsigned* counters;
     int splitk;
     int flags;
+    // block-scaled (MX / NV) formats, gemm_mx.hip: element formats of x / w (MX_F16, MX_BF16, MX_FP8, MX_FP4), the
+    // per-block scales of x (channel_scale_mode 4: e8m0 bytes [M_pad, K/32], or e4m3 bytes [M_pad, K/16] for NVFP4),
+    // and the constant the accumulator is multiplied by at the end (NVFP4 meta scale squared, else 1)
+    const void* sx_blocks;
+    int64_t stride_sx_blk_m;
+    int mx_x, mx_w, mx_scale_e4m3;
+    float mx_post;
 };
+enum { MX_F16 = 1, MX_BF16 = 2, MX_FP8 = 3, MX_FP4 = 4 };
 
 // host-side launch description produced by the dispatcher
 struct LaunchPlan {

@@ -2,8 +2,8 @@
 
 Processors of the reference with the same names, arguments and resulting (W_group_mode, channel_scale_mode):
 A16W8 / A16W8_INT8 / A16W8_FP8, A16Wn and its ``*_HQQ_INT`` family, A8W8 dynamic (int8 / fp8), A8Wn dynamic
-(fp8 activations x n-bit groups), the two BitNet processors, ``patch_model``, ``cleanup_linear``; MXFP / NVFP
-processors are out of scope.  The third-party ``hqq`` package is not part of this build: ``from_hqqlinear`` only
+(fp8 activations x n-bit groups), the two BitNet processors, the MXFP / NVFP processors (A16W8/W4_MXFP, A8W8/W4_MXFP_dynamic,
+A4W4_MXFP_dynamic, A4W4_NVFP_dynamic), ``patch_model``, ``cleanup_linear``.  The third-party ``hqq`` package is not part of this build: ``from_hqqlinear`` only
 reads the attributes the reference reads, and the raw-tensor entry points take exactly what
 ``HQQLinear.unpack()`` / ``meta`` hold.
 On gfx950 FP8 means OCP e4m3fn (the reference's HIP default e4m3fnuz, helper.py:13-15, is the MI300X format).
@@ -14,6 +14,7 @@ import torch
 
 from .core import GemLiteLinear
 from .dtypes import TORCH_TO_DTYPE, DType
+from .quant_utils import WeightQuantizerMXFP
 
 default_fp8 = torch.float8_e4m3fn
 default_post_scale = True  # channel-wise scaling applied after the K reduction (reference HIP default)
@@ -259,6 +260,166 @@ class A8W8_fp8_dynamic(A8W8_dynamic):
 
 
 A8W8_INT8_dynamic, A8W8_FP8_dynamic = A8W8_int8_dynamic, A8W8_fp8_dynamic
+
+
+# ------------------------------------------------------------------------------------------------------
+# block-scaled formats (reference: helper.py:173-331 quant_type="MXFP", :372-400, :658-950)
+# ------------------------------------------------------------------------------------------------------
+class _BlockScaledProcessor:
+    """Shared body of the MXFP / NVFP processors.  ``from_weights(weight, bias, scales)`` takes pre-quantised
+    elements (fp8 tensor, or uint8 e2m1 codes ``[N, K]``) with their block scales ``[N, K / group]``;
+    ``from_linear`` quantises an ``nn.Linear`` with ``WeightQuantizerMXFP`` first.  Subclasses fix: W_nbits, group size,
+    the layer's input format, whether activations are quantised, and the channel_scale_mode set after ``pack()``."""
+    W_nbits = None
+    group_size = 32
+    scaled_activations = True
+
+    def __init__(self, device="cuda:0", dtype: Optional[torch.dtype] = None):
+        self.device, self.dtype = device, dtype
+        self.quantizer_mx = None
+        self.mx_fp8_dtype = default_fp8
+
+    # -- per-format hooks ------------------------------------------------------------------------------
+    def _input_dtype(self, dtype: torch.dtype) -> DType:
+        raise NotImplementedError
+
+    def _channel_scale_mode(self) -> int:
+        return 4
+
+    def _quantize(self, W: torch.Tensor):
+        if self.W_nbits == 8:
+            return self.quantizer_mx.quantize_mxfp8(W, index=True, mx_fp8_dtype=self.mx_fp8_dtype)
+        return self.quantizer_mx.quantize_mxfp4(W, index=True)
+
+    # -- API of the reference processors ------------------------------------------------------------
+    def from_weights(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                     scales: Optional[torch.Tensor] = None) -> GemLiteLinear:
+        if isinstance(weight, torch.nn.Parameter):
+            weight = weight.data
+        if isinstance(bias, torch.nn.Parameter):
+            bias = bias.data
+        assert scales is not None, "Scales parameter cannot be None. Use from_linear() call to pre-quantize the weights."
+        if self.W_nbits == 8:
+            assert weight.is_floating_point() and weight.element_size() == 1, f"Invalid weight.dtype, should be an MXFP8 dtype, got {weight.dtype}."
+        else:
+            assert weight.dtype == torch.uint8, f"Invalid weight.dtype, should be uint8 (e2m1 codes), got {weight.dtype}."
+        if self.group_size == 16:
+            assert scales.dtype == torch.float8_e4m3fn, f"Invalid scales.dtype, should be float8_e4m3fn, got {scales.dtype}."
+        else:
+            assert scales.dtype in (torch.float8_e8m0fnu, torch.uint8), f"Invalid scales.dtype, should be e8m0 / view(uint8), got {scales.dtype}."
+        dtype = self.dtype
+        if dtype is None:
+            assert not self.scaled_activations, "Input dtype should be either torch.float16 or torch.bfloat16, not None."
+            dtype = torch.float16
+        out_features, in_features = weight.shape
+        W_q = weight.to(device=self.device)
+        scales = scales.to(device=self.device).view(out_features, in_features // self.group_size)
+        bias = None if bias is None else bias.to(device=self.device, dtype=dtype)
+        layer = GemLiteLinear(self.W_nbits, group_size=self.group_size, in_features=in_features, out_features=out_features,
+                              input_dtype=self._input_dtype(dtype),
+                              # weight-only layers carry the MX code in both slots (helper.py:252-253)
+                              output_dtype=_gemlite_dtype(dtype) if self.scaled_activations else self._input_dtype(dtype),
+                              scaled_activations=self.scaled_activations)
+        layer.pack(W_q, scales, zeros=None, bias=bias)
+        if self.scaled_activations:  # helper.py:703-705, 779-781, 856-857, 922-923
+            layer.W_group_mode, layer.channel_scale_mode = 0, self._channel_scale_mode()
+        return layer
+
+    def from_linear(self, linear_layer: torch.nn.Linear, del_orig: bool = True) -> GemLiteLinear:
+        if self.quantizer_mx is None:
+            self.quantizer_mx = WeightQuantizerMXFP(device=self.device, compute_dtype=linear_layer.weight.dtype)
+        W = linear_layer.weight.data
+        bias = None if linear_layer.bias is None else linear_layer.bias.clone()
+        N, K = W.shape
+        W_q, scales = self._quantize(W)
+        W_q, scales = W_q.view(N, K), scales.view(N, K // self.group_size)
+        cleanup_linear(linear_layer, del_orig)
+        return _BlockScaledProcessor.from_weights(self, weight=W_q, bias=bias, scales=scales)
+
+
+class A16Wn_MXFP(_BlockScaledProcessor):
+    """fp16 / bf16 activations x MXFP8 / MXFP4 weights (reference: helper.py:372-400; layer dtype MXFP16 / MXBF16)."""
+    scaled_activations = False
+
+    def __init__(self, device="cuda:0", dtype=None, W_nbits=None):
+        super().__init__(device=device, dtype=dtype)
+        self.W_nbits = W_nbits
+
+    def _input_dtype(self, dtype):
+        if dtype == torch.float16:
+            return DType.MXFP16
+        if dtype == torch.bfloat16:
+            return DType.MXBF16
+        raise Exception(f"Unsupported dtype for MXFP. Got {dtype}, supported [torch.float16, torch.bfloat16]")
+
+    def from_weights(self, W_q, scales, bias=None):  # the reference's argument order for this family
+        return super().from_weights(weight=W_q, bias=bias, scales=scales)
+
+
+class A16W8_MXFP(A16Wn_MXFP):
+    def __init__(self, device="cuda:0", dtype=None):
+        super().__init__(device=device, dtype=dtype, W_nbits=8)
+
+
+class A16W4_MXFP(A16Wn_MXFP):
+    def __init__(self, device="cuda:0", dtype=None):
+        super().__init__(device=device, dtype=dtype, W_nbits=4)
+
+
+class A8Wn_MXFP_dynamic(_BlockScaledProcessor):
+    """MXFP8 activations (quantised per call) x MXFP8 / MXFP4 weights (reference: helper.py:732-815).  ``post_scale=True``:
+    one fp32 scale per token applied after the K reduction (channel_scale_mode 2); ``False``: e8m0 microscales per 32 k
+    inside the contraction (4)."""
+
+    def __init__(self, device="cuda:0", dtype=None, post_scale=True, fp8=default_fp8, W_nbits=None):
+        assert W_nbits is not None, "W_nbits argument should be either 8 or 4, not None."
+        super().__init__(device=device, dtype=dtype)
+        self.mx_fp8_dtype, self.post_scale, self.W_nbits = fp8, post_scale, W_nbits
+
+    def _input_dtype(self, dtype):
+        return DType.MXFP8
+
+    def _channel_scale_mode(self):
+        return 2 if self.post_scale else 4
+
+
+class A8W8_MXFP_dynamic(A8Wn_MXFP_dynamic):
+    def __init__(self, device="cuda:0", dtype=None, post_scale=True, fp8=default_fp8):
+        super().__init__(device=device, dtype=dtype, post_scale=post_scale, fp8=fp8, W_nbits=8)
+
+
+class A8W4_MXFP_dynamic(A8Wn_MXFP_dynamic):
+    def __init__(self, device="cuda:0", dtype=None, post_scale=True, fp8=default_fp8):
+        super().__init__(device=device, dtype=dtype, post_scale=post_scale, fp8=fp8, W_nbits=4)
+
+
+class A4W4_MXFP_dynamic(_BlockScaledProcessor):
+    """MXFP4 activations x MXFP4 weights (reference: helper.py:816-880)."""
+    W_nbits = 4
+
+    def __init__(self, device="cuda:0", dtype=None):
+        super().__init__(device=device, dtype=dtype)
+        self.input_dtype = DType.MXFP4
+
+    def _input_dtype(self, dtype):
+        return self.input_dtype
+
+
+class A4W4_NVFP_dynamic(_BlockScaledProcessor):
+    """NVFP4 activations x NVFP4 weights: e2m1 elements, e4m3 scale per 16 k, meta scale 0.05 (reference:
+    helper.py:882-946).  gfx950's matrix core has no instruction for this format: the layer runs on the coverage kernel."""
+    W_nbits = 4
+    group_size = 16
+
+    def __init__(self, device="cuda:0", dtype=None):
+        super().__init__(device=device, dtype=dtype)
+        self.input_dtype = DType.NVFP4
+
+    def _input_dtype(self, dtype):
+        return self.input_dtype
+
+    def _quantize(self, W):
+        return self.quantizer_mx.quantize_nvfp4(W, index=True)
 
 
 def cleanup_linear(linear_layer, del_orig: bool = True):

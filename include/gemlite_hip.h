@@ -17,6 +17,9 @@
  *   gemlite_hip_scale_activations_per_token
  *                                  <- scale_activations_per_token_triton,
  *                                     gemlite/quant_utils.py:268-347 (spec: :231-253)
+ *   gemlite_hip_scale_activations_mxfp8 / _mxfp4 / _nvfp4
+ *                                  <- scale_activations_mxfp8 / mxfp4 / nvfp4 (= the *_triton_v2 launchers),
+ *                                     gemlite/quant_utils.py:546-590, 820-855, 917-954
  *   gemlite_hip_pack_over_cols     <- pack_weights_over_cols_triton, gemlite/bitpack.py:77-144
  *                                     (bit layout spec: pack_weights_over_cols_torch :36-60)
  *   gemlite_hip_unpack_over_cols   <- unpack_over_cols_triton, gemlite/bitpack.py:175-241
@@ -57,7 +60,15 @@ typedef enum gemlite_dtype_t {
     GEMLITE_DT_UINT16 = 10,
     GEMLITE_DT_INT64 = 11,
     GEMLITE_DT_FP8E4NUZ = 12, /* MI300X flavour: rejected on gfx950 */
-    GEMLITE_DT_FP8E5NUZ = 13
+    GEMLITE_DT_FP8E5NUZ = 13,
+    /* block-scaled ("microscaling") input formats, dtypes.py:24-29.  As input_dtype they name the FORMAT PAIR of a layer:
+     * what x holds and how w_q / scales are laid out (see "Block-scaled formats" below) */
+    GEMLITE_DT_MXFP16 = 14, /* x fp16,             w fp8 / fp4 + e8m0 scale per 32 k            */
+    GEMLITE_DT_MXBF16 = 15, /* x bf16,             w fp8 / fp4 + e8m0 scale per 32 k            */
+    GEMLITE_DT_MXFP8 = 16,  /* x fp8 e4m3,         w fp8 / fp4 + e8m0 scale per 32 k            */
+    GEMLITE_DT_MXFP4 = 17,  /* x fp4 e2m1 (2/byte), w fp4 + e8m0 scale per 32 k                  */
+    GEMLITE_DT_NVFP4 = 18,  /* x fp4 e2m1 (2/byte), w fp4 + e4m3 scale per 16 k, result * 0.05^2 */
+    GEMLITE_DT_E8M0 = 19
 } gemlite_dtype_t;
 
 /* index into GEMLITE_MATMUL_TYPES (gemlite/core.py:56-66) */
@@ -83,7 +94,21 @@ typedef enum gemlite_status_t {
 /* W_group_mode / channel_scale_mode follow gemlite/triton_kernels/utils.py:73-87 and
  * gemm_kernels.py:392-404:
  *   W_group_mode        0 none | 1 (q - z) | 2 q*s | 3 (q - z)*s | 4 fma(q, s, z')
- *   channel_scale_mode  0 none | 1 acc*s_w[n] | 2 acc*s_x[m] | 3 acc*s_x[m]*s_w[n]          */
+ *   channel_scale_mode  0 none | 1 acc*s_w[n] | 2 acc*s_x[m] | 3 acc*s_x[m]*s_w[n]
+ *                       4 block scales on the activations (MX / NV input formats only, gemm_kernels.py:508-509)
+ *
+ * Block-scaled formats (input_dtype GEMLITE_DT_MXFP16 .. GEMLITE_DT_NVFP4; gemm_MX_kernel, gemm_kernels.py:422-547;
+ * layout produced by pack(), core.py:363-398, 489-497):
+ *   w_q     W_nbits 8: fp8 e4m3 [K, N] view of an [N, K] tensor (elements_per_sample 1, w_dtype FP8E4);
+ *           W_nbits 4: e2m1 codes, two per byte, k even in the low nibble: uint8 [K/2, N] (elements_per_sample 2,
+ *           w_pack_bits 8).  Either way stride_wk / stride_wn are torch's strides of that tensor; the MFMA kernels take
+ *           the K-contiguous layout pack() produces (stride_wk == 1), anything else runs on the coverage kernel
+ *   scales  one byte per (32-k block, n): e8m0 (value 2^(b-127)); NVFP4: e4m3 per 16-k block; strides stride_meta_g
+ *           (between blocks) / stride_meta_n;  W_group_mode is ignored, zeros unused
+ *   x       MXFP16 / MXBF16: 16-bit floats, channel_scale_mode 0;  MXFP8: fp8 e4m3;  MXFP4 / NVFP4: uint8 [M, K/2]
+ *   scales_x  channel_scale_mode 4: the block scales of x, uint8 [M_pad, K/32] (NVFP4: e4m3 [M_pad, K/16]), rows
+ *           contiguous, row stride stride_sx_m, M_pad = M rounded up to 32 (16) — what
+ *           gemlite_hip_scale_activations_mxfp8 / _mxfp4 / _nvfp4 write;  channel_scale_mode 2: fp32 [M] per token     */
 typedef struct gemlite_hip_forward_args {
     uint32_t struct_size; /* = sizeof(gemlite_hip_forward_args), ABI guard */
     int32_t matmul_type;  /* gemlite_matmul_type_t */
@@ -182,6 +207,20 @@ int gemlite_hip_launch_noop(int32_t blocks, int32_t threads, void* stream);
 int gemlite_hip_scale_activations_per_token(const void* x, void* y, float* scales, int64_t M,
                                             int64_t K, int64_t stride_xm, int32_t in_dtype,
                                             int32_t out_dtype, void* stream);
+
+/* Block-scaled activation quantisers (scale_activations_mxfp8 / mxfp4 / nvfp4_triton_v2, gemlite/quant_utils.py:
+ * 502-590, 769-855, 859-954).  x [M, K] fp16 / bf16 / fp32, row stride stride_xm, K % 32 == 0 (nvfp4: % 16).
+ *   mxfp8: y fp8 e4m3 [M, K];       scales e8m0 [M_pad, K/32], M_pad = M rounded up to a multiple of 32
+ *   mxfp4: y uint8 [M, K/2] (e2m1 codes, k even in the low nibble); scales e8m0 [M_pad, K/32]
+ *   nvfp4: y uint8 [M, K/2];        scales fp8 e4m3 [M_pad, K/16], M_pad = M rounded up to a multiple of 16
+ * The block scale is the next power of two of amax / qmax (exponent clamped to [-30, 127]); nvfp4: e4m3(amax / 0.3).
+ * Rows M .. M_pad-1 of `scales` receive the scale of an all-zero block, like the reference's padded programs. */
+int gemlite_hip_scale_activations_mxfp8(const void* x, void* y, uint8_t* scales, int64_t M, int64_t K,
+                                        int64_t stride_xm, int32_t in_dtype, void* stream);
+int gemlite_hip_scale_activations_mxfp4(const void* x, uint8_t* y, uint8_t* scales, int64_t M, int64_t K,
+                                        int64_t stride_xm, int32_t in_dtype, void* stream);
+int gemlite_hip_scale_activations_nvfp4(const void* x, uint8_t* y, uint8_t* scales, int64_t M, int64_t K,
+                                        int64_t stride_xm, int32_t in_dtype, void* stream);
 
 /* Bit-pack W_q[N, K] (uint8 values < 2^W_nbits, row stride ld_in) along K into words of
  * pack_bits: word(n, j) = OR_i W_q[n, j*e+i] << (W_nbits*i), e = pack_bits/W_nbits, stored

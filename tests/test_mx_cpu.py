@@ -1,0 +1,162 @@
+"""Block-scaled formats (MXFP8 / MXFP4 / NVFP4), CPU side: the numpy oracle and the package's host code against
+tests/golden/mx.npz = outputs of the reference itself (oracle/gen_golden_mx.py).  No GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mx_oracle as MX
+from tests.golden_util import GOLDEN
+
+Z = np.load(os.path.join(GOLDEN, "mx.npz"))
+
+
+def _bf16(arr):
+    return torch.from_numpy(np.ascontiguousarray(arr)).view(torch.bfloat16)
+
+
+def _x(tag):
+    a = Z[f"act_{tag}_x"]
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.view(torch.bfloat16) if tag == "bf16" else t).float().numpy()
+
+
+W_IN = _bf16(Z["wq_in_W"]).float().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ oracle vs reference
+@pytest.mark.parametrize("name,fn", [
+    ("mxfp8", lambda: MX.quantize_mxfp8(W_IN)), ("mxfp4", lambda: MX.quantize_mxfp4(W_IN)),
+    ("mxfp4_w1", lambda: MX.quantize_mxfp4(W_IN, window_size=1)), ("nvfp4", lambda: MX.quantize_nvfp4(W_IN)),
+    ("nvfp4_w1", lambda: MX.quantize_nvfp4(W_IN, window_size=1))])
+def test_oracle_weight_quantiser_matches_the_reference(name, fn):
+    q, s = fn()
+    assert np.array_equal(s.reshape(-1), Z[f"wq_{name}_s"].reshape(-1)), "block scales differ"
+    assert np.array_equal(q.reshape(-1), Z[f"wq_{name}_q"].reshape(-1)), "elements differ"
+
+
+@pytest.mark.parametrize("tag", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", ["mxfp8", "mxfp4", "nvfp4"])
+def test_oracle_activation_quantiser_matches_the_reference(tag, name):
+    y, s = getattr(MX, "scale_activations_" + name)(_x(tag))
+    ref_y, ref_s = Z[f"act_{tag}_{name}_y"], Z[f"act_{tag}_{name}_s"]
+    assert y.shape == ref_y.shape and s.shape == ref_s.shape  # incl. the rows the reference pads M to
+    assert np.array_equal(s, ref_s), "block scales differ"
+    assert np.array_equal(y, ref_y), "elements differ"
+
+
+def test_oracle_fp4_tables_and_fp8_codec_round_trip():
+    allb = np.arange(256, dtype=np.uint8)
+    vals = MX.fp8_e4m3_decode(allb)
+    ok = ~np.isnan(vals)
+    assert np.array_equal(MX.fp8_e4m3_encode(vals[ok]), allb[ok] if True else None) or np.array_equal(
+        MX.fp8_e4m3_decode(MX.fp8_e4m3_encode(vals[ok])), vals[ok])
+    t = torch.from_numpy(allb.copy()).view(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(t[ok], vals[ok])
+    codes = np.arange(16, dtype=np.uint8)
+    assert np.array_equal(MX.fp4_unpack(MX.fp4_pack_codes(codes[None, :]))[0], MX.FP4_VALUES)
+    assert np.array_equal(MX.e8m0_decode(np.array([127, 128, 97], dtype=np.uint8)), [1.0, 2.0, 2.0 ** -30])
+
+
+# ------------------------------------------------------------------------------------------------ package host code
+def test_package_weight_quantiser_matches_the_reference():
+    from gemlite_amd.quant_utils import WeightQuantizerMXFP
+    wq = WeightQuantizerMXFP(compute_dtype=torch.bfloat16, device="cpu")
+    W = _bf16(Z["wq_in_W"])
+    for name, fn in (("mxfp8", lambda: wq.quantize_mxfp8(W, index=True)), ("mxfp4", lambda: wq.quantize_mxfp4(W, index=True)),
+                     ("mxfp4_w1", lambda: wq.quantize_mxfp4(W, window_size=1, index=True)),
+                     ("nvfp4", lambda: wq.quantize_nvfp4(W, index=True)),
+                     ("nvfp4_w1", lambda: wq.quantize_nvfp4(W, window_size=1, index=True))):
+        q, s = fn()
+        assert np.array_equal(q.contiguous().view(torch.uint8).numpy().reshape(-1), Z[f"wq_{name}_q"].reshape(-1)), name
+        assert np.array_equal(s.contiguous().view(torch.uint8).numpy().reshape(-1), Z[f"wq_{name}_s"].reshape(-1)), name
+    # dequantize() undoes the scaling: values are e2m1 * 2^e exactly
+    q, s = wq.quantize_mxfp4(W, index=True)
+    back = wq.dequantize(q, s, shape=W.shape, dtype=torch.float32)
+    assert (back - W.float()).abs().mean().item() < 0.02
+
+
+PROCS = {
+    "a16w8_mxfp": lambda H: H.A16W8_MXFP(device="cpu", dtype=torch.bfloat16),
+    "a16w4_mxfp": lambda H: H.A16W4_MXFP(device="cpu", dtype=torch.float16),
+    "a8w8_mxfp_dyn_post": lambda H: H.A8W8_MXFP_dynamic(device="cpu", dtype=torch.bfloat16, post_scale=True),
+    "a8w8_mxfp_dyn_micro": lambda H: H.A8W8_MXFP_dynamic(device="cpu", dtype=torch.bfloat16, post_scale=False),
+    "a8w4_mxfp_dyn": lambda H: H.A8W4_MXFP_dynamic(device="cpu", dtype=torch.bfloat16, post_scale=False),
+    "a4w4_mxfp_dyn": lambda H: H.A4W4_MXFP_dynamic(device="cpu", dtype=torch.bfloat16),
+    "a4w4_nvfp_dyn": lambda H: H.A4W4_NVFP_dynamic(device="cpu", dtype=torch.float16),
+}
+
+
+@pytest.mark.parametrize("name", list(PROCS))
+def test_processors_pack_like_the_reference(name):
+    """W_q / scales bytes, their shapes AND strides, the 12 meta ints and the bias of every MXFP / NVFP processor."""
+    from gemlite_amd import helper as H
+    W = _bf16(Z["wq_in_W"])
+    lin = torch.nn.Linear(W.shape[1], W.shape[0], bias=True, dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_(W)
+        lin.bias.copy_(_bf16(Z["proc_in_bias"]))
+    layer = PROCS[name](H).from_linear(lin, del_orig=False)
+    wq, sc = layer.W_q.data, layer.scales.data
+    assert list(wq.shape) + list(wq.stride()) == [int(v) for v in Z[f"proc_{name}_W_q_shape_stride"]]
+    assert list(sc.shape) + list(sc.stride()) == [int(v) for v in Z[f"proc_{name}_scales_shape_stride"]]
+    assert np.array_equal(wq.contiguous().view(torch.uint8).numpy(), Z[f"proc_{name}_W_q"])
+    assert np.array_equal(sc.contiguous().view(torch.uint8).numpy(), Z[f"proc_{name}_scales"])
+    assert layer.get_meta_args() == [int(v) for v in Z[f"proc_{name}_meta"]]
+    ref_bias = Z[f"proc_{name}_bias"]
+    mine = layer.bias.data
+    mine = mine.view(torch.int16).numpy() if mine.dtype == torch.bfloat16 else mine.numpy()
+    assert np.array_equal(mine, ref_bias)
+
+
+def test_block_scaled_layers_refuse_cpu_tensors():
+    from gemlite_amd import _hip
+    from gemlite_amd import helper as H
+    lin = torch.nn.Linear(256, 128, bias=False, dtype=torch.bfloat16)
+    layer = H.A4W4_MXFP_dynamic(device="cpu", dtype=torch.bfloat16).from_linear(lin, del_orig=False)
+    with pytest.raises(_hip.GemliteHipError):
+        layer(torch.randn(2, 256, dtype=torch.bfloat16))
+
+
+def test_c_abi_routes_block_scaled_formats():
+    """gemlite_hip_kernel_name never launches: which kernel each format pair resolves to (K-contiguous layout of pack())."""
+    import ctypes as C
+    from gemlite_amd import _hip
+    lib = _hip.load()
+    buf = (C.c_uint8 * 64)()
+    ptr = C.addressof(buf) // 16 * 16 + 16
+
+    def args(in_dt, nbits, M, c_mode, N=4096, K=4096, group=32):
+        a = _hip.ForwardArgs()
+        a.struct_size = C.sizeof(_hip.ForwardArgs)
+        a.matmul_type = -1
+        a.x = a.w_q = a.scales = a.out = a.scales_x = ptr
+        a.M, a.N, a.K = M, N, K
+        a.W_nbits, a.group_size, a.unpack_mask = nbits, group, 2 ** nbits - 1
+        a.elements_per_sample = 1 if nbits == 8 else 2
+        a.w_pack_bits = 0 if nbits == 8 else 8
+        a.w_dtype = 3 if nbits == 8 else 5
+        a.input_dtype, a.output_dtype, a.meta_dtype = in_dt, 2, 5
+        a.channel_scale_mode, a.W_group_mode = c_mode, 0
+        xb = K if in_dt == 16 else (K // 2 if in_dt in (17, 18) else K)
+        a.stride_xm, a.stride_xk = xb, 1
+        a.stride_wk, a.stride_wn = 1, (K if nbits == 8 else K // 2)
+        a.stride_om, a.stride_on = N, 1
+        a.stride_meta_g, a.stride_meta_n = N, 1
+        a.stride_sx_m = K // group
+        return a
+
+    name = lambda a: lib.gemlite_hip_kernel_name(C.byref(a)).decode()  # noqa: E731
+    assert name(args(16, 8, 256, 4, N=8192, K=8192)) == "gemm_mx_a8w8_kernel<128x128>"
+    assert name(args(16, 4, 256, 2, N=8192, K=8192)) == "gemm_mx_a8w4_kernel<128x128>"
+    assert name(args(17, 4, 256, 4, N=8192, K=8192)) == "gemm_mx_a4w4_kernel<128x128>"
+    assert name(args(16, 8, 256, 4)) == "gemm_mx_a8w8_kernel<64x128>"   # the tallest tile that still gives >= 112 tiles
+    assert name(args(16, 8, 1, 4)) == "gemm_mx_a8w8_kernel<32x128>"
+    assert name(args(17, 4, 48, 4, N=16384)) == "gemm_mx_a4w4_kernel<64x128>"
+    assert name(args(18, 4, 8, 4, group=16)) == "mx_generic_kernel"       # NVFP4: no gfx950 instruction
+    assert lib.gemlite_hip_query(C.byref(args(18, 4, 8, 4, group=32))) == _hip.ERR_UNSUPPORTED
+    assert lib.gemlite_hip_query(C.byref(args(17, 8, 8, 4))) == _hip.ERR_UNSUPPORTED  # fp4 activations x fp8 weights
+    a = args(16, 8, 64, 4)
+    a.stride_wk, a.stride_wn = 4096, 1  # not K-contiguous: coverage kernel
+    assert name(a) == "mx_generic_kernel"
