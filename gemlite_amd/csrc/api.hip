@@ -24,6 +24,7 @@ bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, Lau
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
+bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 const void* mx_generic_kernel_fn();
 const void* act_quant_mx_kernel_fn(int mode);
 const void* generic_kernel_fn();
@@ -162,6 +163,18 @@ static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
     g.splitk = 1;
     r.gp = g;
     if (a.tuning[0] == 0 && plan_gemm_mx_mma(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
+    if (a.tuning[0] == 0 && (a.input_dtype == GEMLITE_DT_MXFP16 || a.input_dtype == GEMLITE_DT_MXBF16)) {
+        // 16-bit activations: the tiled MFMA kernel of the integer formats with the block-scaled weight geometry
+        WnParams p{};
+        p.x = a.x; p.w = (const uint32_t*)a.w_q; p.scales = a.scales; p.zeros = nullptr;
+        p.epi = g.epi;
+        p.epi.meta_dt = p.epi.out_dt;  // no channel scales: keeps the typed epilogue
+        p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
+        p.group_size = 32;
+        p.stride_xm = a.stride_xm; p.stride_xk = a.stride_xk; p.stride_wk = 1;
+        p.flags = a.tuning[3];
+        if (plan_gemm_wn_mma_mx(a, p, r.lp)) { r.kind = K_TILED_WN; r.wn = p; return; }
+    }
     if (a.M > 65535) { r.status = GEMLITE_ERR_BAD_SHAPE; return; }
     r.kind = K_GENERIC;
     r.lp.fn = mx_generic_kernel_fn();

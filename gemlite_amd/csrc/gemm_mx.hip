@@ -116,9 +116,11 @@ __global__ __launch_bounds__(256) void act_quant_mx_kernel(const void* x, uint8_
             const float q = __fdiv_rn(v[e], s), a = fabsf(q);
             uint32_t c = (a > 0.25f) + (a > 0.75f) + (a > 1.25f) + (a > 1.75f) + (a > 2.5f) + (a > 3.5f) + (a > 5.0f) + (a > 7.0f);
             if (!(q >= 0.f)) c += 8u;
-            c &= 0xFFu;
-            if ((e & 7) == 0) o[e >> 3] = c;
-            else o[e >> 3] += c << (4 * (e & 7));  // += : a code of 16 (|q| > 7 and negative) carries like lo | (hi << 4) on uint8 pairs
+            // byte = lo | (hi << 4) in uint8 arithmetic, like the reference's pack (quant_utils.py:805-806): a code above 15 —
+            // only when the block scale was floored (|q| > 7) — spills into / out of the byte exactly as it does there
+            const uint32_t part = ((e & 1) ? ((c << 4) & 0xFFu) : c) << (8 * ((e & 7) >> 1));
+            if ((e & 7) == 0) o[e >> 3] = part;
+            else o[e >> 3] |= part;
         }
         uint8_t* dst = y + m * (K / 2) + g * (G / 2);
         if (G == 32) *(u32x4*)dst = (u32x4){o[0], o[1], o[2], o[3]};

@@ -92,6 +92,47 @@ struct Geo {
     }
 };
 
+// Block-scaled weights under 16-bit activations (A16W8 / A16W4 MXFP, helper.py:372-400): NBITS = 108 (fp8 e4m3) / 104 (e2m1
+// codes, two per byte).  These rows are K-CONTIGUOUS per output column (core.py:363-398): lane half h owns the 32 k of ONE
+// microscaling block of the 64-k sub-block — 32 / 16 consecutive bytes = WPL dwords, fetched as 16-byte pieces — and
+// slice u is its k [8u, 8u + 8): k_of(u, h) = 32 h + 8 u (any k order works as long as A follows).  E = 1: "packed rows"
+// are k itself.
+constexpr int MXW8 = 108, MXW4 = 104;
+template <>
+struct Geo<MXW8> {
+    static constexpr int E = 1, WPL = 8, ROWS = 64, HS = 0, WBYTES64 = 64;
+    static __device__ __forceinline__ constexpr int row_of(int) { return 0; }
+    static __device__ __forceinline__ constexpr int k_of(int u, int h) { return 32 * h + 8 * u; }
+};
+template <>
+struct Geo<MXW4> {
+    static constexpr int E = 1, WPL = 4, ROWS = 64, HS = 0, WBYTES64 = 32;
+    static __device__ __forceinline__ constexpr int row_of(int) { return 0; }
+    static __device__ __forceinline__ constexpr int k_of(int u, int h) { return 32 * h + 8 * u; }
+};
+// pair j (k = 2j, 2j + 1 of the slice) of a block-scaled fragment: hardware converters with the block scale applied
+// (v_cvt_scalef32_pk_{bf16,f16}_{fp8,fp4}; operand order measured with scripts/ubench/probe_mx.hip)
+template <typename Tag, int NBITS, int J>
+__device__ __forceinline__ uint32_t mx_pair_c(const uint32_t* w, int u, float sc) {  // the selectors are immediates
+    if constexpr (NBITS == MXW4) {
+        if constexpr (std::is_same<Tag, bf16_tag>::value) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w[u], sc, J));
+        else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w[u], sc, J));
+    } else {
+        const uint32_t src = w[2 * u + (J >> 1)];
+        if constexpr (std::is_same<Tag, bf16_tag>::value) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc, (J & 1) != 0));
+        else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(src, sc, (J & 1) != 0));
+    }
+}
+template <typename Tag, int NBITS>
+__device__ __forceinline__ uint32_t mx_pair(const uint32_t* w, int u, int j, float sc) {
+    switch (j) {
+        case 0: return mx_pair_c<Tag, NBITS, 0>(w, u, sc);
+        case 1: return mx_pair_c<Tag, NBITS, 1>(w, u, sc);
+        case 2: return mx_pair_c<Tag, NBITS, 2>(w, u, sc);
+        default: return mx_pair_c<Tag, NBITS, 3>(w, u, sc);
+    }
+}
+
 // ---- integer codes of slice u as bytes: byte j of `ev` = code 2j, byte j of `od` = code 2j + 1 (natural k order) -----
 template <int NBITS>
 struct Extract;
@@ -233,6 +274,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     typedef typename XO::frag_t frag_t;
     constexpr int ES = XO::ES;  // bytes per activation
     constexpr int BM = 32 * MI, KW = KSTEP / 2, SUB = KW / 64, WPL = G::WPL;
+    constexpr bool MXW = NBITS == MXW8 || NBITS == MXW4;  // block-scaled K-contiguous weights (16-bit activations only)
+    static_assert(!MXW || XDT == 0, "block-scaled weights on this kernel: 16-bit activations");
     constexpr int PITCH = KSTEP * ES, STAGE = BM * PITCH;  // bytes per row / per stage of x
     constexpr int SWZ = (PITCH / 16 < 16 ? PITCH / 16 : 16) - 1;  // XOR swizzle of the 16-byte slots inside a row (8 or 16 slots)
     constexpr int PIECES = STAGE / 1024 / 8;               // 1-KiB LDS-DMA pieces per wave and stage
@@ -298,29 +341,52 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
 
     // ---- B stream --------------------------------------------------------------------------------------------------
     struct BStep { uint32_t w[SUB][WPL]; uint32_t s[SUB], z[SUB]; };
-    const uint32_t wvoff = (uint32_t)(G::HS * h * sw + n) * 4u;
-    const uint32_t mvoff = (uint32_t)n * 2u;
     const int wave_row0 = kh * (KW / G::E);  // first packed row of this wave's half inside a step
-    constexpr int NLB = SUB * (WPL + 2);   // weight / metadata requests per step and wave
+    constexpr int NREQ = MXW ? WPL / 4 + 1 : WPL + 2;  // requests per sub-block: MX = 16-byte pieces + one scale byte
+    constexpr int NLB = SUB * NREQ;                    // weight / metadata requests per step and wave
     // request `it` (0 .. NLB-1) of step `step` (slice-relative) into ring slot b
     // (the weight / metadata requests are ordinary buffer loads the compiler tracks: it retires them with its own COUNTED
     //  vmcnt — it cannot see the asm DMAs, so its count can only over-wait, never under-wait — and it never copies a
     //  register whose load is still in flight, which it is free to do with the output of an asm load)
-    const __amdgpu_buffer_rsrc_t brW =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)row_s0 * sw), (short)0, nsteps * STEP_ROWS * sw * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t brS = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(need_s ? p.scales : (const void*)p.w), (short)0, need_s ? meta_bytes : 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t brZ = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(need_z ? p.zeros : (const void*)p.w), (short)0, need_z ? meta_bytes : 4, 0x00020000);
+    uint32_t wvoff, mvoff;
+    __amdgpu_buffer_rsrc_t brW, brS, brZ;
+    if constexpr (MXW) {
+        constexpr int WB = G::WBYTES64;  // weight bytes per 64 k
+        wvoff = (uint32_t)((int64_t)n * p.stride_wn_b + (int64_t)(k_s0 + kh * KW) * WB / 64 + h * (WB / 2));
+        mvoff = (uint32_t)((int64_t)n * p.stride_meta_n + (int64_t)((k_s0 + kh * KW) / 32 + h) * p.stride_meta_g);
+        brW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn_b + (int64_t)p.K * WB / 64), 0x00020000);
+        brS = __builtin_amdgcn_make_buffer_rsrc((void*)p.scales, (short)0,
+                                                (int)((int64_t)(p.K / 32 - 1) * p.stride_meta_g + (int64_t)(p.N - 1) * p.stride_meta_n + 1), 0x00020000);
+        brZ = brS;
+    } else {
+        wvoff = (uint32_t)(G::HS * h * sw + n) * 4u;
+        mvoff = (uint32_t)n * 2u;
+        brW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)row_s0 * sw), (short)0, nsteps * STEP_ROWS * sw * 4, 0x00020000);
+        brS = __builtin_amdgcn_make_buffer_rsrc((void*)(need_s ? p.scales : (const void*)p.w), (short)0, need_s ? meta_bytes : 4, 0x00020000);
+        brZ = __builtin_amdgcn_make_buffer_rsrc((void*)(need_z ? p.zeros : (const void*)p.w), (short)0, need_z ? meta_bytes : 4, 0x00020000);
+    }
     auto req_b = [&](BStep& b, int step, int it) {
-        const int sb = it / (WPL + 2), i = it % (WPL + 2);
-        const int rb = step * STEP_ROWS + wave_row0 + sb * G::ROWS;  // packed row (slice-relative) of the sub-block
-        if (i < WPL) {
-            b.w[sb][i] = __builtin_amdgcn_raw_buffer_load_b32(brW, wvoff, (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((rb + G::row_of(i)) * sw * 4), 0);
+        const int sb = it / NREQ, i = it % NREQ;
+        if constexpr (MXW) {
+            constexpr int WB = G::WBYTES64;
+            if (i < WPL / 4) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                    brW, wvoff, (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((step * KSTEP + sb * 64) * WB / 64 + i * 16), 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b.w[sb][4 * i + t] = v[t];
+            } else {
+                b.s[sb] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(
+                    brS, mvoff, (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane(((step * KSTEP + sb * 64) / 32) * (int)p.stride_meta_g), 0);
+            }
         } else {
-            const uint32_t mo = (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((((k_s0 + rb * G::E) >> p.gs_shift) * ms) * 2);
-            if (i == WPL) b.s[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brS, mvoff, mo, 0);
-            else b.z[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brZ, mvoff, mo, 0);
+            const int rb = step * STEP_ROWS + wave_row0 + sb * G::ROWS;  // packed row (slice-relative) of the sub-block
+            if (i < WPL) {
+                b.w[sb][i] = __builtin_amdgcn_raw_buffer_load_b32(brW, wvoff, (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((rb + G::row_of(i)) * sw * 4), 0);
+            } else {
+                const uint32_t mo = (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((((k_s0 + rb * G::E) >> p.gs_shift) * ms) * 2);
+                if (i == WPL) b.s[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brS, mvoff, mo, 0);
+                else b.z[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brZ, mvoff, mo, 0);
+            }
         }
     };
     // ---- A stream: LDS-DMA pieces.  Piece j of wave w covers LDS bytes [(w * PIECES + j) * 1024, +1024) of a stage;
@@ -362,22 +428,32 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     uint32_t ev = 0, od = 0;  // codes of the slice being dequantised
     // Dequantisation of one slice (-> 4 registers of a B fragment) is cut into pieces that hide behind the MI MFMAs of
     // the slice before it: piece 0 = (scale, zero) of the sub-block + code extraction, then the 4 pairs.
+    float mx_sc = 0.f;  // block scale of the sub-block being dequantised (MX)
     auto deq_piece = [&](const BStep& b, int g, int mi, frag_t& out) {
         const int sb = g >> 2, u = g & 3;
-        if (mi == 0) {
-            if (u == 0) {  // (scale, zero) of the sub-block; slices 1..3 reuse them
-                const float sc = need_s ? TR::to_float((uint16_t)b.s[sb]) : 1.f;
-                const float zr = need_z ? TR::to_float((uint16_t)b.z[sb]) : scalar_zero;
-                cv.set(sc, zr, u13, u4);
-            }
-            Extract<NBITS>::run(b.w[sb], u, ev, od);
-            cv.prep(ev, od);
-            // opaque to the optimiser: otherwise byte i becomes v_bfe_u32 + v_cvt_f32_ubyte0 instead of one v_cvt_f32_ubyte<i>
-            opaque2(ev, od);
-        }
+        if constexpr (MXW) {
+            // e8m0 byte -> fp32 2^(b - 127): the byte IS the exponent field (0 -> 0.0 instead of 2^-127: the quantisers
+            // floor the scale at 2^-30)
+            if (mi == 0 && u == 0) mx_sc = __builtin_bit_cast(float, b.s[sb] << 23);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((MI == 8 ? j + 1 : (j * MI) / 4) == mi) cv.put(out, ev, od, j);
+            for (int j = 0; j < 4; ++j)
+                if ((MI == 8 ? j + 1 : (j * MI) / 4) == mi) out[j] = mx_pair<Tag, NBITS>(b.w[sb], u, j, mx_sc);
+        } else {
+            if (mi == 0) {
+                if (u == 0) {  // (scale, zero) of the sub-block; slices 1..3 reuse them
+                    const float sc = need_s ? TR::to_float((uint16_t)b.s[sb]) : 1.f;
+                    const float zr = need_z ? TR::to_float((uint16_t)b.z[sb]) : scalar_zero;
+                    cv.set(sc, zr, u13, u4);
+                }
+                Extract<NBITS>::run(b.w[sb], u, ev, od);
+                cv.prep(ev, od);
+                // opaque to the optimiser: otherwise byte i becomes v_bfe_u32 + v_cvt_f32_ubyte0 instead of one v_cvt_f32_ubyte<i>
+                opaque2(ev, od);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((MI == 8 ? j + 1 : (j * MI) / 4) == mi) cv.put(out, ev, od, j);
+        }
     };
 
     BStep ring[RD];
@@ -622,8 +698,9 @@ static const void* mma_pick_mi(int mi) {
     switch (mi) {
         case 8: f = gemm_wn_mma_kernel<Tag, NBITS, 8, 128, 4, 2, 0, XDT>; break;
         case 4: f = gemm_wn_mma_kernel<Tag, NBITS, 4, 128, 6, 3, 0, XDT>; break;
-        case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256, 6, (NBITS == 8 ? 2 : 3), 0, XDT>; break;
-        case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256, (NBITS == 8 ? 6 : 8), (NBITS == 8 ? 2 : 4), 0, XDT>; break;
+        // 8 dwords per lane and sub-block (8-bit words, fp8 MX rows): a shallower ring keeps the registers in budget
+        case 2: f = gemm_wn_mma_kernel<Tag, NBITS, 2, 256, 6, (mma::Geo<NBITS>::WPL == 8 ? 2 : 3), 0, XDT>; break;
+        case 1: f = gemm_wn_mma_kernel<Tag, NBITS, 1, 256, (mma::Geo<NBITS>::WPL == 8 ? 6 : 8), (mma::Geo<NBITS>::WPL == 8 ? 2 : 4), 0, XDT>; break;
         default: break;
     }
     return (const void*)f;
@@ -647,6 +724,82 @@ static const void* mma_pick(int nbits, int mi, int xdt) {
         case 8: return mma_pick_mi<Tag, 8, 0>(mi);
         default: return nullptr;
     }
+}
+
+// 16-bit activations x block-scaled weights (layer formats MXFP16 / MXBF16: A16W8_MXFP, A16W4_MXFP): the same kernel with the
+// K-contiguous weight geometry (Geo<MXW8 / MXW4>) — the weights are converted by v_cvt_scalef32_pk_* with their block scale, 4
+// VALU per fragment instead of 23.  `p` arrives with x / w / scales / epilogue / M / N / K / strides filled in by the caller.
+// tuning[1] = K slices, tuning[2] = tile rows / 32.
+bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
+    const bool f16 = a.input_dtype == GEMLITE_DT_MXFP16;
+    if (!f16 && a.input_dtype != GEMLITE_DT_MXBF16) return false;
+    if (a.output_dtype != (f16 ? GEMLITE_DT_FP16 : GEMLITE_DT_BF16)) return false;  // typed epilogue
+    const int nb = a.W_nbits == 8 ? mma::MXW8 : mma::MXW4;
+    if (a.group_size != 32 || a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % mma::BN != 0 || a.K % 128 != 0) return false;
+    if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0 || ((uintptr_t)a.w_q % 16) != 0 || a.stride_wn % 16 != 0) return false;
+    if (((uintptr_t)a.out % 8) != 0 || (a.stride_om * 2) % 8 != 0) return false;
+    if ((int64_t)a.N * a.stride_wn >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31)) return false;
+    if ((int64_t)(a.K / 32) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    auto kstep_of = [](int c) { return c >= 4 ? 128 : 256; };
+    const int cap = a.M > 128 ? 8 : (a.M > 64 ? 4 : (a.M > 32 ? 2 : 1));
+    // cheap conversion: the tallest tile that still gives >= 128 tiles (else >= 64, else the tallest M fills), then the
+    // fewest K slices that give >= 224 blocks while a slice keeps >= 4 steps (the rule of the other non-4-bit widths)
+    int mi = cap;
+    for (int want = 128; want >= 64; want >>= 1) {
+        int found = 0;
+        for (int c = cap; c >= 2 && !found; c >>= 1)
+            if (a.K % kstep_of(c) == 0 && (a.N / mma::BN) * ((a.M + 32 * c - 1) / (32 * c)) >= want) found = c;
+        if (found) { mi = found; break; }
+    }
+    if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4 || a.tuning[2] == 8) mi = a.tuning[2];
+    else if (a.tuning[2] != 0) return false;
+    if (a.K % kstep_of(mi) != 0) {
+        if (a.tuning[2] != 0) return false;
+        mi = mi < 4 ? 4 : mi;
+    }
+    const int ks = kstep_of(mi), bm = 32 * mi;
+    const int units = (int)(a.K / ks);
+    const int64_t tiles = (int64_t)(a.N / mma::BN) * ((a.M + bm - 1) / bm);
+    int splitk = 0;
+    if (a.tuning[1] > 0) splitk = a.tuning[1];
+    else {
+        for (int sk = 1; sk <= units && sk <= 32; ++sk) {
+            if (sk > 1 && units / sk < 4) continue;
+            splitk = sk;
+            if (tiles * sk >= 224) break;
+        }
+        if (!splitk) splitk = 1;
+    }
+    if (splitk > units) return false;
+    if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
+    if ((uint64_t)splitk * bm * mma::BN * 4 >= (1ull << 31)) return false;
+    const void* fn = f16 ? (nb == mma::MXW8 ? mma_pick_mi<half_tag, mma::MXW8, 0>(mi) : mma_pick_mi<half_tag, mma::MXW4, 0>(mi))
+                         : (nb == mma::MXW8 ? mma_pick_mi<bf16_tag, mma::MXW8, 0>(mi) : mma_pick_mi<bf16_tag, mma::MXW4, 0>(mi));
+    if (!fn) return false;
+    p.splitk = splitk;
+    p.rows_per_slice = (int)a.K;  // E = 1: "packed rows" are k
+    p.stride_wn_b = a.stride_wn;  // 1-byte elements
+    p.stride_meta_n = a.stride_meta_n;
+    p.stride_meta_g = a.stride_meta_g;
+    p.w_mode = 2;
+    p.gs_shift = 5;
+    lp.fn = fn;
+    static const char* names[2][4] = {
+        {"gemm_a16w8_mxfp_kernel<32x128>", "gemm_a16w8_mxfp_kernel<64x128>", "gemm_a16w8_mxfp_kernel<128x128>", "gemm_a16w8_mxfp_kernel<256x128>"},
+        {"gemm_a16w4_mxfp_kernel<32x128>", "gemm_a16w4_mxfp_kernel<64x128>", "gemm_a16w4_mxfp_kernel<128x128>", "gemm_a16w4_mxfp_kernel<256x128>"}};
+    lp.name = names[nb == mma::MXW8 ? 0 : 1][mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))];
+    lp.grid = dim3((unsigned)tiles, splitk, 1);
+    lp.block = dim3(512, 1, 1);
+    const bool w8 = nb == mma::MXW8;
+    const int nst = mi == 8 ? 2 : (mi == 4 ? 3 : (w8 ? 2 : (mi == 2 ? 3 : 4)));  // LDS stages of x (mma_pick_mi)
+    const size_t stages = (size_t)nst * bm * ks * 2;
+    const size_t xch = (size_t)4 * mi * 4 * 64 * 16;
+    const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * mma::C_PITCH * 4 + 16;
+    lp.lds_bytes = stages > xch ? stages : xch;
+    if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
+    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * mma::BN * 4 : 0;
+    lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
+    return true;
 }
 
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {

@@ -357,6 +357,7 @@ struct WnParams {
     int splitk;          // K slices (gridDim.y)
     int rows_per_slice;  // packed rows per K slice
     int64_t stride_xm, stride_xk, stride_wk, stride_meta_g;
+    int64_t stride_wn_b, stride_meta_n;  // block-scaled K-contiguous weights (gemm_wn_mma.hip MXW): bytes between weight rows / scale columns
     int flags;           // experiment switches forwarded from tuning[3] (kernel-specific)
     int gs_shift;        // log2(group_size); 31 when one metadata row spans all of K; -1 (not a power of two)
                          // sends the problem to the coverage kernel — an integer division per metadata load costs
