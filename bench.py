@@ -41,6 +41,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak
 INT8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (2x bf16, MI355X_MICROARCH.md)
+MXFP8_MFMA_PEAK_TFLOPS = 5000.0   # block-scaled fp8 (v_mfma_scale_*_f8f6f4), dense
+MXFP4_MFMA_PEAK_TFLOPS = 10000.0  # block-scaled fp4 / fp6, dense
 
 WORKLOADS = {
     # name: (N, K, nbits, group, M, dtype, layers, bound)
@@ -65,8 +67,24 @@ WORKLOADS = {
     "a8w4_4096_m16": (4096, 4096, 4, 128, 16, "fp8", 32, "hbm"),
     "a8w4_4096_m256": (4096, 4096, 4, 128, 256, "fp8", 32, "mfma"),
     "a8w4_8192_m256": (8192, 8192, 4, 128, 256, "fp8", 8, "mfma"),
+    # block-scaled formats (helper.py:372-400, 658-950): group = 32, weights quantised by WeightQuantizerMXFP.  dtype names the
+    # layer: mxa8 = MXFP8 activations with e8m0 microscales (pre-quantised outside the timed matmul), mxa4 = MXFP4 activations,
+    # mxa16 = bf16 activations x MX weights
+    "mx_a8w8_4096_m1": (4096, 4096, 8, 32, 1, "mxa8", 16, "hbm"),
+    "mx_a8w8_4096_m256": (4096, 4096, 8, 32, 256, "mxa8", 16, "mfma"),
+    "mx_a8w8_8192_m256": (8192, 8192, 8, 32, 256, "mxa8", 4, "mfma"),
+    "mx_a8w8_8192_m2048": (8192, 8192, 8, 32, 2048, "mxa8", 4, "mfma"),
+    "mx_a8w4_8192_m256": (8192, 8192, 4, 32, 256, "mxa8", 8, "mfma"),
+    "mx_a4w4_4096_m1": (4096, 4096, 4, 32, 1, "mxa4", 32, "hbm"),
+    "mx_a4w4_8192_m256": (8192, 8192, 4, 32, 256, "mxa4", 8, "mfma"),
+    "mx_a4w4_8192_m2048": (8192, 8192, 4, 32, 2048, "mxa4", 8, "mfma"),
+    "mx_a16w4_4096_m1": (4096, 4096, 4, 32, 1, "mxa16", 32, "hbm"),
+    "mx_a16w4_4096_m256": (4096, 4096, 4, 32, 256, "mxa16", 32, "mfma"),
+    "mx_a16w4_8192_m256": (8192, 8192, 4, 32, 256, "mxa16", 8, "mfma"),
+    "mx_a16w8_8192_m256": (8192, 8192, 8, 32, 256, "mxa16", 4, "mfma"),
 }
-PREQUANT = ("int8", "fp8")  # workloads whose x is quantised once, outside the timed matmul
+PREQUANT = ("int8", "fp8", "mxa8", "mxa4")  # workloads whose x is quantised once, outside the timed matmul
+MX = ("mxa8", "mxa4", "mxa16")
 
 
 def algorithmic_bytes(M, N, K, nbits, group, esize=2):
@@ -81,6 +99,9 @@ def work_per_launch(name):
         nbytes = K * N + N * 4 + M * K + M * 4 + M * N * 2
     if dt == "fp8":  # packed W + fp16 group metadata + fp8 x + fp32 token scales + fp16 out
         nbytes = K * N * nbits // 8 + 2 * (K // group) * N * 2 + M * K + M * 4 + M * N * 2
+    if dt in MX:  # W elements + one scale byte per 32 k, x elements (+ its scale bytes), bf16 out
+        xb = {"mxa8": M * K + M * K // 32, "mxa4": M * K // 2 + M * K // 32, "mxa16": M * K * 2}[dt]
+        nbytes = K * N * nbits // 8 + (K // 32) * N + xb + M * N * 2
     return nbytes, 2 * M * N * K
 
 
@@ -90,6 +111,24 @@ def build_layers(name, device, layers=None):
 
     N, K, nbits, group, M, dt, nl, bound = WORKLOADS[name]
     layers = nl if layers is None else layers
+    if dt in MX:
+        from gemlite_amd import helper as H
+        from gemlite_amd.quant_utils import scale_activations_mxfp4, scale_activations_mxfp8
+        g = torch.Generator(device=device).manual_seed(0)
+        tdt = torch.bfloat16
+        proc = {"mxa8": lambda: H.A8Wn_MXFP_dynamic(device=device, dtype=tdt, post_scale=False, W_nbits=nbits),
+                "mxa4": lambda: H.A4W4_MXFP_dynamic(device=device, dtype=tdt),
+                "mxa16": lambda: H.A16Wn_MXFP(device=device, dtype=tdt, W_nbits=nbits)}[dt]()
+        mods = []
+        for _ in range(layers):
+            lin = torch.nn.Linear(K, N, bias=False, device=device, dtype=tdt)
+            with torch.no_grad():
+                lin.weight.copy_((torch.randn(N, K, generator=g, device=device) / 30).to(tdt))
+            mods.append(proc.from_linear(lin, del_orig=True))
+        x = (torch.randn(M, K, generator=g, device=device) / 10).to(tdt)
+        if dt == "mxa16":
+            return mods, x
+        return mods, (scale_activations_mxfp8(x) if dt == "mxa8" else scale_activations_mxfp4(x))
     if dt == "int8":
         from gemlite_amd.helper import A8W8_int8_dynamic
         from gemlite_amd.quant_utils import scale_activations_per_token
@@ -223,10 +262,12 @@ class Runner:
         a.x = a.out = 0x1000
         a.M = x.shape[0]
         from gemlite_amd.dtypes import TORCH_TO_DTYPE
-        a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
+        a.input_dtype = lin.input_dtype.value if self.dt in MX else TORCH_TO_DTYPE[x.dtype].value
         a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = x.stride(0), x.stride(1), a.N, 1
         if self.dt in PREQUANT:
             a.scales_x = 0x1000
+            if self.dt in MX:
+                a.stride_sx_m = self.x[1].stride(0)
         import gemlite_amd.core as core
         t = core.TUNING_OVERRIDE or core.lookup_tuning(-1, a.M, a)
         if t:
@@ -245,7 +286,9 @@ class Runner:
         if self.bound == "hbm":
             peak, unit, work = HBM_PEAK_GBS, "GB/s", self.bytes / 1e9
         else:
-            peak, unit, work = (INT8_MFMA_PEAK_TOPS if self.dt in PREQUANT else MFMA_PEAK_TFLOPS), "TFLOP/s", self.flops / 1e12
+            peak = {"int8": INT8_MFMA_PEAK_TOPS, "fp8": INT8_MFMA_PEAK_TOPS, "mxa8": MXFP8_MFMA_PEAK_TFLOPS,
+                    "mxa4": MXFP4_MFMA_PEAK_TFLOPS}.get(self.dt, MFMA_PEAK_TFLOPS)
+            unit, work = "TFLOP/s", self.flops / 1e12
         ach = work / (t * 1e-6)
         out.update({"achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "algorithmic_bytes_per_launch": self.bytes, "flops_per_launch": self.flops})
@@ -326,7 +369,8 @@ def main():
         print(f"[bench] per-kernel event timing unavailable: {e}", file=sys.stderr)
     work = main_run.bytes / 1e9 if bound == "hbm" else main_run.flops / 1e12
     unit = "GB/s" if bound == "hbm" else "TFLOP/s"
-    peak = HBM_PEAK_GBS if bound == "hbm" else (INT8_MFMA_PEAK_TOPS if dt in PREQUANT else MFMA_PEAK_TFLOPS)
+    peak = HBM_PEAK_GBS if bound == "hbm" else {"int8": INT8_MFMA_PEAK_TOPS, "fp8": INT8_MFMA_PEAK_TOPS, "mxa8": MXFP8_MFMA_PEAK_TFLOPS,
+                                                  "mxa4": MXFP4_MFMA_PEAK_TFLOPS}.get(dt, MFMA_PEAK_TFLOPS)
     value = whole_job_rate(layers * work, args.steps, world, elapsed)
     if roof.get("kernel_us") is None:  # fall back to the gap-inclusive figure
         roof.update({"bound": bound, "achieved": round(work / (gap_us * 1e-6), 3), "peak": peak, "unit": unit,
@@ -344,7 +388,7 @@ def main():
         "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dt, "data": "synthetic (seeded random W_q/scales/zeros/x, random-init)",
-        "config": {"workload": f"A{8 if dt in PREQUANT else 16}W{nbits} gs={group} {N}x{K} M={M} {dt}; step = {layers} distinct layers "
+        "config": {"workload": f"A{4 if dt == 'mxa4' else (8 if dt in PREQUANT else 16)}W{nbits} gs={group} {N}x{K} M={M} {dt}; step = {layers} distinct layers "
                                f"(cache-cold rotation), {'hipGraph replay' if main_run.graph is not None else 'eager'}",
                    "layers_per_step": layers, "launches_per_step": layers, "replicas": world,
                    **({"tuning": args.tuning} if args.tuning else {}),
