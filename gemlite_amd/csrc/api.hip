@@ -25,6 +25,7 @@ bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPl
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 const void* mx_generic_kernel_fn();
 const void* act_quant_mx_kernel_fn(int mode);
 const void* generic_kernel_fn();
@@ -162,8 +163,10 @@ static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
     g.mx_post = a.input_dtype == GEMLITE_DT_NVFP4 ? 0.0025f : 1.0f;  // meta_scale_norm = 0.05 ** 2 (gemm_kernels.py:461, 530-531)
     g.splitk = 1;
     r.gp = g;
-    if (a.tuning[0] == 0 && plan_gemm_mx_mma(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
-    if (a.tuning[0] == 0 && (a.input_dtype == GEMLITE_DT_MXFP16 || a.input_dtype == GEMLITE_DT_MXBF16)) {
+    // decode sizes: the streaming kernel (tuning[0] = 2 keeps the MFMA kernels for A/B runs)
+    if (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
+    if ((a.tuning[0] == 0 || a.tuning[0] == 2) && plan_gemm_mx_mma(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
+    if ((a.tuning[0] == 0 || a.tuning[0] == 2) && (a.input_dtype == GEMLITE_DT_MXFP16 || a.input_dtype == GEMLITE_DT_MXBF16)) {
         // 16-bit activations: the tiled MFMA kernel of the integer formats with the block-scaled weight geometry
         WnParams p{};
         p.x = a.x; p.w = (const uint32_t*)a.w_q; p.scales = a.scales; p.zeros = nullptr;

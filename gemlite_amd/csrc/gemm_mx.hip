@@ -183,6 +183,147 @@ __global__ __launch_bounds__(256) void mx_generic_kernel(const GenericParams p) 
 const void* mx_generic_kernel_fn() { return (const void*)mx_generic_kernel; }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// decode kernel (M <= 4): one wave per output column, lanes along K with 16-byte pieces of the K-contiguous weight row (the
+// streaming form of kmajor_matmul_kernel).  A piece is 32 fp4 / 16 fp8 weights of ONE microscaling block: the hardware
+// converters (v_cvt_scalef32_pk_*) turn it into scaled 16-bit pairs (exact: e2m1 / e4m3 times 2^e fits bf16), the same
+// for fp8 / fp4 activations with their block scale, and v_dot2_f32_{bf16,f16} accumulates in fp32.  Replaces the
+// GEMM_SPLITK route the reference takes for MX decode (core.py:100-105).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int XF, int WF, int MB>
+__global__ __launch_bounds__(1024) void mx_gemv_kernel(const GenericParams p) {
+    constexpr bool H16 = XF == MX_F16;            // arithmetic in fp16 pairs only when x is fp16; bf16 otherwise
+    constexpr int CK = WF == MX_FP4 ? 32 : 16;    // k per 16-byte weight piece
+    constexpr int NP = CK / 2;                    // 16-bit pairs per piece
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;  // 4 or 16 waves = adjacent columns: they share the scale lines
+    const int64_t m0 = (int64_t)blockIdx.y * MB;
+    if (n >= p.N) return;
+    const uint8_t* wrow = (const uint8_t*)p.w + n * p.stride_wn;
+    const uint8_t* srow = (const uint8_t*)p.scales + n * p.stride_meta_n;
+    float acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+    auto dot = [](uint32_t a, uint32_t b, float c) -> float {
+        if constexpr (H16) return F16Traits<half_tag>::dot2(a, b, c);
+        else return F16Traits<bf16_tag>::dot2(a, b, c);
+    };
+    const int64_t pieces = p.K / CK;
+    for (int64_t c = lane; c < pieces; c += 64) {
+        const int64_t k0 = c * CK, kb = k0 >> 5;
+        const u32x4 wv = *(const u32x4*)(wrow + c * 16);
+        const float sw = __builtin_bit_cast(float, (uint32_t)srow[kb * p.stride_meta_g] << 23);
+        uint32_t wp[NP];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if constexpr (WF == MX_FP4) {
+                if constexpr (H16) {
+                    wp[4 * d + 0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(wv[d], sw, 0));
+                    wp[4 * d + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(wv[d], sw, 1));
+                    wp[4 * d + 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(wv[d], sw, 2));
+                    wp[4 * d + 3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(wv[d], sw, 3));
+                } else {
+                    wp[4 * d + 0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wv[d], sw, 0));
+                    wp[4 * d + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wv[d], sw, 1));
+                    wp[4 * d + 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wv[d], sw, 2));
+                    wp[4 * d + 3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wv[d], sw, 3));
+                }
+            } else {
+                if constexpr (H16) {
+                    wp[2 * d + 0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(wv[d], sw, false));
+                    wp[2 * d + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(wv[d], sw, true));
+                } else {
+                    wp[2 * d + 0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(wv[d], sw, false));
+                    wp[2 * d + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(wv[d], sw, true));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int64_t m = m0 + i;
+            if (m >= p.M) continue;
+            if constexpr (XF == MX_F16 || XF == MX_BF16) {
+                const uint8_t* xr = (const uint8_t*)p.x + (m * p.stride_xm + k0) * 2;
+#pragma unroll
+                for (int q = 0; q < NP / 4; ++q) {
+                    const u32x4 xv = *(const u32x4*)(xr + 16 * q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i] = dot(wp[4 * q + t], xv[t], acc[i]);
+                }
+            } else {
+                float sx = 1.0f;
+                if (p.sx_blocks) sx = __builtin_bit_cast(float, (uint32_t)((const uint8_t*)p.sx_blocks)[m * p.stride_sx_blk_m + kb] << 23);
+                if constexpr (XF == MX_FP8) {
+                    const uint8_t* xr = (const uint8_t*)p.x + m * p.stride_xm + k0;
+#pragma unroll
+                    for (int q = 0; q < CK / 16; ++q) {
+                        const u32x4 xv = *(const u32x4*)(xr + 16 * q);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(xv[d], sx, false));
+                            const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(xv[d], sx, true));
+                            acc[i] = dot(wp[8 * q + 2 * d], lo, acc[i]);
+                            acc[i] = dot(wp[8 * q + 2 * d + 1], hi, acc[i]);
+                        }
+                    }
+                } else {  // fp4 activations (with fp4 weights: 32 k per piece = 16 bytes of x)
+                    const u32x4 xv = *(const u32x4*)((const uint8_t*)p.x + m * p.stride_xm + (k0 >> 1));
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        acc[i] = dot(wp[4 * d + 0], __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(xv[d], sx, 0)), acc[i]);
+                        acc[i] = dot(wp[4 * d + 1], __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(xv[d], sx, 1)), acc[i]);
+                        acc[i] = dot(wp[4 * d + 2], __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(xv[d], sx, 2)), acc[i]);
+                        acc[i] = dot(wp[4 * d + 3], __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(xv[d], sx, 3)), acc[i]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && m0 + i < p.M) epilogue_store(p.epi, v * p.mx_post, m0 + i, n);
+    }
+}
+
+typedef void (*mx_gemv_fn)(const GenericParams);
+template <int XF, int WF>
+static const void* mx_gemv_pick(int mb) {
+    mx_gemv_fn f = mb == 1 ? mx_gemv_kernel<XF, WF, 1> : mx_gemv_kernel<XF, WF, 4>;
+    return (const void*)f;
+}
+
+// M <= 4, e8m0 scales per 32 k, K-contiguous weights.  (NVFP4 stays on the coverage kernel.)
+bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
+    if (a.M > 4 || g.mx_scale_e4m3 || g.group_size != 32) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.K % 32 != 0) return false;
+    if (g.mx_x == MX_FP4 && g.mx_w != MX_FP4) return false;
+    const int xb = (g.mx_x == MX_F16 || g.mx_x == MX_BF16) ? 2 : 1;
+    if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || (a.stride_xm * xb) % 16 != 0 || a.stride_wn % 16 != 0) return false;
+    const int mb = a.M == 1 ? 1 : 4;
+    const void* fn = nullptr;
+    const bool w8 = g.mx_w == MX_FP8;
+    switch (g.mx_x) {
+        case MX_F16: fn = w8 ? mx_gemv_pick<MX_F16, MX_FP8>(mb) : mx_gemv_pick<MX_F16, MX_FP4>(mb); break;
+        case MX_BF16: fn = w8 ? mx_gemv_pick<MX_BF16, MX_FP8>(mb) : mx_gemv_pick<MX_BF16, MX_FP4>(mb); break;
+        case MX_FP8: fn = w8 ? mx_gemv_pick<MX_FP8, MX_FP8>(mb) : mx_gemv_pick<MX_FP8, MX_FP4>(mb); break;
+        default: fn = mx_gemv_pick<MX_FP4, MX_FP4>(mb); break;
+    }
+    lp.fn = fn;
+    lp.name = w8 ? "mx_gemv_w8_kernel" : "mx_gemv_w4_kernel";
+    // waves (= adjacent columns) per block: measured at 4096^2, M = 1 (profiles/r02/mx): fp4 weights 16 waves 5.9 vs 6.9 us with 4
+    // (the columns share the lines of the [K/32][N] scale bytes), fp8 weights 4 waves 8.1 vs 8.9 us.  tuning[3]: 1 = 4, 2 = 16.
+    const int nw = a.tuning[3] == 1 ? 4 : (a.tuning[3] == 2 ? 16 : (w8 ? 4 : 16));
+    lp.grid = dim3((unsigned)((a.N + nw - 1) / nw), (unsigned)((a.M + mb - 1) / mb), 1);
+    lp.block = dim3(64 * nw, 1, 1);
+    lp.lds_bytes = 0;
+    lp.ws_bytes = 0;
+    lp.slab_bytes = 0;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // scaled-MFMA kernel.  AF / BF: element format of x / w as the instruction's cbsz / blgp code (0 = fp8 e4m3, 4 = fp4 e2m1).
 // A K step moves 256 BYTES of every x row (256 k of fp8, 512 k of fp4); wave (cg, kh) owns all rows x 32 columns x the
 // kh-th half of the step = NS slices of 64 k.  Per slice and lane: A fragment = 16 (fp4) or 2 x 16 (fp8) bytes read from

@@ -22,7 +22,7 @@ CASES = load_cases()
 def test_library_exports_every_header_symbol():
     lib = _hip.load()
     header = open(os.path.join(ROOT, "include", "gemlite_hip.h")).read()
-    declared = set(re.findall(r"\b(gemlite_hip_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(gemlite_hip_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(_hip.EXPORTED_SYMBOLS)
     for name in declared:

@@ -152,7 +152,12 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(args(16, 4, 256, 2, N=8192, K=8192)) == "gemm_mx_a8w4_kernel<128x128>"
     assert name(args(17, 4, 256, 4, N=8192, K=8192)) == "gemm_mx_a4w4_kernel<128x128>"
     assert name(args(16, 8, 256, 4)) == "gemm_mx_a8w8_kernel<64x128>"   # the tallest tile that still gives >= 112 tiles
-    assert name(args(16, 8, 1, 4)) == "gemm_mx_a8w8_kernel<32x128>"
+    assert name(args(16, 8, 1, 4)) == "mx_gemv_w8_kernel"             # decode: streaming kernel up to 4 rows
+    assert name(args(17, 4, 4, 4)) == "mx_gemv_w4_kernel"
+    assert name(args(16, 8, 5, 4)) == "gemm_mx_a8w8_kernel<32x128>"
+    a = args(16, 8, 1, 4)
+    a.tuning[0] = 2                                                       # A/B switch: MFMA kernel at decode sizes
+    assert name(a) == "gemm_mx_a8w8_kernel<32x128>"
     assert name(args(17, 4, 48, 4, N=16384)) == "gemm_mx_a4w4_kernel<64x128>"
     assert name(args(18, 4, 8, 4, group=16)) == "mx_generic_kernel"       # NVFP4: no gfx950 instruction
     assert lib.gemlite_hip_query(C.byref(args(18, 4, 8, 4, group=32))) == _hip.ERR_UNSUPPORTED
