@@ -26,6 +26,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
 bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
+bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 const void* mx_generic_kernel_fn();
 const void* act_quant_mx_kernel_fn(int mode);
 const void* generic_kernel_fn();
@@ -165,6 +166,8 @@ static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
     r.gp = g;
     // decode sizes: the streaming kernel (tuning[0] = 2 keeps the MFMA kernels for A/B runs)
     if (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
+    // prefill sizes of the same-format pairs: 256 x 256 tiles, both operands through LDS (tuning[0] = 3 forces it at any M)
+    if (plan_gemm_mx_tile(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
     if ((a.tuning[0] == 0 || a.tuning[0] == 2) && plan_gemm_mx_mma(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
     if ((a.tuning[0] == 0 || a.tuning[0] == 2) && (a.input_dtype == GEMLITE_DT_MXFP16 || a.input_dtype == GEMLITE_DT_MXBF16)) {
         // 16-bit activations: the tiled MFMA kernel of the integer formats with the block-scaled weight geometry

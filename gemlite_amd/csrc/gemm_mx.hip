@@ -611,6 +611,277 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_mma_kernel(const GenericParams
     if (tid == 0) splitk_reset(p.counters + bid);
 }
 
+typedef void (*mx_kernel_fn_t)(const GenericParams);
+// ---------------------------------------------------------------------------------------------------------------------
+// prefill kernel (M >= 512): 256 x 256 tiles, BOTH operands through LDS, 8 waves (2 x 4) with 128 x 64 wave tiles.
+// The 8-wave kernel above fetches its weight fragments as 64 rows x 16 bytes per request and moves (128 + 128) rows x 256
+// bytes per 128 x 128 x 256 step — 128 flop per operand byte, which at the block-scaled MFMA rate (8 kflop / clk / CU for
+// fp8, 16 for fp4) asks more than the 64 B/clk a CU gets from L2.  Here a block owns 256 x 256 outputs (512 flop per byte):
+//   * x AND w tiles go global -> LDS by LDS-DMA as 64-byte row segments (1 KiB = 16 rows per request), XOR-swizzled through
+//     the source address so that the fragment reads are conflict-free (PMC: 1.6 % of LDS cycles conflict); the block scales
+//     travel the same way (4 bytes per lane).  EVERY request of the K loop is an asm DMA: with compiler-tracked loads in the
+//     loop hipcc waited for all older DMAs before their first use (210 -> 151 us at 8192^2, M = 2048 when the scale loads became
+//     DMAs), and a single scratch reload in the loop costs a vmcnt(0), i.e. the whole pipeline (a 4-wave variant with 128 x 128
+//     wave tiles spilled accumulators: 611 us) — hence per-lane base addresses + immediates + one opaque SGPR per stage;
+//   * NST = 4 stages of 64 bytes per row (3 in flight); a stage is NSL * 4 "rows" of 2 MFMAs, the operands of row r + 1 are
+//     read while the MFMAs of row r issue; one counted s_waitcnt + one s_barrier per stage, before its last row.
+// K is not split.  Measured (profiles/r02/mx): 8192^2, M = 2048: fp8 154 us = 1.78 PFLOP/s (0.36 of the MX-fp8 peak), fp4
+// 88 us = 3.14 PFLOP/s (0.31); the 128-row kernel above: 342 / 251 us.  PMC: the matrix pipe is busy 40 % of the time, waves
+// wait 36 % (barrier + the DMA of HBM-cold panels, 2.4 us ahead) — not LDS, not the fabric (XCD-aware tile order: 1 %).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mxt_slot(int r, int s) { return r * 64 + ((s ^ ((r >> 2) & 3)) << 4); }
+
+// FMT 0: fp8 x fp8, 4: fp4 x fp4;  NST LDS stages of 64 bytes per row;  BLKX: activation block scales (channel_scale_mode 4)
+template <int FMT, int NST, bool BLKX>
+__global__ __launch_bounds__(512, 2) void gemm_mx_tile_kernel(const GenericParams p) {
+    using namespace async;
+    constexpr int BM = 256, BN = 256, PITCH = 64;
+    constexpr int MI = 4, NI = 2;
+    constexpr int A_BYTES = BM * PITCH, TILES = (BM + BN) * PITCH;   // 32 KiB of operand tiles per stage
+    constexpr int SC_A = TILES, SC_B = TILES + 1024, STAGE = TILES + 2048;  // + 1 KiB activation scales + 1 KiB weight scales
+    constexpr int KSTAGE = FMT == 0 ? 64 : 128;                       // k per stage
+    constexpr int NSL = KSTAGE / 64;                                  // 64-k slices per stage (1 or 2)
+    constexpr int KBLK = KSTAGE / 32;                                 // scale blocks per stage (2 or 4)
+    constexpr int FV = FMT == 0 ? 2 : 1;                              // 16-byte pieces per fragment
+    constexpr int PIECES = TILES / 1024 / 8;                          // tile pieces per wave and stage (4)
+    constexpr int R = PIECES + 1;                                     // + one scale piece: requests per wave and stage
+    static_assert((NST - 1) * R <= 63 && NST >= 3 && NST % 2 == 0, "vmcnt is a 6-bit counter; stage parity must be static");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST][STAGE], later the per-wave output tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int col = lane & 31, h = lane >> 5;
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = p.N / BN;
+    // Block b runs on XCD b % 8 and every XCD has its own 4 MiB L2: give each XCD a compact sub-grid (ntiles / 8 weight panels
+    // x all row panels) so that a panel stage is fetched into an L2 once and shared (tuning[3] & 16: plain M-fastest order)
+    int mt = blockIdx.x % mtiles, nt = blockIdx.x / mtiles;
+    if ((ntiles & 7) == 0 && !(p.flags & 16)) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = ntiles >> 3;
+        mt = idx % mtiles;
+        nt = xcd * per + (idx / mtiles) % per;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nstages = p.K / KSTAGE;
+    const int row_bytes = FMT == 0 ? p.K : p.K / 2;
+    const int blocks_k = p.K / 32;
+    constexpr bool blk_x = BLKX;
+    const int m_pad = (p.M + 31) / 32 * 32;
+
+    const srd_t rsX = make_srd(p.x, (uint32_t)((int64_t)(p.M - 1) * p.stride_xm + row_bytes));
+    const srd_t rsW = make_srd(p.w, (uint32_t)((int64_t)(p.N - 1) * p.stride_wn + row_bytes));
+    const srd_t rsSW = make_srd(p.scales, (uint32_t)((int64_t)(blocks_k - 1) * p.stride_meta_g + p.N));
+    const srd_t rsSA = blk_x ? make_srd(p.sx_blocks, (uint32_t)((int64_t)(m_pad - 1) * p.stride_sx_blk_m + blocks_k)) : rsSW;
+
+    // Per wave and stage: PIECES tile pieces (1 KiB = 16 rows x 64 bytes; waves 0..3 move x, waves 4..7 move w; lane i's 16 bytes
+    // land at +16 i = row i / 4, physical slot i % 4 = logical slot ^ ((row >> 2) & 3)) and ONE 256-byte scale piece: waves 0..3
+    // the activation-scale dwords of rows [64 wave, +64), waves 4..7 one 32-k block row of weight scales (fp8: rows repeat).
+    uint32_t dvoff[PIECES];
+    const bool is_w = wave >= 4;
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int byte = (wave * PIECES + j) * 1024 + lane * 16;
+        const int tb = is_w ? byte - A_BYTES : byte;
+        const int r = tb / PITCH, phys = (tb % PITCH) / 16;
+        const int logical = phys ^ ((r >> 2) & 3);
+        if (is_w) dvoff[j] = (uint32_t)((int64_t)(n0 + r) * p.stride_wn + logical * 16);
+        else dvoff[j] = m0 + r < p.M ? (uint32_t)((int64_t)(m0 + r) * p.stride_xm + logical * 16) : 0x80000000u;
+    }
+    const srd_t rsD = is_w ? rsW : rsX;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const uint32_t lds0 = lds_base + (uint32_t)(wave * PIECES) * 1024u;
+    const int brow = (wave & 3) % KBLK;
+    const srd_t rsS = is_w ? rsSW : rsSA;
+    const uint32_t s_voff = is_w ? (uint32_t)((int64_t)brow * p.stride_meta_g + n0 + lane * 4)
+                                 : (blk_x ? (uint32_t)((int64_t)(m0 + wave * 64 + lane) * p.stride_sx_blk_m) : 0u);
+    const uint32_t s_lds = lds_base + (is_w ? (uint32_t)(SC_B + brow * 256) : (uint32_t)(SC_A + wave * 256));
+    auto request = [&](int buf, int stage) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j)
+            req_lds16(rsD, lds0 + (uint32_t)(buf * STAGE + j * 1024), dvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(stage * PITCH));
+        // activation scales: the ALIGNED dword that holds this stage's KBLK bytes (fp8: two stages share a dword);
+        // weight scales: block row stage * KBLK + brow
+        const int so = is_w ? (stage * KBLK) * (int)p.stride_meta_g : (blk_x ? ((stage * KBLK) & ~3) : 0);
+        req_lds4(rsS, s_lds + (uint32_t)(buf * STAGE), s_voff, (uint32_t)__builtin_amdgcn_readfirstlane(so));
+    };
+    // Fragment addresses inside a stage: row block mi adds mi * 32 * PITCH — an immediate — to ONE per-lane base per (slice, piece)
+    // (fp8: slots {h, 2 + h}; fp4: slot 2g + h; the swizzle (row >> 2) & 3 = (col >> 2) & 3 does not depend on the row block),
+    // and the stage's LDS offset is added from an SGPR the optimiser cannot see through: folded into per-stage address
+    // registers, the 4 x 24 addresses spilled, and a scratch reload inside the loop costs a vmcnt(0) — the whole DMA pipeline.
+    int abase[NSL][FV], bbase[NSL][FV];
+#pragma unroll
+    for (int g = 0; g < NSL; ++g)
+#pragma unroll
+        for (int v = 0; v < FV; ++v) {
+            const int slot = FMT == 0 ? 2 * v + h : 2 * g + h;
+            abase[g][v] = mxt_slot(wm * 128 + col, slot);
+            bbase[g][v] = A_BYTES + mxt_slot(wn * 64 + col, slot);
+        }
+    const int sa_base = SC_A + (wm * 128 + col) * 4 + (FMT == 0 ? h : 0);
+    const int sb_base = SC_B + h * 256 + wn * 64 + col;
+    const uint32_t sh_h = 8u * (uint32_t)h;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    // operands: the 4 weight fragments of a 64-k slice (+ this lane's weight block scales), one activation fragment (+ scale)
+    typedef typename std::conditional<FMT == 0, v8i, u32x4>::type frag_t;  // fp4 fragments are 4 registers
+    struct BSet { frag_t b[NI]; uint32_t s[NI]; };
+    struct AFr { frag_t a; uint32_t s; };
+    auto mk = [](u32x4 v0, u32x4 v1) -> frag_t {
+        if constexpr (FMT == 0) return (v8i){(int)v0[0], (int)v0[1], (int)v0[2], (int)v0[3], (int)v1[0], (int)v1[1], (int)v1[2], (int)v1[3]};
+        else return v0;
+    };
+    auto wide = [](frag_t f) -> v8i {
+        if constexpr (FMT == 0) return f;
+        else return (v8i){(int)f[0], (int)f[1], (int)f[2], (int)f[3], 0, 0, 0, 0};
+    };
+    auto stage_ptr = [&](int buf) -> const unsigned char* {
+        int off = buf * STAGE;
+        asm volatile("" : "+s"(off));  // opaque: one s-register per stage, added at every read
+        return smem + off;
+    };
+    auto load_b = [&](BSet& bs, const unsigned char* sb, int g) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const u32x4 v0 = *(const u32x4*)(sb + bbase[g][0] + ni * 32 * PITCH);
+            const u32x4 v1 = FV == 2 ? *(const u32x4*)(sb + bbase[g][FV - 1] + ni * 32 * PITCH) : (u32x4){0u, 0u, 0u, 0u};
+            bs.b[ni] = mk(v0, v1);
+            bs.s[ni] = sb[sb_base + 2 * g * 256 + ni * 32];
+        }
+    };
+    auto load_a = [&](AFr& af, const unsigned char* sb, int g, int mi, int par) {
+        const u32x4 v0 = *(const u32x4*)(sb + abase[g][0] + mi * 32 * PITCH);
+        const u32x4 v1 = FV == 2 ? *(const u32x4*)(sb + abase[g][FV - 1] + mi * 32 * PITCH) : (u32x4){0u, 0u, 0u, 0u};
+        af.a = mk(v0, v1);
+        if constexpr (!blk_x) af.s = 127u;
+        else if constexpr (FMT == 0) af.s = sb[sa_base + mi * 128 + par * 2];                               // block h of this stage
+        else af.s = *(const uint32_t*)(sb + sa_base + mi * 128) >> (sh_h + 16u * (uint32_t)g);              // block 2g + h
+    };
+    auto mma_row = [&](const AFr& af, const BSet& bs, int mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(af.a), wide(bs.b[ni]), acc[mi][ni], FMT, FMT, 0, (int)af.s, 0,
+                                                                         (int)bs.s[ni]);
+    };
+
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0) request(s0, s0 < nstages ? s0 : nstages - 1);
+    wait_vm<(NST - 2) * R>();
+    __builtin_amdgcn_s_barrier();
+    BSet bs[2];
+    AFr af[2];
+    load_b(bs[0], stage_ptr(0), 0);
+    load_a(af[0], stage_ptr(0), 0, 0, 0);
+
+    // Stage st (J = st % NST): request stage st + NST - 1 into the buffer stage st - 1 used (every wave passed the barrier after
+    // its last read of it).  The stage is NSL * MI "rows" of 4 MFMAs (one activation fragment against the slice's 4 weight
+    // fragments); the operands of row r + 1 are read while the MFMAs of row r issue.  Before the LAST row: "stage st + 1 has
+    // landed" (counted wait + barrier), then the first operands of stage st + 1, then the last row's MFMAs.
+    auto do_stage = [&](auto Jc, int st) {
+        constexpr int J = decltype(Jc)::value;  // NST is even: J & 1 == st & 1
+        const int nx = st + NST - 1 < nstages ? st + NST - 1 : nstages - 1;  // past the end: repeat the last stage (never read)
+        request((J + NST - 1) % NST, nx);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sb_cur = stage_ptr(J);
+        const unsigned char* sb_nxt = stage_ptr((J + 1) % NST);
+        constexpr int ROWS = NSL * MI;
+        // (ROWS is even and MI is even: the parities of the A ring and of the B sets are the same in every stage)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int g = r / MI, mi = r % MI;
+            if (r + 1 < ROWS) {
+                const int g1 = (r + 1) / MI, mi1 = (r + 1) % MI;
+                if (mi1 == 0) load_b(bs[g1 & 1], sb_cur, g1);  // (NSL == 2: slices alternate between the two sets)
+                load_a(af[(r + 1) & 1], sb_cur, g1, mi1, J & 1);
+            } else {
+                wait_vm<(NST - 2) * R>();            // everything but the newest NST - 2 stages: stage st + 1 has landed
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // this wave's LDS reads of stage st are complete
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                load_b(bs[NSL == 1 ? ((J + 1) & 1) : 0], sb_nxt, 0);
+                load_a(af[0], sb_nxt, 0, 0, (J + 1) & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_row(af[r & 1], bs[NSL == 1 ? (J & 1) : (g & 1)], mi);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto chain = [&](auto self, auto Jc, int s0) -> void {
+        constexpr int J = decltype(Jc)::value;
+        do_stage(Jc, s0 + J);
+        if constexpr (J + 1 < NST) {
+            if (s0 + J + 1 < nstages) self(self, std::integral_constant<int, J + 1>{}, s0);
+        }
+    };
+    for (int s0 = 0; s0 < nstages; s0 += NST) chain(chain, std::integral_constant<int, 0>{}, s0);
+    wait_vm<0>();
+
+    // ---- epilogue: every wave transposes its 32 x 32 blocks through a private LDS tile, rows leave as 8-byte (4-column) stores
+    __syncthreads();
+    float* ct = (float*)smem + wave * (32 * 36);
+    const float post = p.mx_post;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ct[((e & 3) + 8 * (e >> 2) + 4 * h) * 36 + col] = acc[mi][ni][e];
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            const int r = lane >> 1, c0 = (lane & 1) * 16;
+            const int m = m0 + wm * 128 + mi * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *(const f32x4*)(ct + r * 36 + c0 + 4 * q);
+                if (m < p.M) store_out4_any(p.epi, v * (f32x4){post, post, post, post}, m, (int64_t)n0 + wn * 64 + ni * 32 + c0 + 4 * q);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+}
+
+// M >= 512 (or tuning[0] == 3), fp8 x fp8 or fp4 x fp4, N % 256 == 0
+bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
+    if (g.mx_scale_e4m3 || g.group_size != 32) return false;
+    const bool f8 = g.mx_x == MX_FP8 && g.mx_w == MX_FP8, f4 = g.mx_x == MX_FP4 && g.mx_w == MX_FP4;
+    if (!f8 && !f4) return false;
+    if (a.tuning[0] != 3 && (a.tuning[0] != 0 || a.M < 512)) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 256 != 0 || a.K % (f8 ? 64 : 128) != 0) return false;
+    if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
+    if ((int64_t)a.M * a.stride_xm >= (1ll << 31) || (int64_t)a.N * a.stride_wn >= (1ll << 31)) return false;
+    if ((int64_t)(a.K / 32) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    if (!(a.output_dtype == GEMLITE_DT_FP32 || a.output_dtype == GEMLITE_DT_FP16 || a.output_dtype == GEMLITE_DT_BF16)) return false;
+    const int oal = a.output_dtype == GEMLITE_DT_FP32 ? 16 : 8;
+    if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
+    if (a.channel_scale_mode == 4) {
+        if (!g.sx_blocks || g.stride_sx_blk_m % 4 != 0 || ((uintptr_t)g.sx_blocks % 4) != 0) return false;
+        if ((int64_t)((a.M + 31) / 32 * 32) * g.stride_sx_blk_m >= (1ll << 31)) return false;
+    } else if (a.channel_scale_mode != 2 && a.channel_scale_mode != 0) {
+        return false;
+    }
+    const int64_t tiles = (int64_t)(a.N / 256) * ((a.M + 255) / 256);
+    if (tiles > 0x7FFFFFFF) return false;
+    constexpr int nst = 4;  // LDS stages of 34 KiB (tiles + scales): 136 KiB
+    if (a.stride_meta_n != 1 || ((uintptr_t)a.scales % 4) != 0 || a.stride_meta_g % 4 != 0) return false;  // 4-byte scale pieces
+    const bool bx = a.channel_scale_mode == 4;
+    mx_kernel_fn_t f = f8 ? (bx ? gemm_mx_tile_kernel<0, nst, true> : gemm_mx_tile_kernel<0, nst, false>)
+                          : (bx ? gemm_mx_tile_kernel<4, nst, true> : gemm_mx_tile_kernel<4, nst, false>);
+    g.splitk = 1;
+    g.flags = a.tuning[3];  // & 16: plain M-fastest tile order (A/B runs)
+    lp.fn = (const void*)f;
+    lp.name = f8 ? "gemm_mx_a8w8_tile_kernel<256x256>" : "gemm_mx_a4w4_tile_kernel<256x256>";
+    lp.grid = dim3((unsigned)tiles, 1, 1);
+    lp.block = dim3(512, 1, 1);
+    lp.lds_bytes = (size_t)nst * ((256 + 256) * 64 + 2048);
+    lp.ws_bytes = 0;
+    lp.slab_bytes = 0;
+    return true;
+}
+
 typedef void (*mx_kernel_fn)(const GenericParams);
 template <int AF, int BF>
 static const void* mx_pick(int mi) {

@@ -33,6 +33,12 @@ __device__ __forceinline__ void req_lds16(srd_t rs, uint32_t lds_addr, uint32_t 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
 }
+// the same with 4 bytes per lane: 64 lanes x 4 bytes to LDS [lds_addr, +256)
+__device__ __forceinline__ void req_lds4(srd_t rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void tie(uint32_t& v) { asm volatile("" : "+v"(v)); }

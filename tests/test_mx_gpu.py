@@ -232,6 +232,34 @@ def test_reference_acceptance_bar(proc, tol, M):
     assert layer.W_q.numel() * layer.W_q.element_size() == 4096 * 2048 // (1 if "W8" in proc else 2)
 
 
+@pytest.mark.parametrize("proc,kname", [("A8W8_MXFP_dynamic", "gemm_mx_a8w8_tile_kernel"), ("A4W4_MXFP_dynamic", "gemm_mx_a4w4_tile_kernel"),
+                                        ("A8W8_MXFP_dynamic_post", "gemm_mx_a8w8_tile_kernel")])
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
+def test_prefill_tile_kernel_vs_oracle(proc, kname, tdt):
+    """256 x 256 tiles with both operands through LDS: picked from M = 512, forced (tuning[0] = 3) on ragged smaller M"""
+    N, K = 512, 2048
+    lin = _linear(N, K, tdt, seed=21)
+    bias = lin.bias.data.clone()
+    layer = PROCS[proc](tdt).from_linear(lin, del_orig=False)
+    g = torch.Generator().manual_seed(13)
+    for M, tuning in ((700, (0, 0, 0, 0)), (512, (0, 0, 0, 0)), (300, (3, 0, 0, 0)), (33, (3, 0, 0, 0))):
+        x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
+        try:
+            C.TUNING_OVERRIDE = tuning if any(tuning) else None
+            name = _kernel_name(layer, x, tuning)
+            assert name.startswith(kname), (M, tuning, name)
+            y = layer(x)
+        finally:
+            C.TUNING_OVERRIDE = None
+        ref = _oracle(layer, x) + bias.float().cpu().numpy().astype(np.float64)
+        _check(f"{proc} {tdt} M={M} {name}", y, ref, tdt)
+        try:  # and the 128-row kernel gives the same answer
+            C.TUNING_OVERRIDE = (2, 0, 0, 0)
+            _check(f"{proc} {tdt} M={M} 8-wave kernel", layer(x), ref, tdt)
+        finally:
+            C.TUNING_OVERRIDE = None
+
+
 def test_mx_layer_state_dict_round_trip_and_functional_op():
     tdt = torch.bfloat16
     lin = _linear(256, 512, tdt, seed=9)
