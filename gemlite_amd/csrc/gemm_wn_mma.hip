@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     // opt-in timeline (tuning[3] & 4): lane 0 of every wave of block (0, 0) stores s_memtime stamps behind the tickets
     const bool probe = (p.flags & 4) && p.counters && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0;
     unsigned long long* stamps = (unsigned long long*)(p.counters + MAX_SPLITK_COUNTERS) + wave * 16;
-    auto stamp = [&](int i) {
+    auto stamp = [&](int i) __attribute__((always_inline)) {
         if (probe) stamps[i] = __builtin_readcyclecounter();
     };
     stamp(0);
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         brS = __builtin_amdgcn_make_buffer_rsrc((void*)(need_s ? p.scales : (const void*)p.w), (short)0, need_s ? meta_bytes : 4, 0x00020000);
         brZ = __builtin_amdgcn_make_buffer_rsrc((void*)(need_z ? p.zeros : (const void*)p.w), (short)0, need_z ? meta_bytes : 4, 0x00020000);
     }
-    auto req_b = [&](BStep& b, int step, int it) {
+    auto req_b = [&](BStep& b, int step, int it) __attribute__((always_inline)) {
         const int sb = it / NREQ, i = it % NREQ;
         if constexpr (MXW) {
             constexpr int WB = G::WBYTES64;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         xvoff[j] = m0 + r < p.M ? (uint32_t)(((int64_t)(m0 + r) * p.stride_xm + k_s0) * ES + logical * 16) : 0x80000000u;
     }
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PIECES) * 1024u);
-    auto req_x = [&](int stage, int step, int j) {
+    auto req_x = [&](int stage, int step, int j) __attribute__((always_inline)) {
         req_lds16(rsX, lds0 + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP * ES));
     };
     // A fragment of slot q = (slice g, row block mi): row mi*32 + col, k = kh*KW + (g/4)*64 + k_of(g%4, h)
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
             const int slot = kb >> 4;
             fbase[st][g] = st * STAGE + col * PITCH + (((slot & ~SWZ) | ((slot ^ col) & SWZ)) << 4) + (kb & 15);
         }
-    auto read_frag = [&](int stage, int q) -> frag_t {
+    auto read_frag = [&](int stage, int q) __attribute__((always_inline)) -> frag_t {
         return *(const frag_t*)(smem + fbase[stage][q / MI] + (q % MI) * 32 * PITCH);
     };
 
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     // Dequantisation of one slice (-> 4 registers of a B fragment) is cut into pieces that hide behind the MI MFMAs of
     // the slice before it: piece 0 = (scale, zero) of the sub-block + code extraction, then the 4 pairs.
     float mx_sc = 0.f;  // block scale of the sub-block being dequantised (MX)
-    auto deq_piece = [&](const BStep& b, int g, int mi, frag_t& out) {
+    auto deq_piece = [&](const BStep& b, int g, int mi, frag_t& out) __attribute__((always_inline)) {
         const int sb = g >> 2, u = g & 3;
         if constexpr (MXW) {
             // e8m0 byte -> fp32 2^(b - 127): the byte IS the exponent field (0 -> 0.0 instead of 2^-127: the quantisers
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     constexpr int NQI = NQ - L;                       // request slots
     constexpr int RPS = (NL + NQI - 1) / NQI;         // requests per slot
     static_assert((NST - 2) * PIECES + (NST - 1) * NLB + NL <= 63, "vmcnt is a 6-bit counter");
-    auto do_step = [&](auto Jc, int step) {
+    auto do_step = [&](auto Jc, int step) __attribute__((always_inline)) {
         constexpr int J = decltype(Jc)::value;
         constexpr int stage = J % NST, stage_next = (J + 1) % NST, stage_fill = (J + NST - 1) % NST;
         const BStep& bc = ring[J];
@@ -550,6 +550,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
             if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
         }
     };
+    // (A loop of whole RD-step groups without exits + a conditional tail was tried: hipcc's waitcnt pass then stops draining the
+    //  request queue at the first step of every group — vmcnt(1..2) instead of vmcnt(18) — but the kernel time did not move:
+    //  cfgB 44.36 vs 44.37 us, profiles/r02 lab notes.)
     for (int s0 = 0; s0 < nsteps; s0 += RD) chain(chain, std::integral_constant<int, 0>{}, s0);
     // retire every outstanding request (the last step's run-ahead DMA) before the LDS is reused
     wait_vm<0>();
