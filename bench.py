@@ -53,6 +53,9 @@ WORKLOADS = {
     "a16w4_4096_m256": (4096, 4096, 4, 128, 256, "bf16", 32, "mfma"),
     "a16w4_4096_m256_fp16": (4096, 4096, 4, 128, 256, "fp16", 32, "mfma"),
     "a16w4_8192_m256": (8192, 8192, 4, 128, 256, "bf16", 8, "mfma"),
+    "a16w4_8192_m2048": (8192, 8192, 4, 128, 2048, "bf16", 8, "mfma"),   # prefill-sized M: the tiles fill the chip without K slices
+    "a16w4_4096_m2048": (4096, 4096, 4, 128, 2048, "bf16", 32, "mfma"),
+    "a16w4_8192_m8192": (8192, 8192, 4, 128, 8192, "bf16", 8, "mfma"),
     "a16w4_8192_m1": (8192, 8192, 4, 128, 1, "fp16", 8, "hbm"),
     "a16w2_16384_m1": (16384, 16384, 2, 128, 1, "fp16", 4, "hbm"),
     "a16w2_16384_m256": (16384, 16384, 2, 128, 256, "bf16", 4, "mfma"),
