@@ -427,7 +427,7 @@ static const void* pick_shape(int cq, int r, bool xd, int nw) {
     }
     if (nw == 8) {  // two waves per SIMD: one wave's unpack arithmetic overlaps the other's memory wait (long K)
         if (r != 4) return nullptr;
-        return cq == 4 ? inst<Tag, NBITS, MB, 4, 4, false, 8>() : (cq == 3 ? inst<Tag, NBITS, MB, 4, 3, false, 8>() : nullptr);
+        return cq == 4 ? inst<Tag, NBITS, MB, 4, 4, false, 8>() : (cq == 3 ? inst<Tag, NBITS, MB, 4, 3, false, 8>() : inst<Tag, NBITS, MB, 4, 2, false, 8>());
     }
     if (cq == 2) return r == 4 ? inst<Tag, NBITS, MB, 4, 2>() : nullptr;
     if (cq == 3) return r == 4 ? inst<Tag, NBITS, MB, 4, 3>() : (r == 2 ? inst<Tag, NBITS, MB, 2, 3>() : nullptr);
@@ -550,7 +550,7 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         }
         // LDS-x path with 8 waves (tuning[2] == 8; auto when every wave still gets >= 4 chunks: the long-K shapes, where
         // one wave per SIMD spends ~2/3 of its time in unpack arithmetic that nothing overlaps with the weight stream)
-        if (!xd && r == 4 && cq >= 3 && (nbits == 4 || nbits == 2) &&
+        if (!xd && r == 4 && (cq >= 3 || a.tuning[2] == 8) && (nbits == 4 || nbits == 2) &&
             (a.tuning[2] == 8 || (a.tuning[2] == 0 && GEMV_AUTO_8W && nbits == 2 && (units / splitk) >= 32)))
             nw = 8;
         const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, xd, nw)
@@ -572,7 +572,7 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         lp.name = (xd && nw == 16) ? "gemv_wn_kernel<tile16,xdirect,16w>"
                   : (xd && nw == 8) ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect,8w>" : "gemv_wn_kernel<tile32,xdirect,8w>")
                   : xd ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect>" : (cq == 3 ? "gemv_wn_kernel<tile32,xdirect>" : "gemv_wn_kernel<tile64,xdirect>"))
-                     : (nw == 8 ? (cq == 3 ? "gemv_wn_kernel<tile32,8w>" : "gemv_wn_kernel<tile64,8w>")
+                     : (nw == 8 ? (cq == 2 ? "gemv_wn_kernel<tile16,8w>" : (cq == 3 ? "gemv_wn_kernel<tile32,8w>" : "gemv_wn_kernel<tile64,8w>"))
                                 : (cq == 2 ? "gemv_wn_kernel<tile16>" : (cq == 3 ? "gemv_wn_kernel<tile32>" : "gemv_wn_kernel<tile64>")));
         lp.grid = dim3(tiles, splitk, 1);
         lp.block = dim3(64 * nw, 1, 1);

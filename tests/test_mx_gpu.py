@@ -296,3 +296,69 @@ def test_large_shape_and_linearity():
     finally:
         C.TUNING_OVERRIDE = None
     _check("8192^2 vs coverage kernel", y[:8], y_cov.float().cpu().numpy(), tdt)
+
+
+@pytest.mark.parametrize("proc", ["A16W4_MXFP", "A8W8_MXFP_dynamic", "A4W4_MXFP_dynamic", "A4W4_NVFP_dynamic"])
+def test_odd_shapes_run_on_the_coverage_kernel(proc):
+    """N not a multiple of 128, K a bare multiple of 32 (no MFMA tile divides them): correct on the coverage kernel, at
+    decode and at batch sizes"""
+    tdt = torch.bfloat16
+    N, K = 192, 160
+    lin = _linear(N, K, tdt, seed=4)
+    layer = PROCS[proc](tdt).from_linear(lin, del_orig=False)
+    bias = lin.bias.data.float().cpu().numpy().astype(np.float64)
+    g = torch.Generator().manual_seed(2)
+    for M in (1, 7, 40):
+        x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
+        name = _kernel_name(layer, x)
+        assert name in ("mx_generic_kernel", "mx_gemv_w4_kernel", "mx_gemv_w8_kernel"), name
+        if M > 4:
+            assert name == "mx_generic_kernel", name
+        _check(f"{proc} odd M={M} {name}", layer(x), _oracle(layer, x) + bias, tdt)
+
+
+def test_n_contiguous_mx_weights_take_the_coverage_kernel():
+    """pack(contiguous=True) stores the fp4 bytes [K/2, N] N-contiguous: not the layout the MFMA kernels read, still correct"""
+    tdt = torch.bfloat16
+    N, K = 256, 512
+    lin = _linear(N, K, tdt, seed=6)
+    from gemlite_amd.quant_utils import WeightQuantizerMXFP
+    wq, sc = WeightQuantizerMXFP(compute_dtype=tdt, device=DEV).quantize_mxfp4(lin.weight.data, index=True)
+    layer = gemlite_amd.GemLiteLinear(4, 32, K, N, DType.MXFP4, DType.BF16, scaled_activations=True)
+    layer.pack(wq.view(N, K), sc.view(N, K // 32), None, None, contiguous=True)
+    layer.W_group_mode, layer.channel_scale_mode = 0, 4
+    assert layer.W_q.is_contiguous() and layer.data_contiguous
+    x = (torch.randn(9, K) / 4).to(tdt).to(DEV)
+    assert _kernel_name(layer, x) == "mx_generic_kernel"
+    _check("contiguous fp4", layer(x), _oracle(layer, x), tdt)
+
+
+def test_mx_layer_under_torch_compile_and_graph_capture():
+    tdt = torch.bfloat16
+    lin = _linear(256, 512, tdt, seed=8)
+    layer = H.A8W8_MXFP_dynamic(device=DEV, dtype=tdt, post_scale=False).from_linear(lin, del_orig=False)
+    x = (torch.randn(16, 512) / 4).to(tdt).to(DEV)
+    y = layer(x)
+
+    class Mod(torch.nn.Module):
+        def __init__(self, l):
+            super().__init__()
+            self.l = l
+
+        def forward(self, t):
+            return self.l(t) * 2
+
+    yc = torch.compile(Mod(layer), fullgraph=True)(x)
+    assert torch.equal(yc, y * 2)
+    # hipGraph capture: the quantiser and the matmul are plain launches on the capture stream
+    sstream = torch.cuda.Stream()
+    sstream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(sstream):
+        layer(x)
+    torch.cuda.current_stream().wait_stream(sstream)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=sstream):
+        yg = layer(x)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, y)
