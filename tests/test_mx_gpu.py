@@ -362,3 +362,34 @@ def test_mx_layer_under_torch_compile_and_graph_capture():
     gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(yg, y)
+
+
+def _random_mx_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    procs = [p for p in PROCS]
+    out = []
+    for i in range(n):
+        proc = procs[int(rng.integers(len(procs)))]
+        N = int(rng.choice([64, 128, 192, 256, 384, 512, 1024]))
+        K = int(rng.choice([32, 64, 96, 128, 256, 512, 640, 1024, 1536, 2048, 4096]))
+        M = int(rng.choice([1, 2, 3, 4, 5, 8, 17, 32, 33, 64, 100, 129, 255, 300, 513, 600]))
+        tdt = torch.float16 if rng.random() < 0.4 else torch.bfloat16
+        out.append((i, proc, N, K, M, tdt))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_mx_cases(64, seed=77), ids=lambda c: f"r{c[0]}-{c[1]}-{c[2]}x{c[3]}-M{c[4]}-{str(c[5])[6:]}")
+def test_random_block_scaled_cases_against_the_oracle(case):
+    """Seeded random sweep over processor x (N, K) (incl. sizes no MFMA tile divides) x M (every kernel family: decode, 8-wave
+    scaled MFMA, 256 x 256 prefill tiles, 16-bit-activation MFMA, coverage) x output dtype, each against the float64 oracle."""
+    i, proc, N, K, M, tdt = case
+    if proc == "A4W4_NVFP_dynamic" and K % 32 != 0:
+        pytest.skip("quantiser pieces are 32 k")
+    lin = _linear(N, K, tdt, seed=100 + i)
+    bias = lin.bias.data.float().cpu().numpy().astype(np.float64)
+    layer = PROCS[proc](tdt).from_linear(lin, del_orig=False)
+    g = torch.Generator().manual_seed(1000 + i)
+    x = (torch.randn(M, K, generator=g) * (0.05 + 2 * float(torch.rand(1, generator=g)))).to(tdt).to(DEV)
+    name = _kernel_name(layer, x)
+    y = layer(x)
+    _check(f"random mx {case} {name}", y, _oracle(layer, x) + bias, tdt)
