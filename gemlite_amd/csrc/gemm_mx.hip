@@ -849,7 +849,10 @@ bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, Laun
     if (g.mx_scale_e4m3 || g.group_size != 32) return false;
     const bool f8 = g.mx_x == MX_FP8 && g.mx_w == MX_FP8, f4 = g.mx_x == MX_FP4 && g.mx_w == MX_FP4;
     if (!f8 && !f4) return false;
-    if (a.tuning[0] != 3 && (a.tuning[0] != 0 || a.M < 512)) return false;
+    // worth it from ~100 tiles of 256 x 256 (sweep: M = 512: 8192^2 = 64 tiles 161 vs 110 us for the 128-row kernel, 14336 x 4096 =
+    // 112 tiles 90 vs 90.5; M = 2048, 8192^2 = 256 tiles 154 vs 342)
+    const int64_t tiles256 = (int64_t)(a.N / 256) * ((a.M + 255) / 256);
+    if (a.tuning[0] != 3 && (a.tuning[0] != 0 || tiles256 < 96)) return false;
     if (a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 256 != 0 || a.K % (f8 ? 64 : 128) != 0) return false;
     if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
     if ((int64_t)a.M * a.stride_xm >= (1ll << 31) || (int64_t)a.N * a.stride_wn >= (1ll << 31)) return false;
@@ -916,24 +919,36 @@ bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, Launc
     }
     const int units = (int)(a.K / kstep);
     const int cap = a.M > 64 ? 4 : (a.M > 32 ? 2 : 1);
-    int mi = 1;
+    // Tile rows and K slices (sweep: scripts/probe_mx.py, profiles/r02/mx/probe_mx_tilings.jsonl — 4 shapes x 6 batch sizes x 18
+    // candidates, HBM-cold): nothing is dequantised here, so a tall tile only saves weight re-reads, and slices are cheap as long
+    // as each keeps >= 1024 k.  Take the TALLEST tile (<= the rows M fills) that reaches >= 224 blocks with the slices it may
+    // use, then the fewest slices that get there (mean regret against the measured best 3 %; the rule this replaces, tallest
+    // tile with >= 112 tiles: 12 % incl. long-K shapes such as 4096 x 14336, M = 128: 63 -> 43 us).
+    const int sk_max = units * kstep / 1024 < 1 ? 1 : (units * kstep / 1024 > 8 ? 8 : units * kstep / 1024);
+    int mi = 1, splitk = 0;
     for (int c = cap; c >= 1; c >>= 1) {
-        if ((int64_t)(a.N / 128) * ((a.M + 32 * c - 1) / (32 * c)) >= 112) { mi = c; break; }
+        const int64_t t = (int64_t)(a.N / 128) * ((a.M + 32 * c - 1) / (32 * c));
+        if (t * sk_max >= 224 || c == 1) {
+            mi = c;
+            for (int sk = 1; sk <= sk_max && sk <= units; ++sk) {
+                splitk = sk;
+                if (t * sk >= 224) break;
+            }
+            break;
+        }
     }
     if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4) mi = a.tuning[2];
     const int bm = 32 * mi;
     const int64_t tiles = (int64_t)(a.N / 128) * ((a.M + bm - 1) / bm);
-    int splitk = 0;
     if (a.tuning[1] > 0) {
         if (a.tuning[1] > units) return false;
         splitk = a.tuning[1];
-    } else {
-        for (int sk = 1; sk <= units && sk <= 32; ++sk) {
-            if (sk > 1 && units / sk < 2) continue;
+    } else if (a.tuning[2] != 0 || !splitk) {  // forced tile height: the fewest slices that fill the chip
+        splitk = 1;
+        for (int sk = 1; sk <= sk_max && sk <= units; ++sk) {
             splitk = sk;
             if (tiles * sk >= 224) break;
         }
-        if (!splitk) splitk = 1;
     }
     if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
     if ((uint64_t)splitk * bm * 128 * 4 >= (1ull << 31)) return false;

@@ -151,7 +151,9 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(args(16, 8, 256, 4, N=8192, K=8192)) == "gemm_mx_a8w8_kernel<128x128>"
     assert name(args(16, 4, 256, 2, N=8192, K=8192)) == "gemm_mx_a8w4_kernel<128x128>"
     assert name(args(17, 4, 256, 4, N=8192, K=8192)) == "gemm_mx_a4w4_kernel<128x128>"
-    assert name(args(16, 8, 256, 4)) == "gemm_mx_a8w8_kernel<64x128>"   # the tallest tile that still gives >= 112 tiles
+    assert name(args(16, 8, 256, 4)) == "gemm_mx_a8w8_kernel<128x128>"  # the tallest tile that fills the chip with <= K / 1024 slices
+    assert name(args(16, 8, 2048, 4, N=8192, K=8192)) == "gemm_mx_a8w8_tile_kernel<256x256>"  # >= 96 tiles of 256 x 256
+    assert name(args(16, 8, 512, 4, N=8192, K=8192)) == "gemm_mx_a8w8_kernel<128x128>"        # 64 tiles: the 128-row kernel
     assert name(args(16, 8, 1, 4)) == "mx_gemv_w8_kernel"             # decode: streaming kernel up to 4 rows
     assert name(args(17, 4, 4, 4)) == "mx_gemv_w4_kernel"
     assert name(args(16, 8, 5, 4)) == "gemm_mx_a8w8_kernel<32x128>"

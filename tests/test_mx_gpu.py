@@ -236,13 +236,14 @@ def test_reference_acceptance_bar(proc, tol, M):
                                         ("A8W8_MXFP_dynamic_post", "gemm_mx_a8w8_tile_kernel")])
 @pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
 def test_prefill_tile_kernel_vs_oracle(proc, kname, tdt):
-    """256 x 256 tiles with both operands through LDS: picked from M = 512, forced (tuning[0] = 3) on ragged smaller M"""
+    """256 x 256 tiles with both operands through LDS, forced (tuning[0] = 3) on ragged M (the planner picks it from ~100 tiles:
+    test_prefill_tile_kernel_is_the_default_when_the_tiles_fill_the_chip)"""
     N, K = 512, 2048
     lin = _linear(N, K, tdt, seed=21)
     bias = lin.bias.data.clone()
     layer = PROCS[proc](tdt).from_linear(lin, del_orig=False)
     g = torch.Generator().manual_seed(13)
-    for M, tuning in ((700, (0, 0, 0, 0)), (512, (0, 0, 0, 0)), (300, (3, 0, 0, 0)), (33, (3, 0, 0, 0))):
+    for M, tuning in ((700, (3, 0, 0, 0)), (512, (3, 0, 0, 0)), (300, (3, 0, 0, 0)), (33, (3, 0, 0, 0))):
         x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
         try:
             C.TUNING_OVERRIDE = tuning if any(tuning) else None
@@ -258,6 +259,18 @@ def test_prefill_tile_kernel_vs_oracle(proc, kname, tdt):
             _check(f"{proc} {tdt} M={M} 8-wave kernel", layer(x), ref, tdt)
         finally:
             C.TUNING_OVERRIDE = None
+
+
+def test_prefill_tile_kernel_is_the_default_when_the_tiles_fill_the_chip():
+    tdt = torch.bfloat16
+    N, K, M = 4096, 512, 1536   # 16 x 6 = 96 tiles of 256 x 256
+    lin = _linear(N, K, tdt, seed=31)
+    lin.bias = None
+    layer = H.A4W4_MXFP_dynamic(device=DEV, dtype=tdt).from_linear(lin, del_orig=False)
+    x = (torch.randn(M, K, generator=torch.Generator().manual_seed(3)) / 4).to(tdt).to(DEV)
+    assert _kernel_name(layer, x).startswith("gemm_mx_a4w4_tile_kernel")
+    _check("tile kernel, natural", layer(x), _oracle(layer, x), tdt)
+    assert _kernel_name(layer, x[:1024]).startswith("gemm_mx_a4w4_kernel")  # 64 tiles: the 128-row kernel
 
 
 def test_mx_layer_state_dict_round_trip_and_functional_op():
