@@ -78,6 +78,7 @@ WORKLOADS = {
     "mx_a8w8_8192_m256": (8192, 8192, 8, 32, 256, "mxa8", 4, "mfma"),
     "mx_a8w8_8192_m2048": (8192, 8192, 8, 32, 2048, "mxa8", 4, "mfma"),
     "mx_a8w4_8192_m256": (8192, 8192, 4, 32, 256, "mxa8", 8, "mfma"),
+    "mx_a8w4_8192_m2048": (8192, 8192, 4, 32, 2048, "mxa8", 8, "mfma"),
     "mx_a4w4_4096_m1": (4096, 4096, 4, 32, 1, "mxa4", 32, "hbm"),
     "mx_a4w4_8192_m256": (8192, 8192, 4, 32, 256, "mxa4", 8, "mfma"),
     "mx_a4w4_8192_m2048": (8192, 8192, 4, 32, 2048, "mxa4", 8, "mfma"),

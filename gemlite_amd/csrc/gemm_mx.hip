@@ -629,21 +629,26 @@ typedef void (*mx_kernel_fn_t)(const GenericParams);
 // 88 us = 3.14 PFLOP/s (0.31); the 128-row kernel above: 342 / 251 us.  PMC: the matrix pipe is busy 40 % of the time, waves
 // wait 36 % (barrier + the DMA of HBM-cold panels, 2.4 us ahead) — not LDS, not the fabric (XCD-aware tile order: 1 %).
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int mxt_slot(int r, int s) { return r * 64 + ((s ^ ((r >> 2) & 3)) << 4); }
+// row r, logical 16-byte slot s of a tile with P bytes per row: rows 256 / P apart share an LDS bank period, so the slot is
+// XOR-ed with (r / (256 / P)) — 16 consecutive rows then read 16 different bank groups
+template <int P>
+__device__ __forceinline__ int mxt_slot(int r, int s) { return r * P + ((s ^ ((r / (256 / P)) & (P / 16 - 1))) << 4); }
 
-// FMT 0: fp8 x fp8, 4: fp4 x fp4;  NST LDS stages of 64 bytes per row;  BLKX: activation block scales (channel_scale_mode 4)
-template <int FMT, int NST, bool BLKX>
+// AF / BF: element format of x / w (0 fp8 e4m3, 4 fp4 e2m1): fp8 x fp8, fp4 x fp4 and fp8 x fp4 (A8W4).  NST LDS stages.
+// BLKX: activation block scales (channel_scale_mode 4), else the constant 127.
+template <int AF, int BF, int NST, bool BLKX>
 __global__ __launch_bounds__(512, 2) void gemm_mx_tile_kernel(const GenericParams p) {
     using namespace async;
-    constexpr int BM = 256, BN = 256, PITCH = 64;
+    constexpr int BM = 256, BN = 256;
     constexpr int MI = 4, NI = 2;
-    constexpr int A_BYTES = BM * PITCH, TILES = (BM + BN) * PITCH;   // 32 KiB of operand tiles per stage
+    constexpr int KSTAGE = AF == 0 ? 64 : 128;                        // k per stage (64 bytes of every x row)
+    constexpr int PA = 64, PB = BF == 0 ? KSTAGE : KSTAGE / 2;        // bytes per row and stage of the x / w tile (w: 64, or 32 for A8W4)
+    constexpr int A_BYTES = BM * PA, TILES = A_BYTES + BN * PB;       // operand tiles per stage: 32 KiB (24 KiB)
     constexpr int SC_A = TILES, SC_B = TILES + 1024, STAGE = TILES + 2048;  // + 1 KiB activation scales + 1 KiB weight scales
-    constexpr int KSTAGE = FMT == 0 ? 64 : 128;                       // k per stage
     constexpr int NSL = KSTAGE / 64;                                  // 64-k slices per stage (1 or 2)
     constexpr int KBLK = KSTAGE / 32;                                 // scale blocks per stage (2 or 4)
-    constexpr int FV = FMT == 0 ? 2 : 1;                              // 16-byte pieces per fragment
-    constexpr int PIECES = TILES / 1024 / 8;                          // tile pieces per wave and stage (4)
+    constexpr int FVA = AF == 0 ? 2 : 1, FVB = BF == 0 ? 2 : 1;       // 16-byte pieces per fragment
+    constexpr int PIECES = TILES / 1024 / 8;                          // tile pieces per wave and stage (4 or 3)
     constexpr int R = PIECES + 1;                                     // + one scale piece: requests per wave and stage
     static_assert((NST - 1) * R <= 63 && NST >= 3 && NST % 2 == 0, "vmcnt is a 6-bit counter; stage parity must be static");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST][STAGE], later the per-wave output tiles
@@ -663,31 +668,38 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_tile_kernel(const GenericParam
     }
     const int m0 = mt * BM, n0 = nt * BN;
     const int nstages = p.K / KSTAGE;
-    const int row_bytes = FMT == 0 ? p.K : p.K / 2;
+    const int xrow_bytes = AF == 0 ? p.K : p.K / 2, wrow_bytes = BF == 0 ? p.K : p.K / 2;
     const int blocks_k = p.K / 32;
     constexpr bool blk_x = BLKX;
     const int m_pad = (p.M + 31) / 32 * 32;
 
-    const srd_t rsX = make_srd(p.x, (uint32_t)((int64_t)(p.M - 1) * p.stride_xm + row_bytes));
-    const srd_t rsW = make_srd(p.w, (uint32_t)((int64_t)(p.N - 1) * p.stride_wn + row_bytes));
+    const srd_t rsX = make_srd(p.x, (uint32_t)((int64_t)(p.M - 1) * p.stride_xm + xrow_bytes));
+    const srd_t rsW = make_srd(p.w, (uint32_t)((int64_t)(p.N - 1) * p.stride_wn + wrow_bytes));
     const srd_t rsSW = make_srd(p.scales, (uint32_t)((int64_t)(blocks_k - 1) * p.stride_meta_g + p.N));
     const srd_t rsSA = blk_x ? make_srd(p.sx_blocks, (uint32_t)((int64_t)(m_pad - 1) * p.stride_sx_blk_m + blocks_k)) : rsSW;
 
     // Per wave and stage: PIECES tile pieces (1 KiB = 16 rows x 64 bytes; waves 0..3 move x, waves 4..7 move w; lane i's 16 bytes
     // land at +16 i = row i / 4, physical slot i % 4 = logical slot ^ ((row >> 2) & 3)) and ONE 256-byte scale piece: waves 0..3
     // the activation-scale dwords of rows [64 wave, +64), waves 4..7 one 32-k block row of weight scales (fp8: rows repeat).
-    uint32_t dvoff[PIECES];
-    const bool is_w = wave >= 4;
+    uint32_t dvoff[PIECES], dsoff_step[PIECES];
+    bool d_is_w[PIECES];  // wave-uniform per piece (A8W4: 24 pieces, the x / w border falls inside wave 5)
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
-        const int byte = (wave * PIECES + j) * 1024 + lane * 16;
-        const int tb = is_w ? byte - A_BYTES : byte;
-        const int r = tb / PITCH, phys = (tb % PITCH) / 16;
-        const int logical = phys ^ ((r >> 2) & 3);
-        if (is_w) dvoff[j] = (uint32_t)((int64_t)(n0 + r) * p.stride_wn + logical * 16);
-        else dvoff[j] = m0 + r < p.M ? (uint32_t)((int64_t)(m0 + r) * p.stride_xm + logical * 16) : 0x80000000u;
+        const int piece = wave * PIECES + j;
+        d_is_w[j] = piece * 1024 >= A_BYTES;
+        const int tb = (d_is_w[j] ? piece * 1024 - A_BYTES : piece * 1024) + lane * 16;
+        if (d_is_w[j]) {
+            const int r = tb / PB, phys = (tb % PB) / 16;
+            const int logical = phys ^ ((r / (256 / PB)) & (PB / 16 - 1));
+            dvoff[j] = (uint32_t)((int64_t)(n0 + r) * p.stride_wn + logical * 16);
+        } else {
+            const int r = tb / PA, phys = (tb % PA) / 16;
+            const int logical = phys ^ ((r / (256 / PA)) & (PA / 16 - 1));
+            dvoff[j] = m0 + r < p.M ? (uint32_t)((int64_t)(m0 + r) * p.stride_xm + logical * 16) : 0x80000000u;
+        }
+        dsoff_step[j] = d_is_w[j] ? PB : PA;
     }
-    const srd_t rsD = is_w ? rsW : rsX;
+    const bool is_w = wave >= 4;  // scale pieces: waves 0..3 activation scales, 4..7 weight scales
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const uint32_t lds0 = lds_base + (uint32_t)(wave * PIECES) * 1024u;
     const int brow = (wave & 3) % KBLK;
@@ -698,7 +710,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_tile_kernel(const GenericParam
     auto request = [&](int buf, int stage) {
 #pragma unroll
         for (int j = 0; j < PIECES; ++j)
-            req_lds16(rsD, lds0 + (uint32_t)(buf * STAGE + j * 1024), dvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(stage * PITCH));
+            req_lds16(d_is_w[j] ? rsW : rsX, lds0 + (uint32_t)(buf * STAGE + j * 1024), dvoff[j],
+                      (uint32_t)__builtin_amdgcn_readfirstlane(stage * (int)dsoff_step[j]));
         // activation scales: the ALIGNED dword that holds this stage's KBLK bytes (fp8: two stages share a dword);
         // weight scales: block row stage * KBLK + brow
         const int so = is_w ? (stage * KBLK) * (int)p.stride_meta_g : (blk_x ? ((stage * KBLK) & ~3) : 0);
@@ -708,16 +721,15 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_tile_kernel(const GenericParam
     // (fp8: slots {h, 2 + h}; fp4: slot 2g + h; the swizzle (row >> 2) & 3 = (col >> 2) & 3 does not depend on the row block),
     // and the stage's LDS offset is added from an SGPR the optimiser cannot see through: folded into per-stage address
     // registers, the 4 x 24 addresses spilled, and a scratch reload inside the loop costs a vmcnt(0) — the whole DMA pipeline.
-    int abase[NSL][FV], bbase[NSL][FV];
+    int abase[NSL][FVA], bbase[NSL][FVB];
 #pragma unroll
-    for (int g = 0; g < NSL; ++g)
+    for (int g = 0; g < NSL; ++g) {
 #pragma unroll
-        for (int v = 0; v < FV; ++v) {
-            const int slot = FMT == 0 ? 2 * v + h : 2 * g + h;
-            abase[g][v] = mxt_slot(wm * 128 + col, slot);
-            bbase[g][v] = A_BYTES + mxt_slot(wn * 64 + col, slot);
-        }
-    const int sa_base = SC_A + (wm * 128 + col) * 4 + (FMT == 0 ? h : 0);
+        for (int v = 0; v < FVA; ++v) abase[g][v] = mxt_slot<PA>(wm * 128 + col, AF == 0 ? 4 * g + 2 * v + h : 2 * g + h);
+#pragma unroll
+        for (int v = 0; v < FVB; ++v) bbase[g][v] = A_BYTES + mxt_slot<PB>(wn * 64 + col, BF == 0 ? 4 * g + 2 * v + h : 2 * g + h);
+    }
+    const int sa_base = SC_A + (wm * 128 + col) * 4 + (KBLK == 2 ? h : 0);
     const int sb_base = SC_B + h * 256 + wn * 64 + col;
     const uint32_t sh_h = 8u * (uint32_t)h;
 
@@ -730,17 +742,14 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_tile_kernel(const GenericParam
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
     // operands: the 4 weight fragments of a 64-k slice (+ this lane's weight block scales), one activation fragment (+ scale)
-    typedef typename std::conditional<FMT == 0, v8i, u32x4>::type frag_t;  // fp4 fragments are 4 registers
-    struct BSet { frag_t b[NI]; uint32_t s[NI]; };
-    struct AFr { frag_t a; uint32_t s; };
-    auto mk = [](u32x4 v0, u32x4 v1) -> frag_t {
-        if constexpr (FMT == 0) return (v8i){(int)v0[0], (int)v0[1], (int)v0[2], (int)v0[3], (int)v1[0], (int)v1[1], (int)v1[2], (int)v1[3]};
-        else return v0;
+    typedef typename std::conditional<AF == 0, v8i, u32x4>::type afrag_t;  // fp4 fragments are 4 registers
+    typedef typename std::conditional<BF == 0, v8i, u32x4>::type bfrag_t;
+    struct BSet { bfrag_t b[NI]; uint32_t s[NI]; };
+    struct AFr { afrag_t a; uint32_t s; };
+    auto mk8 = [](u32x4 v0, u32x4 v1) -> v8i {
+        return (v8i){(int)v0[0], (int)v0[1], (int)v0[2], (int)v0[3], (int)v1[0], (int)v1[1], (int)v1[2], (int)v1[3]};
     };
-    auto wide = [](frag_t f) -> v8i {
-        if constexpr (FMT == 0) return f;
-        else return (v8i){(int)f[0], (int)f[1], (int)f[2], (int)f[3], 0, 0, 0, 0};
-    };
+    auto wide4 = [](u32x4 f) -> v8i { return (v8i){(int)f[0], (int)f[1], (int)f[2], (int)f[3], 0, 0, 0, 0}; };
     auto stage_ptr = [&](int buf) -> const unsigned char* {
         int off = buf * STAGE;
         asm volatile("" : "+s"(off));  // opaque: one s-register per stage, added at every read
@@ -749,25 +758,29 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_tile_kernel(const GenericParam
     auto load_b = [&](BSet& bs, const unsigned char* sb, int g) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const u32x4 v0 = *(const u32x4*)(sb + bbase[g][0] + ni * 32 * PITCH);
-            const u32x4 v1 = FV == 2 ? *(const u32x4*)(sb + bbase[g][FV - 1] + ni * 32 * PITCH) : (u32x4){0u, 0u, 0u, 0u};
-            bs.b[ni] = mk(v0, v1);
+            const u32x4 v0 = *(const u32x4*)(sb + bbase[g][0] + ni * 32 * PB);
+            if constexpr (BF == 0) bs.b[ni] = mk8(v0, *(const u32x4*)(sb + bbase[g][FVB - 1] + ni * 32 * PB));
+            else bs.b[ni] = v0;
             bs.s[ni] = sb[sb_base + 2 * g * 256 + ni * 32];
         }
     };
     auto load_a = [&](AFr& af, const unsigned char* sb, int g, int mi, int par) {
-        const u32x4 v0 = *(const u32x4*)(sb + abase[g][0] + mi * 32 * PITCH);
-        const u32x4 v1 = FV == 2 ? *(const u32x4*)(sb + abase[g][FV - 1] + mi * 32 * PITCH) : (u32x4){0u, 0u, 0u, 0u};
-        af.a = mk(v0, v1);
+        const u32x4 v0 = *(const u32x4*)(sb + abase[g][0] + mi * 32 * PA);
+        if constexpr (AF == 0) af.a = mk8(v0, *(const u32x4*)(sb + abase[g][FVA - 1] + mi * 32 * PA));
+        else af.a = v0;
         if constexpr (!blk_x) af.s = 127u;
-        else if constexpr (FMT == 0) af.s = sb[sa_base + mi * 128 + par * 2];                               // block h of this stage
+        else if constexpr (KBLK == 2) af.s = sb[sa_base + mi * 128 + par * 2];                               // block h of this stage
         else af.s = *(const uint32_t*)(sb + sa_base + mi * 128) >> (sh_h + 16u * (uint32_t)g);              // block 2g + h
     };
     auto mma_row = [&](const AFr& af, const BSet& bs, int mi) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(af.a), wide(bs.b[ni]), acc[mi][ni], FMT, FMT, 0, (int)af.s, 0,
-                                                                         (int)bs.s[ni]);
+        {
+            v8i av, bv;
+            if constexpr (AF == 0) av = af.a; else av = wide4(af.a);
+            if constexpr (BF == 0) bv = bs.b[ni]; else bv = wide4(bs.b[ni]);
+            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[mi][ni], AF, BF, 0, (int)af.s, 0, (int)bs.s[ni]);
+        }
     };
 
 #pragma unroll
@@ -848,12 +861,13 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_tile_kernel(const GenericParam
 bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
     if (g.mx_scale_e4m3 || g.group_size != 32) return false;
     const bool f8 = g.mx_x == MX_FP8 && g.mx_w == MX_FP8, f4 = g.mx_x == MX_FP4 && g.mx_w == MX_FP4;
-    if (!f8 && !f4) return false;
+    const bool f84 = g.mx_x == MX_FP8 && g.mx_w == MX_FP4;
+    if (!f8 && !f4 && !f84) return false;
     // worth it from ~100 tiles of 256 x 256 (sweep: M = 512: 8192^2 = 64 tiles 161 vs 110 us for the 128-row kernel, 14336 x 4096 =
     // 112 tiles 90 vs 90.5; M = 2048, 8192^2 = 256 tiles 154 vs 342)
     const int64_t tiles256 = (int64_t)(a.N / 256) * ((a.M + 255) / 256);
     if (a.tuning[0] != 3 && (a.tuning[0] != 0 || tiles256 < 96)) return false;
-    if (a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 256 != 0 || a.K % (f8 ? 64 : 128) != 0) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 256 != 0 || a.K % (f4 ? 128 : 64) != 0) return false;
     if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
     if ((int64_t)a.M * a.stride_xm >= (1ll << 31) || (int64_t)a.N * a.stride_wn >= (1ll << 31)) return false;
     if ((int64_t)(a.K / 32) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
@@ -871,12 +885,13 @@ bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, Laun
     constexpr int nst = 4;  // LDS stages of 34 KiB (tiles + scales): 136 KiB
     if (a.stride_meta_n != 1 || ((uintptr_t)a.scales % 4) != 0 || a.stride_meta_g % 4 != 0) return false;  // 4-byte scale pieces
     const bool bx = a.channel_scale_mode == 4;
-    mx_kernel_fn_t f = f8 ? (bx ? gemm_mx_tile_kernel<0, nst, true> : gemm_mx_tile_kernel<0, nst, false>)
-                          : (bx ? gemm_mx_tile_kernel<4, nst, true> : gemm_mx_tile_kernel<4, nst, false>);
+    mx_kernel_fn_t f = f8 ? (bx ? gemm_mx_tile_kernel<0, 0, nst, true> : gemm_mx_tile_kernel<0, 0, nst, false>)
+                      : (f4 ? (bx ? gemm_mx_tile_kernel<4, 4, nst, true> : gemm_mx_tile_kernel<4, 4, nst, false>)
+                            : (bx ? gemm_mx_tile_kernel<0, 4, nst, true> : gemm_mx_tile_kernel<0, 4, nst, false>));
     g.splitk = 1;
     g.flags = a.tuning[3];  // & 16: plain M-fastest tile order (A/B runs)
     lp.fn = (const void*)f;
-    lp.name = f8 ? "gemm_mx_a8w8_tile_kernel<256x256>" : "gemm_mx_a4w4_tile_kernel<256x256>";
+    lp.name = f8 ? "gemm_mx_a8w8_tile_kernel<256x256>" : (f4 ? "gemm_mx_a4w4_tile_kernel<256x256>" : "gemm_mx_a8w4_tile_kernel<256x256>");
     lp.grid = dim3((unsigned)tiles, 1, 1);
     lp.block = dim3(512, 1, 1);
     lp.lds_bytes = (size_t)nst * ((256 + 256) * 64 + 2048);

@@ -233,7 +233,8 @@ def test_reference_acceptance_bar(proc, tol, M):
 
 
 @pytest.mark.parametrize("proc,kname", [("A8W8_MXFP_dynamic", "gemm_mx_a8w8_tile_kernel"), ("A4W4_MXFP_dynamic", "gemm_mx_a4w4_tile_kernel"),
-                                        ("A8W8_MXFP_dynamic_post", "gemm_mx_a8w8_tile_kernel")])
+                                        ("A8W8_MXFP_dynamic_post", "gemm_mx_a8w8_tile_kernel"), ("A8W4_MXFP_dynamic", "gemm_mx_a8w4_tile_kernel"),
+                                        ("A8W4_MXFP_dynamic_post", "gemm_mx_a8w4_tile_kernel")])
 @pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
 def test_prefill_tile_kernel_vs_oracle(proc, kname, tdt):
     """256 x 256 tiles with both operands through LDS, forced (tuning[0] = 3) on ragged M (the planner picks it from ~100 tiles:
