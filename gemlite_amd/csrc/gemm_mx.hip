@@ -887,7 +887,7 @@ bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, Laun
     const bool bx = a.channel_scale_mode == 4;
     mx_kernel_fn_t f = f8 ? (bx ? gemm_mx_tile_kernel<0, 0, nst, true> : gemm_mx_tile_kernel<0, 0, nst, false>)
                       : (f4 ? (bx ? gemm_mx_tile_kernel<4, 4, nst, true> : gemm_mx_tile_kernel<4, 4, nst, false>)
-                            : (bx ? gemm_mx_tile_kernel<0, 4, nst, true> : gemm_mx_tile_kernel<0, 4, nst, false>));
+                            : (bx ? gemm_mx_tile_kernel<0, 4, nst, true> : gemm_mx_tile_kernel<0, 4, nst, false>));  // (6 stages of 26 KiB for A8W4: 142 vs 139 us — depth is not the limit)
     g.splitk = 1;
     g.flags = a.tuning[3];  // & 16: plain M-fastest tile order (A/B runs)
     lp.fn = (const void*)f;
