@@ -180,4 +180,12 @@ def workspace(device: torch.device, stream_handle: int, nbytes: int) -> torch.Te
 
 
 def current_stream_handle(device: torch.device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """hipStream_t of torch's current stream on `device`, as an int.  (torch.cuda.current_stream() builds a Stream object:
+    4 us of the per-launch host path; the raw getter is the same value.)"""
+    idx = device.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    try:
+        return torch._C._cuda_getCurrentRawStream(idx)
+    except AttributeError:  # pragma: no cover  (private API moved: fall back to the public one)
+        return torch.cuda.current_stream(device).cuda_stream

@@ -11,6 +11,7 @@ What is different by design: there is no Triton and no autotuner.  ``forward`` b
 reference kernel families map onto hand-written CDNA4 kernels inside libgemlite_hip.so.  Tensors must live on
 the GPU — there is no CPU / eager fallback and a missing library raises.
 """
+import bisect
 import json
 import logging
 import os
@@ -52,22 +53,28 @@ _FILE_LOCK = threading.Lock()
 # ------------------------------------------------------------------------------------------------------
 # small setters with the reference's names (core.py:86-97)
 # ------------------------------------------------------------------------------------------------------
-def _closest_m_default(M: int) -> int:
-    """Round M up to the reference's tuning buckets: powers of two plus the 1/2 and 1/4 interpolations for
-    2^i >= 32, capped at 4096 (triton_kernels/utils.py:140-174)."""
-    if M <= 0:
-        return 1  # the reference's table maps 0 to its smallest bucket
-    if M >= 4096:
-        return 4096
-    vals = set()
-    i = 0
+def _m_buckets():
+    vals, i = set(), 0
     while (1 << i) <= 4096:
         v, nxt = 1 << i, 1 << (i + 1)
         vals.add(v)
         if v >= 32 and nxt <= 4096:
             vals.update(((v + nxt) // 2, (v + nxt) // 4))
         i += 1
-    return min(v for v in vals if v >= M)
+    return sorted(vals)
+
+
+_M_BUCKETS = _m_buckets()
+
+
+def _closest_m_default(M: int) -> int:
+    """Round M up to the reference's tuning buckets: powers of two plus the 1/2 and 1/4 interpolations for
+    2^i >= 32, capped at 4096 (triton_kernels/utils.py:140-174).  (Table built once: this sits on the per-launch host path.)"""
+    if M <= 0:
+        return 1  # the reference's table maps 0 to its smallest bucket
+    if M >= 4096:
+        return 4096
+    return _M_BUCKETS[bisect.bisect_left(_M_BUCKETS, M)]
 
 
 _closest_m = _closest_m_default
@@ -309,10 +316,12 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
                  x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0)
         if not fused:
             x, scales_x = scale_activations_per_token(x, w_dtype=DTYPE_TO_TORCH[in_code])
-    x2 = x.view(-1, x.shape[-1])
+    x2 = x if x.dim() == 2 else x.view(-1, x.shape[-1])
     # matmul_type < 0 (auto) is resolved inside the library: the HIP kernel families have their own M
     # thresholds (GEMV <= 4 rows, streaming MFMA above), unlike the Triton ones of get_matmul_type()
-    out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type).view(out_shape)
+    out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type)
+    if len(out_shape) != 2:
+        out = out.view(out_shape)
     if bias is not None:
         out += bias
     return out
