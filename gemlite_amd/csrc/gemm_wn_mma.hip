@@ -180,9 +180,17 @@ struct Extract<1> {
 // ---- codes -> one B fragment (8 dequantised 16-bit floats, natural k order) --------------------------------------------
 template <typename Tag>
 struct Convert;
+// Integer codes 0 .. 15 read as e4m3 BYTES are linear (b < 8: subnormal b * 2^-9; 8 <= b < 16: (8 + (b - 8)) * 2^-9), so the
+// block-scale converter of gfx950 turns two code bytes into two exact fp32 integers in ONE instruction (scale 2^9) where
+// v_cvt_f32_ubyte<i> takes two.  HI selects bytes 2, 3 of the register (an immediate).
+typedef float f2_t __attribute__((ext_vector_type(2)));
+template <bool HI>
+__device__ __forceinline__ f2_t codes_f32x2(uint32_t bytes) { return __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(bytes, 512.0f, HI); }
+
 template <>
 struct Convert<bf16_tag> {
     float A, B;  // v = fma(q, A, B) in fp32, rounded once to bf16
+    f2_t te, to; // LIN: the fp32 values of codes (4h, 4h + 2) and (4h + 1, 4h + 3) of the half-slice in flight
     __device__ __forceinline__ void set(float s, float z, float u13, float u4) {
         A = s;
         B = z * __builtin_fmaf(-u13, s, u4);
@@ -192,6 +200,21 @@ struct Convert<bf16_tag> {
         const float lo = (float)((ev >> (8 * j)) & 0xFFu), hi = (float)((od >> (8 * j)) & 0xFFu);
         const b2_t v = {(__bf16)__builtin_fmaf(lo, A, B), (__bf16)__builtin_fmaf(hi, A, B)};
         return __builtin_bit_cast(uint32_t, v);
+    }
+    // LIN (codes < 16): per half-slice two converter ops + two v_pk_fma_f32, then one v_cvt_pk_bf16_f32 per pair: 15 VALU per
+    // fragment with the extraction instead of 23
+    template <bool LIN>
+    __device__ __forceinline__ uint32_t put(uint32_t ev, uint32_t od, int j) {
+        if constexpr (!LIN) return pair(ev, od, j);
+        else {
+            if ((j & 1) == 0) {
+                const f2_t A2 = {A, A}, B2 = {B, B};
+                te = __builtin_elementwise_fma((j >> 1) ? codes_f32x2<true>(ev) : codes_f32x2<false>(ev), A2, B2);
+                to = __builtin_elementwise_fma((j >> 1) ? codes_f32x2<true>(od) : codes_f32x2<false>(od), A2, B2);
+            }
+            const b2_t v = {(__bf16)((j & 1) ? te.y : te.x), (__bf16)((j & 1) ? to.y : to.x)};
+            return __builtin_bit_cast(uint32_t, v);
+        }
     }
 };
 template <>
@@ -210,6 +233,8 @@ struct Convert<half_tag> {
         const h2_t q = __builtin_bit_cast(h2_t, h) - (h2_t){(_Float16)1024.0f, (_Float16)1024.0f};
         return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(q - zsub2, s2, zadd2));
     }
+    template <bool LIN>
+    __device__ __forceinline__ uint32_t put(uint32_t ev, uint32_t od, int j) { return pair(ev, od, j); }
 };
 
 // ---- codes -> one B fragment in the activation type ----------------------------------------------------------------------
@@ -218,7 +243,8 @@ struct ConvertX {  // 16-bit activations: the converters above, pair j -> regist
     Convert<Tag> c;
     __device__ __forceinline__ void set(float s, float z, float u13, float u4) { c.set(s, z, u13, u4); }
     __device__ __forceinline__ void prep(uint32_t&, uint32_t&) const {}
-    __device__ __forceinline__ void put(u32x4& out, uint32_t ev, uint32_t od, int j) const { out[j] = c.pair(ev, od, j); }
+    template <bool LIN>
+    __device__ __forceinline__ void put(u32x4& out, uint32_t ev, uint32_t od, int j) { out[j] = c.template put<LIN>(ev, od, j); }
 };
 template <typename Tag>
 struct ConvertX<Tag, GEMLITE_DT_FP8E4> {  // fp32 fma, one rounding to e4m3 (v_cvt_pk_fp8_f32): pair j -> half j & 1 of register j >> 1
@@ -228,10 +254,23 @@ struct ConvertX<Tag, GEMLITE_DT_FP8E4> {  // fp32 fma, one rounding to e4m3 (v_c
         B = z * __builtin_fmaf(-u13, s, u4);
     }
     __device__ __forceinline__ void prep(uint32_t&, uint32_t&) const {}
-    __device__ __forceinline__ void put(u32x2& out, uint32_t ev, uint32_t od, int j) const {
-        const float lo = (float)((ev >> (8 * j)) & 0xFFu), hi = (float)((od >> (8 * j)) & 0xFFu);
+    f2_t te, to;
+    template <bool LIN>
+    __device__ __forceinline__ void put(u32x2& out, uint32_t ev, uint32_t od, int j) {
+        float a, b;
+        if constexpr (LIN) {  // see Convert<bf16_tag>::put
+            if ((j & 1) == 0) {
+                const f2_t A2 = {A, A}, B2 = {B, B};
+                te = __builtin_elementwise_fma((j >> 1) ? codes_f32x2<true>(ev) : codes_f32x2<false>(ev), A2, B2);
+                to = __builtin_elementwise_fma((j >> 1) ? codes_f32x2<true>(od) : codes_f32x2<false>(od), A2, B2);
+            }
+            a = (j & 1) ? te.y : te.x;
+            b = (j & 1) ? to.y : to.x;
+        } else {
+            const float lo = (float)((ev >> (8 * j)) & 0xFFu), hi = (float)((od >> (8 * j)) & 0xFFu);
+            a = __builtin_fmaf(lo, A, B), b = __builtin_fmaf(hi, A, B);
+        }
         const uint32_t prev = out[j >> 1];
-        const float a = __builtin_fmaf(lo, A, B), b = __builtin_fmaf(hi, A, B);
         out[j >> 1] = (j & 1) ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)prev, true)
                               : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)prev, false);
     }
@@ -245,6 +284,7 @@ struct ConvertX<Tag, GEMLITE_DT_INT8> {  // integer codes minus an integer zero 
         ev = ((ev | 0x80808080u) - zz) ^ 0x80808080u;
         od = ((od | 0x80808080u) - zz) ^ 0x80808080u;
     }
+    template <bool LIN>
     __device__ __forceinline__ void put(u32x2& out, uint32_t ev, uint32_t od, int j) const {
         if (j & 1) out[j >> 1] = __builtin_amdgcn_perm(od, ev, j == 1 ? 0x05010400u : 0x07030602u);  // {ev[2r], od[2r], ev[2r+1], od[2r+1]}
     }
@@ -452,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if ((MI == 8 ? j + 1 : (j * MI) / 4) == mi) cv.put(out, ev, od, j);
+                if ((MI == 8 ? j + 1 : (j * MI) / 4) == mi) cv.template put<(NBITS <= 4)>(out, ev, od, j);
         }
     };
 
