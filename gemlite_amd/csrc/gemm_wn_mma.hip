@@ -307,7 +307,11 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 // EXP (development builds only, -DGL_MMA_EXPERIMENTS + tuning[3] >> 8): drop parts of the K loop to see what each costs —
 // 1 barrier + counted wait, 2 dequant VALU, 4 A-fragment reads, 8 x DMA requests, 16 weight requests, 32 the scalar address
 // arithmetic of the requests (constant offsets).  Results are wrong.
-template <typename Tag, int NBITS, int MI, int KSTEP, int RD, int NST, int EXP = 0, int XDT = 0>
+// KH = 2 (default): tile 32 MI x 128, wave (cg = wave & 3, kh = wave >> 2) owns 32 columns x one HALF of every K step.
+// KH = 1 ("wide"): tile 32 MI x 256, wave cg = wave owns 32 columns x the whole step — every x byte DMA'd into LDS feeds twice
+// the columns: the 128-column tiles move 576 B of operands per k for 2 * 256 * 128 flop, i.e. ~10 TB/s through the L2s at the
+// prefill rate they reach, which is the measured ceiling of that path; the wide tile needs 640 B per k for twice the flop.
+template <typename Tag, int NBITS, int MI, int KSTEP, int RD, int NST, int EXP = 0, int XDT = 0, int KH = 2>
 __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     using namespace mma;
     using TR = F16Traits<Tag>;  // output / metadata type; also the activation type when XDT == 0
@@ -315,11 +319,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     using XO = XOps<Tag, XDT>;
     typedef typename XO::frag_t frag_t;
     constexpr int ES = XO::ES;  // bytes per activation
-    constexpr int BM = 32 * MI, KW = KSTEP / 2, SUB = KW / 64, WPL = G::WPL;
+    constexpr int BM = 32 * MI, KW = KSTEP / KH, SUB = KW / 64, WPL = G::WPL;
+    constexpr int BN = 256 / KH, C_PITCH = BN + 4;  // (shadow the namespace's 128-column constants)
+    static_assert(KH == 1 || KH == 2, "one or two K parts per step");
     constexpr bool MXW = NBITS == MXW8 || NBITS == MXW4;  // block-scaled K-contiguous weights (16-bit activations only)
     static_assert(!MXW || XDT == 0, "block-scaled weights on this kernel: 16-bit activations");
     constexpr int PITCH = KSTEP * ES, STAGE = BM * PITCH;  // bytes per row / per stage of x
     constexpr int SWZ = (PITCH / 16 < 16 ? PITCH / 16 : 16) - 1;  // XOR swizzle of the 16-byte slots inside a row (8 or 16 slots)
+    // the swizzle key of row r: r itself for rows of >= 256 B (one row spans all 64 banks); 128-byte rows alternate between
+    // the two bank halves, so rows r and r + 8 of one ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31})
+    // would meet in the same slot AND the same half — key r >> 1 separates them (PMC on the first wide build:
+    // SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE with key r)
+    constexpr int SWZ_SH = (PITCH == 128 && ES == 2) ? 1 : 0;
     constexpr int PIECES = STAGE / 1024 / 8;               // 1-KiB LDS-DMA pieces per wave and stage
     constexpr int NS = SUB * 4;                            // MFMA slices (k16) per wave and step
     constexpr int NQ = NS * MI;                            // MFMA slots per wave and step
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg = wave & 3, kh = wave >> 2;
+    const int cg = KH == 2 ? (wave & 3) : wave, kh = KH == 2 ? (wave >> 2) : 0;
     const int col = lane & 31, h = lane >> 5;
     const int mtiles = (p.M + BM - 1) / BM;
     // (tile, K slice) of this block.  Opt-in (tuning[3] & 8): block b runs on XCD b % 8 and every XCD has its own L2, so
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     for (int j = 0; j < PIECES; ++j) {
         const int byte = (wave * PIECES + j) * 1024 + lane * 16;
         const int r = byte / PITCH, phys = (byte % PITCH) / 16;
-        const int logical = phys ^ (r & SWZ);
+        const int logical = phys ^ ((r >> SWZ_SH) & SWZ);
         xvoff[j] = m0 + r < p.M ? (uint32_t)(((int64_t)(m0 + r) * p.stride_xm + k_s0) * ES + logical * 16) : 0x80000000u;
     }
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PIECES) * 1024u);
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         for (int g = 0; g < NS; ++g) {
             const int kb = (kh * KW + (g >> 2) * 64 + G::k_of(g & 3, h)) * ES;  // byte offset inside the row
             const int slot = kb >> 4;
-            fbase[st][g] = st * STAGE + col * PITCH + (((slot & ~SWZ) | ((slot ^ col) & SWZ)) << 4) + (kb & 15);
+            fbase[st][g] = st * STAGE + col * PITCH + (((slot & ~SWZ) | ((slot ^ (col >> SWZ_SH)) & SWZ)) << 4) + (kb & 15);
         }
     auto read_frag = [&](int stage, int q) __attribute__((always_inline)) -> frag_t {
         return *(const frag_t*)(smem + fbase[stage][q / MI] + (q % MI) * 32 * PITCH);
@@ -607,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
 
     // ---- epilogue 1: add the two K halves (waves 4..7 hand their accumulators to waves 0..3 through LDS) ------------
     __syncthreads();
-    {
+    if constexpr (KH == 2) {
         float* xch = (float*)smem;  // [cg][mi][e4][lane][4]
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -634,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     const int64_t ncol0 = (int64_t)nt * BN;
     constexpr int PASS_ROWS = BM < C_ROWS ? BM : C_ROWS;
     unsigned* flag = (unsigned*)(smem + PASS_ROWS * C_PITCH * 4);
-    constexpr int MIH = MI >= 2 ? MI / 2 : MI;  // row blocks per K-half wave in the combine
+    constexpr int MIH = (KH == 2 && MI >= 2) ? MI / 2 : MI;  // row blocks per wave in the combine
     bool split_rows = false;                    // combine done: the two K-half waves of a column group share the rows
     // ---- epilogue 2 (K split over blocks): the partial tile travels in FRAGMENT order — slabs are private to this
     //      kernel, so nothing is transposed: waves 0..3 store their registers as 16-byte write-through rows (1 KiB per
@@ -687,10 +698,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
                 }
             }
         };
-        if (MI >= 2) {
+        if (KH == 2 && MI >= 2) {
             split_rows = true;
             if (kh == 0) gather(std::integral_constant<int, 0>{});
-            else gather(std::integral_constant<int, (MI >= 2 ? MIH : 0)>{});
+            else gather(std::integral_constant<int, ((KH == 2 && MI >= 2) ? MIH : 0)>{});
         } else if (kh == 0) {
             gather(std::integral_constant<int, 0>{});
         }
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
-            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int u = tid + 512 * i, r = u / (BN / 4), c4 = (u % (BN / 4)) * 4;
             const int m = m0 + ps * PASS_ROWS + r;
             if (r < PASS_ROWS && m < p.M) {
                 const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
@@ -769,6 +780,15 @@ static const void* mma_pick(int nbits, int mi, int xdt) {
         case 8: return mma_pick_mi<Tag, 8, 0>(mi);
         default: return nullptr;
     }
+}
+
+// wide tiles (32 MI x 256, KH = 1, 64-k steps): 16-bit activations x 4- / 2-bit words, 128 or 256 rows
+template <typename Tag>
+static const void* mma_pick_wide(int nbits, int mi) {
+    mma_kernel_fn f = nullptr;
+    if (nbits == 4) f = mi == 8 ? gemm_wn_mma_kernel<Tag, 4, 8, 64, 4, 2, 0, 0, 1> : gemm_wn_mma_kernel<Tag, 4, 4, 64, 6, 3, 0, 0, 1>;
+    else if (nbits == 2) f = mi == 8 ? gemm_wn_mma_kernel<Tag, 2, 8, 64, 4, 2, 0, 0, 1> : gemm_wn_mma_kernel<Tag, 2, 4, 64, 6, 3, 0, 0, 1>;
+    return (const void*)f;
 }
 
 // 16-bit activations x block-scaled weights (layer formats MXFP16 / MXBF16: A16W8_MXFP, A16W4_MXFP): the same kernel with the
@@ -897,7 +917,24 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         return rounds * (P[i] + steps * S[i] + (sk > 1 ? Q[i] + sk * R[i] : 0.0)) + 0.0955 * slab_mb + 0.0484 * x_mb;
     };
     int mi = 0, splitk = 0;
-    if (nbits != 4) {
+    // wide tiles (32 MI x 256): tuning[2] = 16 + MI (20 / 24) forces them
+    const bool wide_ok = x16 && (nbits == 4 || nbits == 2) && a.N % 256 == 0 && a.K % 64 == 0;
+    bool wide = (a.tuning[2] == 20 || a.tuning[2] == 24);
+    if (wide) {
+        if (!wide_ok) return false;
+        mi = a.tuning[2] - 16;
+        const int un = (int)(a.K / 64);
+        const int64_t tl = (int64_t)(a.N / 256) * ((a.M + 32 * mi - 1) / (32 * mi));
+        if (a.tuning[1] > 0) splitk = a.tuning[1];
+        else {
+            for (int sk = 1; sk <= un && sk <= 16; ++sk) {
+                if (sk > 1 && un / sk < 8) continue;
+                splitk = sk;
+                if (tl * sk >= 224) break;
+            }
+            if (!splitk) splitk = 1;
+        }
+    } else if (nbits != 4) {
         // other bit widths (not swept; their unpack arithmetic per weight differs): the rule of thumb the 4-bit model
         // replaced, measured on config 5 (A16W2 16384^2, M = 256: 256-row tiles x 2 slices, 137 us) — the tallest tile
         // (>= 64 rows) that still yields >= 128 tiles, else >= 64, else the tallest M fills; then the fewest K slices that
@@ -943,7 +980,14 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
             }
         if (!mi) return false;  // no tile variant divides K (K % 128 != 0), or an override that does not apply
     }
-    const int ks = kstep_of(mi);
+    // automatic choice of the wide tile: when 256 x 256 tiles alone fill the chip (prefill)
+    if (!wide && wide_ok && a.tuning[1] == 0 && a.tuning[2] == 0 && (int64_t)(a.N / 256) * ((a.M + 255) / 256) >= 192) {
+        wide = true;
+        mi = 8;
+        splitk = 1;
+    }
+    const int bn = wide ? 256 : mma::BN;
+    const int ks = wide ? 64 : kstep_of(mi);
     const int bm = 32 * mi;
     const int rows = (int)(a.K / e), step_rows = ks / e;
     const int units = rows / step_rows;
@@ -951,13 +995,14 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     // buffer descriptors: 32-bit byte offsets
     if ((int64_t)rows * a.stride_wk * 4 >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * es >= (1ll << 31)) return false;
     if (((int64_t)(a.K / (p.group_size > 0 ? p.group_size : a.K)) * p.stride_meta_g + a.N) * 2 >= (1ll << 31)) return false;
-    const int64_t tiles = (int64_t)(a.N / mma::BN) * ((a.M + bm - 1) / bm);
+    const int64_t tiles = (int64_t)(a.N / bn) * ((a.M + bm - 1) / bm);
     if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
-    if ((uint64_t)splitk * bm * mma::BN * 4 >= (1ull << 31)) return false;  // slab buffer descriptor range
+    if ((uint64_t)splitk * bm * bn * 4 >= (1ull << 31)) return false;  // slab buffer descriptor range
     const bool f16 = tag_dt == GEMLITE_DT_FP16;
-    const void* fn = f16 ? mma_pick<half_tag>(nbits, mi, xdt) : mma_pick<bf16_tag>(nbits, mi, xdt);
+    const void* fn = wide ? (f16 ? mma_pick_wide<half_tag>(nbits, mi) : mma_pick_wide<bf16_tag>(nbits, mi))
+                          : (f16 ? mma_pick<half_tag>(nbits, mi, xdt) : mma_pick<bf16_tag>(nbits, mi, xdt));
 #ifdef GL_MMA_EXPERIMENTS
-    if (!f16 && xdt == 0 && nbits == 4 && (mi == 4 || mi == 8)) {
+    if (!wide && !f16 && xdt == 0 && nbits == 4 && (mi == 4 || mi == 8)) {
         mma_kernel_fn f = nullptr;
 #define GL_EXP_CASE(E) case E: f = mi == 4 ? gemm_wn_mma_kernel<bf16_tag, 4, 4, 128, 6, 3, E> : gemm_wn_mma_kernel<bf16_tag, 4, 8, 128, 4, 2, E>; break;
         switch (a.tuning[3] >> 8) { GL_EXP_CASE(1) GL_EXP_CASE(2) GL_EXP_CASE(4) GL_EXP_CASE(8) GL_EXP_CASE(16) GL_EXP_CASE(3) GL_EXP_CASE(6) GL_EXP_CASE(7) GL_EXP_CASE(31) GL_EXP_CASE(32) GL_EXP_CASE(34) GL_EXP_CASE(63) default: break; }
@@ -979,15 +1024,18 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         {"gemm_a8w2_mma_kernel<32x128>", "gemm_a8w2_mma_kernel<64x128>", "gemm_a8w2_mma_kernel<128x128>", "gemm_a8w2_mma_kernel<256x128>"}};
     const int mix = mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3));
     lp.name = xdt ? names8[nbits == 4 ? 0 : 1][mix] : names[nbits == 4 ? 0 : (nbits == 2 ? 1 : (nbits == 1 ? 2 : 3))][mix];
+    static const char* names_wide[2][2] = {{"gemm_w4_mma_kernel<128x256>", "gemm_w4_mma_kernel<256x256>"},
+                                           {"gemm_w2_mma_kernel<128x256>", "gemm_w2_mma_kernel<256x256>"}};
+    if (wide) lp.name = names_wide[nbits == 4 ? 0 : 1][mi == 8 ? 1 : 0];
     lp.grid = dim3((unsigned)tiles, splitk, 1);
     lp.block = dim3(512, 1, 1);
     const int nst = mi == 8 ? 2 : (mi == 4 ? 3 : (nbits == 8 ? 2 : (mi == 2 ? 3 : 4)));  // LDS stages of x (mma_pick_mi)
     const size_t stages = (size_t)nst * bm * ks * es;
     const size_t xch = (size_t)4 * mi * 4 * 64 * 16;  // K-half exchange: [cg][mi][e4][lane] float4
-    const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * mma::C_PITCH * 4 + 16;
+    const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * (bn + 4) * 4 + 16;
     lp.lds_bytes = stages > xch ? stages : xch;
     if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
-    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * mma::BN * 4 : 0;
+    lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * bn * 4 : 0;
     lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
     return true;
 }

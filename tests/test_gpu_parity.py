@@ -629,6 +629,51 @@ def test_mma_kernel_bit_widths_tiles_and_splits(nbits, tdt):
                      abs_gate=None if nbits == 8 else 1e-3, extra=dict(kernel=name))
 
 
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_mma_kernel_wide_tiles(nbits, tdt):
+    """The 256-column tiles of the 8-wave MFMA kernel (tuning[2] = 16 + rows / 32): 128 / 256 rows, ragged M, several M and
+    N tiles, 64-k steps (K = 64 * 21: uneven slices), forced split-K, group sizes 128 and 64 — against the oracle."""
+    from gemlite_amd.core import _hip_matmul
+    for (N, K, gs) in ((512, 1344, 64), (256, 1280, 128)):
+        lin = _make_layer(N, K, nbits, gs, tdt, seed=70 + nbits)
+        for mi, M in ((4, 100), (4, 130), (8, 256), (8, 300)):
+            x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
+            y_or = _oracle_from_layer(lin, x)
+            for sk in (0, 1, 2, 3):
+                tuning = (0, sk, 16 + mi, 0)
+                name = _kernel_name(lin, x, 4, tuning)
+                assert name == f"gemm_w{nbits}_mma_kernel<{32 * mi}x256>", name
+                y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 4, tuning)
+                torch.cuda.synchronize()
+                _compare(f"mma_wide/w{nbits}/{str(tdt)[6:]}/{N}x{K}/M{M}/mi{mi}/sk{sk}", y, y_or, lin.output_dtype.value,
+                         abs_gate=1e-3, extra=dict(kernel=name))
+
+
+def test_mma_kernel_wide_tiles_prefill_shape_and_modes():
+    """What the planner picks for prefill (256 x 256 tiles when they alone fill the chip) at 2048 x 4096 x 8192, every
+    W_group_mode, checked on column blocks against the oracle and on all outputs against the 128-column tiles."""
+    from gemlite_amd.core import _hip_matmul
+    N, K, M = 8192, 4096, 2048
+    for mode, kw in (("fma", {}), ("sub_mul", dict(fma=False)), ("symmetric", dict(zeros_kind="none")), ("int_zero", dict(zeros_kind="int"))):
+        lin = _make_layer(N, K, 4, 128, torch.bfloat16, seed=81, **kw)
+        x = torch.from_numpy(O.gen_x(M, K, seed=3).astype(np.float32)).to(torch.bfloat16).to(DEV)
+        name = _kernel_name(lin, x)
+        assert name == "gemm_w4_mma_kernel<256x256>", name
+        y = lin(x)
+        torch.cuda.synchronize()
+        for c0 in (0, N - 256):
+            cols = slice(c0, c0 + 256)
+            _compare(f"mma_wide/prefill/{mode}/cols{c0}", y[:64, cols], _oracle_columns(lin, x[:64], cols), lin.output_dtype.value,
+                     extra=dict(kernel=name))
+        y2 = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 4, (0, 0, 8, 0))
+        torch.cuda.synchronize()
+        d = (y.float() - y2.float()).abs()  # two summation orders, each rounded to bf16 once: a few ulps at most
+        ref = y2.float().abs()
+        assert bool((d <= 0.02 * ref + 0.02 * float(ref.mean())).all()), (mode, float(d.max()))
+        assert float(d.mean()) < 0.004 * float(ref.mean()), (mode, float(d.mean()))
+
+
 @pytest.mark.parametrize("gs", [128, 64])
 @pytest.mark.parametrize("N,K", [(1024, 11008), (1536, 8960), (1024, 896)])
 def test_llm_shapes_with_odd_k_never_hit_the_coverage_kernel(N, K, gs):
@@ -650,7 +695,7 @@ def _oracle_columns(lin, x, cols, scales_x=None):
     second, independently written kernel family."""
     meta = lin.get_meta_args()
     s = O.to_f64(lin.scales.data)[..., cols] if lin.scales.numel() else None
-    z = O.to_f64(lin.zeros.data)[..., cols] if lin.zeros.numel() > 1 else None
+    z = O.to_f64(lin.zeros.data)[..., cols] if lin.zeros.numel() > 1 else (O.to_f64(lin.zeros.data).reshape(-1) if lin.zeros.numel() == 1 else None)
     Wp = lin.W_q.data[:, cols].cpu().numpy()
     return O.forward_packed(O.to_f64(x).reshape(-1, x.shape[-1]), Wp, s, z, W_nbits=lin.W_nbits, group_size=lin.group_size,
                             W_group_mode=meta[10], channel_scale_mode=meta[9], scales_x=scales_x,

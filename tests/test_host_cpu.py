@@ -129,6 +129,10 @@ def test_struct_abi_and_validation():
     (dict(M=256, tuning=(0, 0, 8, 0)), "gemm_w4_mma_kernel<256x128>"),   # tuning[2]: tile rows / 32
     (dict(M=256, tuning=(2, 0, 8, 0)), "gemm_w4_tiled_kernel<256x128>"),
     (dict(M=256, tuning=(2, 0, 4, 0)), "gemm_w4_tiled_kernel<legacy>"),
+    (dict(M=2048, N=8192, K=8192, in_dt=2), "gemm_w4_mma_kernel<256x256>"),   # prefill: 256 x 256 tiles alone fill the chip
+    (dict(M=1024, N=8192, K=8192, in_dt=2), "gemm_w4_mma_kernel<256x128>"),   # 128 wide tiles do not
+    (dict(M=256, N=8192, K=8192, in_dt=2, tuning=(0, 4, 20, 0)), "gemm_w4_mma_kernel<128x256>"),   # tuning[2] = 16 + rows / 32
+    (dict(M=4096, N=16384, K=16384, nbits=2), "gemm_w2_mma_kernel<256x256>"),
     (dict(M=256, nbits=2), "gemm_w2_mma_kernel<64x128>"),
     (dict(M=256, N=16384, K=16384, nbits=2), "gemm_w2_mma_kernel<256x128>"),   # BASELINE config 5
     (dict(M=4, mt=3), "gemm_wn_direct_kernel<tile16>"),  # manual GEMM_SPLITK
