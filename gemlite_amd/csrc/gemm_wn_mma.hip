@@ -418,6 +418,20 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
         brS = __builtin_amdgcn_make_buffer_rsrc((void*)(need_s ? p.scales : (const void*)p.w), (short)0, need_s ? meta_bytes : 4, 0x00020000);
         brZ = __builtin_amdgcn_make_buffer_rsrc((void*)(need_z ? p.zeros : (const void*)p.w), (short)0, need_z ? meta_bytes : 4, 0x00020000);
     }
+    // (scalar offsets of the packed-word requests = step * bytes-per-step + a loop-invariant per request: one s_mul per step and
+    //  one s_add per request instead of add / mul / shift each — the SIMD issues scalar and vector instructions of its two
+    //  waves one after the other, 36 SALU per step were ~8 % of the loop)
+    uint32_t wconst[SUB][WPL > 8 ? 1 : WPL];
+    const uint32_t step_wbytes = MXW ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane(STEP_ROWS * sw * 4);
+    if constexpr (!MXW) {
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb)
+#pragma unroll
+            for (int i = 0; i < WPL; ++i)
+                wconst[sb][i] = (uint32_t)__builtin_amdgcn_readfirstlane((wave_row0 + sb * G::ROWS + G::row_of(i)) * sw * 4);
+    }
+    const int kconst0 = k_s0 + kh * KW;
+    const int ms2 = ms * 2;
     auto req_b = [&](BStep& b, int step, int it) __attribute__((always_inline)) {
         const int sb = it / NREQ, i = it % NREQ;
         if constexpr (MXW) {
@@ -432,11 +446,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
                     brS, mvoff, (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane(((step * KSTEP + sb * 64) / 32) * (int)p.stride_meta_g), 0);
             }
         } else {
-            const int rb = step * STEP_ROWS + wave_row0 + sb * G::ROWS;  // packed row (slice-relative) of the sub-block
             if (i < WPL) {
-                b.w[sb][i] = __builtin_amdgcn_raw_buffer_load_b32(brW, wvoff, (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((rb + G::row_of(i)) * sw * 4), 0);
+                b.w[sb][i] = __builtin_amdgcn_raw_buffer_load_b32(brW, wvoff, (EXP & 32) ? 0u : (uint32_t)step * step_wbytes + wconst[sb][i], 0);
             } else {
-                const uint32_t mo = (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((((k_s0 + rb * G::E) >> p.gs_shift) * ms) * 2);
+                const uint32_t mo = (EXP & 32) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane(((kconst0 + sb * 64 + step * KSTEP) >> p.gs_shift) * ms2);
                 if (i == WPL) b.s[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brS, mvoff, mo, 0);
                 else b.z[sb] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brZ, mvoff, mo, 0);
             }

@@ -29,15 +29,15 @@ __device__ __forceinline__ void req_u16(uint32_t& dst, srd_t rs, uint32_t voff, 
 }
 // one LDS-DMA piece: 64 lanes x 16 bytes from buffer offset (voff per lane + soff) to LDS [lds_addr, +1024), lane-linear
 __device__ __forceinline__ void req_lds16(srd_t rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+    // m0 is declared clobbered, not saved / restored (two SALU + a 5-cycle nop per piece in the round-2 loops); one wait state
+    // between the SALU write of M0 and the LDS-DMA that reads it
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory", "m0");
 }
 // the same with 4 bytes per lane: 64 lanes x 4 bytes to LDS [lds_addr, +256)
 __device__ __forceinline__ void req_lds4(srd_t rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds"
+                 : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
