@@ -21,6 +21,7 @@ bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
+bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
@@ -281,6 +282,14 @@ coverage:
         r.lp.grid = dim3((unsigned)((a.N + 7) / 8), 1, 1);
         r.lp.block = dim3(512, 1, 1);
         r.lp.lds_bytes = (size_t)((a.K + 15) & ~15) + 64;
+        return;
+    }
+    // A8W8 (int8 / fp8), 2..16 rows: 16-column blocks, one 16-row MFMA per 64-k chunk (tuning[0] = 4 forces it at M = 1 too,
+    // any other non-zero tuning[0] skips it)
+    if (!packed && (a.tuning[0] == 4 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && a.M >= 2)) &&
+        a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
+        a.matmul_type != GEMLITE_MATMUL_GEMV_REVSPLITK && plan_a8w8_rows(a, r.lp)) {
+        r.kind = K_KMAJOR;  // GenericParams, no workspace
         return;
     }
     // A8W8 (int8 / fp8) from 2 rows: the 8-wave MFMA kernel.  tuning[0]: 1 = streaming kernel (one wave per column),

@@ -504,9 +504,10 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
     torch.cuda.synchronize()
     for t, y2 in outs.items():
         assert torch.equal(y, y2), t
-    for M in (2, 5, 16, 31):  # few rows: the 32-row tile of the MFMA kernel instead of one wave per column
+    for M in (2, 5, 16, 17, 31):  # few rows: 16-column blocks up to 16 rows, then the 32-row tile of the 8-wave kernel
         xs = (torch.randn(M, 4096) / 10).half().to(DEV)
-        assert _kernel_name(lin, torch.empty(M, 4096, dtype=torch.int8)).startswith("gemm_a8w8_mma_kernel<32x128>")
+        want = "a8w8_rows_kernel<16x16>" if M <= 16 else "gemm_a8w8_mma_kernel<32x128>"
+        assert _kernel_name(lin, torch.empty(M, 4096, dtype=torch.int8)) == want
         ya = lin(xs)
         gemlite_amd.core.TUNING_OVERRIDE = (1, 0, 0, 0)
         try:
@@ -515,6 +516,39 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
             gemlite_amd.core.TUNING_OVERRIDE = None
         torch.cuda.synchronize()
         assert torch.equal(ya, yb), M
+
+
+@pytest.mark.parametrize("kind", ["int8", "fp8e4", "fp8e5"])
+def test_a8w8_rows_kernel(kind):
+    """2..16 rows of A8W8 (BASELINE config 4, M = 16): 16-column blocks, one 16-row MFMA per 64-k chunk — every M, K = 64 * odd
+    (uneven chunk counts per wave), long K (several ring passes), against the oracle on the kernel's own quantised inputs, and
+    bit-exact against the 8-wave MFMA kernel for int8."""
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    code = {"int8": O.INT8, "fp8e4": O.FP8E4, "fp8e5": O.FP8E5}[kind]
+    qdt = {"int8": torch.int8, "fp8e4": torch.float8_e4m3fn, "fp8e5": torch.float8_e5m2}[kind]
+    for (N, K) in ((512, 4096), (48, 64 * 37), (256, 16384)):
+        g = torch.Generator().manual_seed(N + K)
+        W = (torch.randn(N, K, generator=g) / 30).half()
+        proc = H.A8W8_int8_dynamic(device=DEV, dtype=torch.float16) if kind == "int8" else \
+            H.A8W8_dynamic(device=DEV, dtype=torch.float16, fp8=qdt)
+        lin = proc.from_weights(W)
+        for M in (2, 3, 7, 16) + ((1,) if N == 512 else ()):
+            x = (torch.randn(M, K, generator=g) / 10).half().to(DEV)
+            xq, sx = scale_activations_per_token(x, qdt)
+            tun = (4, 0, 0, 0) if M == 1 else None
+            name = _kernel_name(lin, xq, -1, tun or (0, 0, 0, 0))
+            assert name == "a8w8_rows_kernel<16x16>", (M, name)
+            y = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, tun)
+            torch.cuda.synchronize()
+            xq_o, sx_o = O.scale_activations_per_token(x, code)
+            assert np.array_equal(O.to_f64(xq), xq_o), "activation quantiser differs from the oracle"
+            y_or = (xq_o @ O.to_f64(lin.W_q.data)) * (sx_o.astype(np.float64) * O.to_f64(lin.scales.data).reshape(1, -1))
+            _compare(f"a8w8_rows/{kind}/{N}x{K}/M{M}", y, y_or, 1, abs_gate=5e-3, extra=dict(kernel=name))
+            if kind == "int8" and N % 128 == 0:
+                y2 = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, (0, 1, 1, 0))
+                torch.cuda.synchronize()
+                assert torch.equal(y, y2), (N, K, M)
 
 
 @pytest.mark.parametrize("M", [1, 64])

@@ -137,7 +137,10 @@ def test_struct_abi_and_validation():
     (dict(M=256, N=16384, K=16384, nbits=2), "gemm_w2_mma_kernel<256x128>"),   # BASELINE config 5
     (dict(M=4, mt=3), "gemm_wn_direct_kernel<tile16>"),  # manual GEMM_SPLITK
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
-    (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # A8W8 int8 on MFMA from 2 rows
+    (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),  # A8W8 int8, 2..16 rows: 16-column blocks
+    (dict(M=2, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),
+    (dict(M=17, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # then the 8-wave MFMA kernel
+    (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 1, 0)), "gemm_a8w8_mma_kernel<32x128>"),
     (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<64x128>"),   # fp8 x fp8: tallest tile with >= 112 tiles
     (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<128x128>"),
