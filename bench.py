@@ -65,6 +65,9 @@ WORKLOADS = {
     "a8w8_4096_m1": (4096, 4096, 8, 4096, 1, "int8", 16, "hbm"),
     "a8w8_4096_m16": (4096, 4096, 8, 4096, 16, "int8", 16, "hbm"),
     "a8w8_4096_m256": (4096, 4096, 8, 4096, 256, "int8", 16, "mfma"),
+    # BASELINE config 5, second half: FP8 x FP8 (e4m3, per-token x per-channel scales), 16384 x 16384
+    "fp8_16384_m1": (16384, 16384, 8, 16384, 1, "fp8w8", 2, "hbm"),
+    "fp8_16384_m256": (16384, 16384, 8, 16384, 256, "fp8w8", 2, "mfma"),
     # A8Wn dynamic (helper.py:502-615): fp8 e4m3 activations (pre-quantised per token) x 4-bit g128 weights, fp16 out
     "a8w4_4096_m1": (4096, 4096, 4, 128, 1, "fp8", 32, "hbm"),
     "a8w4_4096_m16": (4096, 4096, 4, 128, 16, "fp8", 32, "hbm"),
@@ -87,7 +90,7 @@ WORKLOADS = {
     "mx_a16w4_8192_m256": (8192, 8192, 4, 32, 256, "mxa16", 8, "mfma"),
     "mx_a16w8_8192_m256": (8192, 8192, 8, 32, 256, "mxa16", 4, "mfma"),
 }
-PREQUANT = ("int8", "fp8", "mxa8", "mxa4")  # workloads whose x is quantised once, outside the timed matmul
+PREQUANT = ("int8", "fp8", "fp8w8", "mxa8", "mxa4")  # workloads whose x is quantised once, outside the timed matmul
 MX = ("mxa8", "mxa4", "mxa16")
 
 
@@ -99,7 +102,7 @@ def algorithmic_bytes(M, N, K, nbits, group, esize=2):
 def work_per_launch(name):
     N, K, nbits, group, M, dt, layers, bound = WORKLOADS[name]
     nbytes = algorithmic_bytes(M, N, K, nbits, group)
-    if dt == "int8":  # int8 W + fp32 channel scales + int8 x + fp32 token scales + fp16 out
+    if dt in ("int8", "fp8w8"):  # 8-bit W + fp32 channel scales + 8-bit x + fp32 token scales + fp16 out
         nbytes = K * N + N * 4 + M * K + M * 4 + M * N * 2
     if dt == "fp8":  # packed W + fp16 group metadata + fp8 x + fp32 token scales + fp16 out
         nbytes = K * N * nbits // 8 + 2 * (K // group) * N * 2 + M * K + M * 4 + M * N * 2
@@ -133,14 +136,14 @@ def build_layers(name, device, layers=None):
         if dt == "mxa16":
             return mods, x
         return mods, (scale_activations_mxfp8(x) if dt == "mxa8" else scale_activations_mxfp4(x))
-    if dt == "int8":
-        from gemlite_amd.helper import A8W8_int8_dynamic
+    if dt in ("int8", "fp8w8"):
+        from gemlite_amd.helper import A8W8_fp8_dynamic, A8W8_int8_dynamic
         from gemlite_amd.quant_utils import scale_activations_per_token
-        g = torch.Generator(device="cpu").manual_seed(0)
-        proc = A8W8_int8_dynamic(device=device, dtype=torch.float16)
-        mods = [proc.from_weights((torch.randn(N, K, generator=g) / 30).half()) for _ in range(layers)]
-        x = (torch.randn(M, K, generator=g) / 10).half().to(device)
-        return mods, scale_activations_per_token(x, torch.int8)  # (x_q int8 [M, K], scales_x fp32 [M, 1])
+        g = torch.Generator(device=device).manual_seed(0)
+        proc = (A8W8_int8_dynamic if dt == "int8" else A8W8_fp8_dynamic)(device=device, dtype=torch.float16)
+        mods = [proc.from_weights((torch.randn(N, K, generator=g, device=device) / 30).half()) for _ in range(layers)]
+        x = (torch.randn(M, K, generator=g, device=device) / 10).half()
+        return mods, scale_activations_per_token(x, torch.int8 if dt == "int8" else torch.float8_e4m3fn)  # (x_q [M, K], scales_x fp32 [M, 1])
     if dt == "fp8":
         from gemlite_amd.helper import A8Wn_HQQ_INT_dynamic
         from gemlite_amd.quant_utils import scale_activations_per_token
@@ -290,7 +293,7 @@ class Runner:
         if self.bound == "hbm":
             peak, unit, work = HBM_PEAK_GBS, "GB/s", self.bytes / 1e9
         else:
-            peak = {"int8": INT8_MFMA_PEAK_TOPS, "fp8": INT8_MFMA_PEAK_TOPS, "mxa8": MXFP8_MFMA_PEAK_TFLOPS,
+            peak = {"int8": INT8_MFMA_PEAK_TOPS, "fp8": INT8_MFMA_PEAK_TOPS, "fp8w8": INT8_MFMA_PEAK_TOPS, "mxa8": MXFP8_MFMA_PEAK_TFLOPS,
                     "mxa4": MXFP4_MFMA_PEAK_TFLOPS}.get(self.dt, MFMA_PEAK_TFLOPS)
             unit, work = "TFLOP/s", self.flops / 1e12
         ach = work / (t * 1e-6)
@@ -373,7 +376,7 @@ def main():
         print(f"[bench] per-kernel event timing unavailable: {e}", file=sys.stderr)
     work = main_run.bytes / 1e9 if bound == "hbm" else main_run.flops / 1e12
     unit = "GB/s" if bound == "hbm" else "TFLOP/s"
-    peak = HBM_PEAK_GBS if bound == "hbm" else {"int8": INT8_MFMA_PEAK_TOPS, "fp8": INT8_MFMA_PEAK_TOPS, "mxa8": MXFP8_MFMA_PEAK_TFLOPS,
+    peak = HBM_PEAK_GBS if bound == "hbm" else {"int8": INT8_MFMA_PEAK_TOPS, "fp8": INT8_MFMA_PEAK_TOPS, "fp8w8": INT8_MFMA_PEAK_TOPS, "mxa8": MXFP8_MFMA_PEAK_TFLOPS,
                                                   "mxa4": MXFP4_MFMA_PEAK_TFLOPS}.get(dt, MFMA_PEAK_TFLOPS)
     value = whole_job_rate(layers * work, args.steps, world, elapsed)
     if roof.get("kernel_us") is None:  # fall back to the gap-inclusive figure

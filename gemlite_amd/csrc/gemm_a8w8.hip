@@ -45,6 +45,17 @@ struct A8Acc {  // accumulator type + one 32-k multiply-accumulate on 16-byte fr
         }
         return c;
     }
+    // 64 k in ONE instruction: the 32x32x16 fp8 forms above run at the bf16 rate on gfx950 (32 cycles for 16 k; PMC on FP8 x FP8
+    // 16384^2, M = 256: SQ_VALU_MFMA_BUSY_CYCLES = 32 per instruction, matrix pipes 63 % busy at 110 us) — the fp8 peak
+    // belongs to v_mfma_f32_32x32x64_f8f6f4 (64 cycles for 64 k).  Two consecutive 16-byte fragments of a lane are exactly
+    // its 32-byte operand (k = 32 (b >> 4) + 16 (lane >> 5) + (b & 15)); unit block scales (e8m0 127).
+    static __device__ __forceinline__ T mma64(u32x4 a0, u32x4 a1, u32x4 b0, u32x4 b1, T c) {
+        typedef int v8i __attribute__((ext_vector_type(8)));
+        const v8i av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+        const v8i bv = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+        constexpr int FMT = DT == GEMLITE_DT_FP8E4 ? 0 : 1;  // e4m3 / e5m2
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, FMT, FMT, 0, 127, 0, 127);
+    }
     static __device__ __forceinline__ float to_float(T c, int e) { return c[e]; }
 };
 template <>
@@ -257,8 +268,12 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
             const int slot = (kh * KW + g * 32 + h * 16) >> 4;
             fbase[st][g] = st * STAGE + col * PITCH + (((slot ^ col) & 15) << 4);
         }
+    // slot q -> (slice g, row block mi).  fp8: the slices are consumed in PAIRS by one 64-k MFMA, so the two slices of a pair
+    // are adjacent slots: q = (pair * MI + mi) * 2 + (g & 1)
+    auto slot_g = [&](int q) { return INT ? q / MI : 2 * (q / (2 * MI)) + (q & 1); };
+    auto slot_mi = [&](int q) { return INT ? q % MI : (q >> 1) % MI; };
     auto read_frag = [&](int stage, int q) -> u32x4 {
-        return *(const u32x4*)(smem + fbase[stage][q / MI] + (q % MI) * 32 * PITCH);
+        return *(const u32x4*)(smem + fbase[stage][slot_g(q)] + slot_mi(q) * 32 * PITCH);
     };
 
     acc_t acc[MI];
@@ -302,16 +317,22 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
         const int xstep = step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int g = q / MI, mi = q % MI;
-            acc[mi] = AC::mma(af[q % L], bc.w[g], acc[mi]);
+            const int g = slot_g(q), mi = slot_mi(q);
+            if constexpr (INT) acc[mi] = AC::mma(af[q % L], bc.w[g], acc[mi]);
+            else if (q & 1) acc[mi] = AC::mma64(af[(q - 1) % L], af[q % L], bc.w[g - 1], bc.w[g], acc[mi]);
             if (q == NQI) {
                 wait_vm<(NST - 2) * PIECES + (NST - 1) * NLB>();  // the x DMA of step + 1 has landed
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
-            if (q + L < NQ) af[q % L] = read_frag(stage, q + L);
-            else af[q % L] = read_frag(stage_next, q + L - NQ);
+            // refill the ring L slots ahead (fp8: both fragments of a pair after the pair's MFMA; NQI is even, so the
+            // reads of the current stage are still all issued before the barrier slot)
+#pragma unroll
+            for (int r = (INT ? q : (q & 1 ? q - 1 : NQ)); r <= q; ++r) {
+                if (r + L < NQ) af[r % L] = read_frag(stage, r + L);
+                else af[r % L] = read_frag(stage_next, r + L - NQ);
+            }
 #pragma unroll
             for (int it = q * RPS; it < (q + 1) * RPS && it < NL; ++it) {
                 if (it < PIECES) req_x(stage_fill, xstep, it);
