@@ -186,6 +186,110 @@ __global__ __launch_bounds__(256, 2) void gemm_a8w8_kernel(const GenericParams p
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// Shared epilogue of the 8-wave kernels: K halves through LDS, transpose, split-K slabs + combine, scaled output.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT, int MI>
+__device__ __forceinline__ void a8_epilogue(const GenericParams& p, typename A8Acc<DT>::T (&acc)[MI], unsigned char* smem, int tid,
+                                            int lane, int cg, int kh, int col, int h, int bid, int slice, int m0, int nt) {
+    using AC = A8Acc<DT>;
+    typedef typename AC::T acc_t;
+    constexpr bool INT = DT == GEMLITE_DT_INT8;
+    constexpr int BM = 32 * MI, BN = 128;
+    constexpr int C_ROWS = 128, C_PITCH = BN + 4;
+    // ---- epilogue 1: add the two K halves through LDS (raw 32-bit accumulator words: int32 stays exact) -------------
+    __syncthreads();
+    {
+        acc_t* xch = (acc_t*)smem;  // [cg][mi][lane] whole accumulators (64 bytes per lane)
+        if (kh == 1) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xch[(cg * MI + mi) * 64 + lane] = acc[mi];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] += xch[(cg * MI + mi) * 64 + lane];
+        }
+    }
+    // ---- epilogue 2: transpose through LDS (128 rows per pass): slabs / output move as 16-byte row segments ------------
+    typedef typename std::conditional<INT, int, float>::type word_t;
+    typedef word_t word4 __attribute__((ext_vector_type(4)));
+    word_t* ct = (word_t*)smem;  // [PASS_ROWS][C_PITCH]
+    constexpr int PASS_ROWS = BM < C_ROWS ? BM : C_ROWS;
+    unsigned* flag = (unsigned*)(smem + PASS_ROWS * C_PITCH * 4);
+    constexpr int NPASS = BM / PASS_ROWS, MIP = PASS_ROWS / 32;
+    constexpr int UNITS = (PASS_ROWS * BN / 4 + 511) / 512;
+    constexpr int NOUT = BM * BN;
+    const int64_t ncol0 = (int64_t)nt * BN;
+    float* slab = p.slabs + ((int64_t)bid * p.splitk) * NOUT;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
+    auto finish = [&](word4 v, int m, int c4) {
+        f32x4 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = (float)v[j];
+        store_out4_any(p.epi, f, m, ncol0 + c4);
+    };
+    word4 own[NPASS][UNITS];  // this block's partial tile, kept for the combine (its own slab is not read back)
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MIP; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    ct[r * C_PITCH + cg * 32 + col] = acc[ps * MIP + mi][e];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + ps * PASS_ROWS + r;
+            own[ps][i] = (word4){0, 0, 0, 0};
+            if (r < PASS_ROWS && m < p.M) {
+                const word4 v = *(const word4*)(ct + r * C_PITCH + c4);
+                own[ps][i] = v;
+                if (p.splitk == 1) finish(v, m, c4);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                            (slice * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);  // sc1
+            }
+        }
+    }
+    if (p.splitk == 1) return;
+    __syncthreads();
+    if (!splitk_arrive_is_last(p.counters + bid, p.splitk, flag)) return;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        word4 sum[UNITS];
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) sum[i] = (word4){0, 0, 0, 0};
+        for (int sl = 0; sl < p.splitk; ++sl) {
+            if (sl == slice) {  // own partial: from registers (fixed slice order keeps the sum deterministic)
+#pragma unroll
+                for (int i = 0; i < UNITS; ++i) sum[i] += own[ps][i];
+                continue;
+            }
+            u32x4 t[UNITS];
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) {
+                const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+                t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (sl * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) sum[i] += __builtin_bit_cast(word4, t[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+            const int m = m0 + ps * PASS_ROWS + r;
+            if (r < PASS_ROWS && m < p.M) finish(sum[i], m, c4);
+        }
+    }
+    if (tid == 0) splitk_reset(p.counters + bid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 8-wave kernel (default).  Same skeleton as gemm_wn_mma.hip: tile (32 MI) x 128, wave (cg, kh) owns all rows x 32
 // columns x one half of every 256-byte K step; x goes global -> LDS by LDS-DMA (XOR-swizzled through the source
 // address), the wave's B fragments — 16 consecutive bytes of ONE weight row = exactly a lane's operand of
@@ -203,7 +307,6 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
     constexpr int PIECES = STAGE / 1024 / 8;  // LDS-DMA pieces per wave and stage (= MI)
     constexpr int NS = KW / 32;               // 32-k slices per wave and step
     constexpr int NQ = NS * MI, L = MI >= 4 ? 4 : (MI == 2 ? 4 : 2);
-    constexpr int C_ROWS = 128, C_PITCH = BN + 4;
     constexpr int PD = RD - 2;  // weights are requested PD steps ahead: a step is only 4 MI MFMAs per wave (128 MI cycles)
                                 // and an HBM round trip under load 2-3k cycles, so the small tiles need a deep ring
     // NST LDS stages of x (the tile of step s + NST - 1 is requested during step s): see gemm_wn_mma.hip
@@ -364,97 +467,148 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
     }
     wait_vm<0>();
 
-    // ---- epilogue 1: add the two K halves through LDS (raw 32-bit accumulator words: int32 stays exact) -------------
-    __syncthreads();
-    {
-        acc_t* xch = (acc_t*)smem;  // [cg][mi][lane] whole accumulators (64 bytes per lane)
-        if (kh == 1) {
+    a8_epilogue<DT, MI>(p, acc, smem, tid, lane, cg, kh, col, h, bid, slice, m0, nt);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 8-wave kernel with BOTH operands through LDS (128- / 256-row tiles).  A lane's B operand is 16 bytes of ONE weight row,
+// so loading it straight from memory makes every wave instruction touch 32 rows x 32 bytes — FP8 x FP8 16384^2 at M = 256
+// streamed its 268 MB of weights at 2.4 TB/s that way (110 us; matrix pipes 63 % busy even at the slow 16-k instruction).
+// Here the weight tile [128 rows][128 bytes] of a step travels like the x tile: 1-KiB LDS-DMA pieces (8 rows x 128
+// contiguous bytes per wave instruction, full cache lines), XOR-swizzled through the source address, and the lanes pick
+// their fragments with ds_read_b128.  Steps are 128 bytes of K (wave half: 64 = two 32-k slices), NST stages, no register
+// ring; every request is an asm DMA with one counted wait per step.  fp8 consumes the two slices of a step with ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 per row block.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT, int MI, int NST>
+__global__ __launch_bounds__(512, 2) void gemm_a8w8_lds_kernel(const GenericParams p) {
+    using namespace async;
+    using AC = A8Acc<DT>;
+    typedef typename AC::T acc_t;
+    constexpr bool INT = DT == GEMLITE_DT_INT8;
+    constexpr int BM = 32 * MI, BN = 128, KSTEP = 128, KW = 64, PITCH = KSTEP;
+    constexpr int STAGE = (BM + BN) * PITCH;              // x rows, then weight rows
+    constexpr int PX = BM * PITCH / 1024 / 8, PW = BN * PITCH / 1024 / 8, PT = PX + PW;  // DMA pieces per wave and stage
+    constexpr int NS = KW / 32, NQ = NS * MI, L = 4;
+    constexpr int U = (NST % 2 == 0) ? NST : 2 * NST;     // steps per unrolled group: stage AND buffer parity static
+    static_assert(MI >= 4 && PX >= 1 && NS == 2 && NQ >= 2 * L && NST >= 2, "128- / 256-row tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST][STAGE], later the epilogue tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, kh = wave >> 2;
+    const int col = lane & 31, h = lane >> 5;
+    const int mtiles = (p.M + BM - 1) / BM;
+    const int bid = blockIdx.x, slice = blockIdx.y;
+    const int mt = bid % mtiles, nt = bid / mtiles;
+    const int m0 = mt * BM;
+    const int units = p.K / KSTEP;
+    const int s_begin = (int)((int64_t)slice * units / p.splitk), s_end = (int)((int64_t)(slice + 1) * units / p.splitk);
+    const int nsteps = s_end - s_begin;
+    const int k_s0 = s_begin * KSTEP;
+
+    const srd_t rsX = make_srd(p.x, (uint32_t)((int64_t)(p.M - 1) * p.stride_xm + p.K));
+    const srd_t rsW = make_srd(p.w, (uint32_t)((int64_t)(p.N - 1) * p.stride_wn + p.K));
+    // piece j of wave w covers LDS bytes [(w * P + j) * 1024, +1024) of its region: row = byte / 128, physical 16-byte slot
+    // (byte % 128) / 16 holds the logical slot phys ^ ((row >> 1) & 7) (128-byte rows: key row >> 1, see gemm_wn_mma.hip)
+    uint32_t xvoff[PX], wvoff[PW];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) xch[(cg * MI + mi) * 64 + lane] = acc[mi];
-        }
-        __syncthreads();
-        if (kh == 0) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi] += xch[(cg * MI + mi) * 64 + lane];
-        }
+    for (int j = 0; j < PX; ++j) {
+        const int byte = (wave * PX + j) * 1024 + lane * 16;
+        const int r = byte / PITCH, phys = (byte % PITCH) / 16;
+        const int logical = phys ^ ((r >> 1) & 7);
+        xvoff[j] = m0 + r < p.M ? (uint32_t)((int64_t)(m0 + r) * p.stride_xm + k_s0 + logical * 16) : 0x80000000u;
     }
-    // ---- epilogue 2: transpose through LDS (128 rows per pass): slabs / output move as 16-byte row segments ------------
-    typedef typename std::conditional<INT, int, float>::type word_t;
-    typedef word_t word4 __attribute__((ext_vector_type(4)));
-    word_t* ct = (word_t*)smem;  // [PASS_ROWS][C_PITCH]
-    constexpr int PASS_ROWS = BM < C_ROWS ? BM : C_ROWS;
-    unsigned* flag = (unsigned*)(smem + PASS_ROWS * C_PITCH * 4);
-    constexpr int NPASS = BM / PASS_ROWS, MIP = PASS_ROWS / 32;
-    constexpr int UNITS = (PASS_ROWS * BN / 4 + 511) / 512;
-    constexpr int NOUT = BM * BN;
-    const int64_t ncol0 = (int64_t)nt * BN;
-    float* slab = p.slabs + ((int64_t)bid * p.splitk) * NOUT;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
-    auto finish = [&](word4 v, int m, int c4) {
-        f32x4 f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) f[j] = (float)v[j];
-        store_out4_any(p.epi, f, m, ncol0 + c4);
+    for (int j = 0; j < PW; ++j) {
+        const int byte = (wave * PW + j) * 1024 + lane * 16;
+        const int r = byte / PITCH, phys = (byte % PITCH) / 16;
+        const int logical = phys ^ ((r >> 1) & 7);
+        wvoff[j] = (uint32_t)((int64_t)(nt * BN + r) * p.stride_wn + k_s0 + logical * 16);
+    }
+    const uint32_t ldsx = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PX) * 1024u);
+    const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(BM * PITCH) + (uint32_t)(wave * PW) * 1024u);
+    auto request = [&](int stage, int step, int j) __attribute__((always_inline)) {  // piece j of the step's PT pieces
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP);
+        if (j < PX) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], so);
+        else req_lds16(rsW, ldsw + (uint32_t)(stage * STAGE + (j - PX) * 1024), wvoff[j - PX], so);
     };
-    word4 own[NPASS][UNITS];  // this block's partial tile, kept for the combine (its own slab is not read back)
+    // fragments: A of (slice g, row block mi): row mi * 32 + col; B of slice g: weight row cg * 32 + col; both at byte
+    // kh * 64 + g * 32 + h * 16 of the row
+    int fa[NST][NS], fb[NST][NS];
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        __syncthreads();
-        if (kh == 0) {
+    for (int st = 0; st < NST; ++st)
 #pragma unroll
-            for (int mi = 0; mi < MIP; ++mi)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    ct[r * C_PITCH + cg * 32 + col] = acc[ps * MIP + mi][e];
-                }
+        for (int g = 0; g < NS; ++g) {
+            const int slot = (kh * KW + g * 32 + h * 16) >> 4;
+            const int off = ((slot ^ (col >> 1)) & 7) << 4;
+            fa[st][g] = st * STAGE + col * PITCH + off;
+            fb[st][g] = st * STAGE + (BM + cg * 32 + col) * PITCH + off;
         }
-        __syncthreads();
+    // slot q -> (slice g, row block mi): int8 walks slice-major; fp8 pairs the two slices of a row block
+    auto slot_g = [&](int q) { return INT ? q / MI : (q & 1); };
+    auto slot_mi = [&](int q) { return INT ? q % MI : (q >> 1); };
+    auto read_a = [&](int stage, int q) -> u32x4 { return *(const u32x4*)(smem + fa[stage][slot_g(q)] + slot_mi(q) * 32 * PITCH); };
+    auto read_b = [&](int stage, int g) -> u32x4 { return *(const u32x4*)(smem + fb[stage][g]); };
+
+    acc_t acc[MI];
 #pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
-            const int m = m0 + ps * PASS_ROWS + r;
-            own[ps][i] = (word4){0, 0, 0, 0};
-            if (r < PASS_ROWS && m < p.M) {
-                const word4 v = *(const word4*)(ct + r * C_PITCH + c4);
-                own[ps][i] = v;
-                if (p.splitk == 1) finish(v, m, c4);
-                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
-                                                            (slice * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);  // sc1
+    for (int i = 0; i < MI; ++i) acc[i] = AC::zero();
+    u32x4 af[L], bw[2][NS];
+
+    // ---- prologue: stages 0 .. NST-2 requested, stage 0 waited for ----------------------------------------------------
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) request(st, st < nsteps ? st : nsteps - 1, j);
+    wait_vm<(NST - 2) * PT>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int g = 0; g < NS; ++g) bw[0][g] = read_b(0, g);
+#pragma unroll
+    for (int q = 0; q < L; ++q) af[q] = read_a(0, q);
+    __builtin_amdgcn_sched_barrier(0);
+
+    constexpr int NQI = NQ - L;  // the barrier slot: every read of the current stage has been issued before it
+    auto do_step = [&](auto Jc, int step) __attribute__((always_inline)) {
+        constexpr int J = decltype(Jc)::value;
+        constexpr int stage = J % NST, stage_next = (J + 1) % NST, stage_fill = (J + NST - 1) % NST, P = J & 1;
+        const int xstep = step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1;  // past the end: repeat the last step (never consumed)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int g = slot_g(q), mi = slot_mi(q);
+            if constexpr (INT) acc[mi] = AC::mma(af[q % L], bw[P][g], acc[mi]);
+            else if (q & 1) acc[mi] = AC::mma64(af[(q - 1) % L], af[q % L], bw[P][0], bw[P][1], acc[mi]);
+            if (q == NQI) {
+                wait_vm<(NST - 2) * PT>();  // the DMAs of step + 1 have landed (those of later stages stay in flight)
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the current stage are complete
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             }
-        }
-    }
-    if (p.splitk == 1) return;
-    __syncthreads();
-    if (!splitk_arrive_is_last(p.counters + bid, p.splitk, flag)) return;
+            if (q == NQI + 1) {  // the next step's B fragments, into the other buffer
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        word4 sum[UNITS];
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) sum[i] = (word4){0, 0, 0, 0};
-        for (int sl = 0; sl < p.splitk; ++sl) {
-            if (sl == slice) {  // own partial: from registers (fixed slice order keeps the sum deterministic)
-#pragma unroll
-                for (int i = 0; i < UNITS; ++i) sum[i] += own[ps][i];
-                continue;
-            }
-            u32x4 t[UNITS];
-#pragma unroll
-            for (int i = 0; i < UNITS; ++i) {
-                const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
-                t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (sl * NOUT + (ps * PASS_ROWS + r) * BN + c4) * 4, 0, 16);
+                for (int gg = 0; gg < NS; ++gg) bw[P ^ 1][gg] = read_b(stage_next, gg);
             }
 #pragma unroll
-            for (int i = 0; i < UNITS; ++i) sum[i] += __builtin_bit_cast(word4, t[i]);
+            for (int r = (INT ? q : (q & 1 ? q - 1 : NQ)); r <= q; ++r) {
+                if (r + L < NQ) af[r % L] = read_a(stage, r + L);
+                else af[r % L] = read_a(stage_next, r + L - NQ);
+            }
+            if (q < PT) request(stage_fill, xstep, q);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
-            const int m = m0 + ps * PASS_ROWS + r;
-            if (r < PASS_ROWS && m < p.M) finish(sum[i], m, c4);
+    };
+    static_assert(PT <= NQ, "one request per slot");
+    auto chain = [&](auto self, auto Jc, int s0) -> void {
+        constexpr int J = decltype(Jc)::value;
+        do_step(std::integral_constant<int, J>{}, s0 + J);
+        if constexpr (J + 1 < U) {
+            if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
         }
-    }
-    if (tid == 0) splitk_reset(p.counters + bid);
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += U) chain(chain, std::integral_constant<int, 0>{}, s0);
+    wait_vm<0>();
+    a8_epilogue<DT, MI>(p, acc, smem, tid, lane, cg, kh, col, h, bid, slice, m0, nt);
 }
 
 typedef void (*a8_kernel_fn)(const GenericParams);
@@ -471,7 +625,16 @@ static const void* a8_pick(int mi) {
     return (const void*)f;
 }
 
-// 8-wave kernel: M >= 2 (tuning[0]: 2 = the 4-wave kernel of round 1; tuning[1] = K slices; tuning[2] = tile rows / 32)
+template <int DT>
+static const void* a8_pick_lds(int mi) {
+    a8_kernel_fn f = nullptr;
+    if (mi == 8) f = gemm_a8w8_lds_kernel<DT, 8, 3>;
+    else if (mi == 4) f = gemm_a8w8_lds_kernel<DT, 4, 4>;
+    return (const void*)f;
+}
+
+// 8-wave kernels: M >= 2 (tuning[0]: 2 = the 4-wave kernel of round 1; tuning[1] = K slices; tuning[2] = tile rows / 32;
+// tuning[3] & 64: weights straight from memory also for the 128- / 256-row tiles, the A/B switch of the LDS-B variant)
 bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
     if (a.elements_per_sample != 1 || a.W_group_mode != 0 || a.M < 2) return false;
     if (a.w_dtype != a.input_dtype) return false;
@@ -483,7 +646,7 @@ bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, Lau
     if ((a.channel_scale_mode == 1 || a.channel_scale_mode == 3) &&
         !(a.meta_dtype == GEMLITE_DT_FP32 || a.meta_dtype == GEMLITE_DT_FP16 || a.meta_dtype == GEMLITE_DT_BF16)) return false;
     if ((a.channel_scale_mode == 1 || a.channel_scale_mode == 3) && ((uintptr_t)a.scales % 16) != 0) return false;
-    const int units = (int)(a.K / 256);
+    int units = (int)(a.K / 256);
     // Tile rows: nothing is dequantised here, so a small tile costs no extra arithmetic (only more weight re-reads from
     // L2) while every K slice costs slab traffic and a tail: take the TALLEST tile (<= the rows M fills) that still gives
     // >= 112 tiles, i.e. at most two K slices; below that, the smallest tile with as many slices as needed.
@@ -492,8 +655,17 @@ bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, Lau
     for (int c = cap; c >= 1; c >>= 1) {
         if ((int64_t)(a.N / 128) * ((a.M + 32 * c - 1) / (32 * c)) >= 112) { mi = c; break; }
     }
+    // From 65 rows on, the two tiles whose weights travel through LDS (measured 7-25 % faster than the direct loads at every
+    // shape of profiles/r02/wide/probe_a8lds.log, and faster than the 64-row direct tile at M = 256): 256 rows when they
+    // alone fill the chip, or with two K slices of a long K (16384); else 128 rows.
+    if (cap >= 4) {
+        const int64_t t8 = (int64_t)(a.N / 128) * ((a.M + 255) / 256);
+        mi = (cap >= 8 && (t8 >= 224 || (2 * t8 >= 224 && a.K >= 16384))) ? 8 : 4;
+    }
     if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4 || a.tuning[2] == 8) mi = a.tuning[2];
     const int bm = 32 * mi;
+    const bool lds_b = mi >= 4 && !(a.tuning[3] & 64);  // both operands through LDS (128-byte K steps)
+    if (lds_b) units = (int)(a.K / 128);
     const int64_t tiles = (int64_t)(a.N / 128) * ((a.M + bm - 1) / bm);
     int splitk = 0;
     if (a.tuning[1] > 0) {
@@ -501,7 +673,7 @@ bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, Lau
         splitk = a.tuning[1];
     } else {
         for (int sk = 1; sk <= units && sk <= 32; ++sk) {
-            if (units / sk < 2) continue;
+            if (units / sk < (lds_b ? 4 : 2)) continue;
             splitk = sk;
             if (tiles * sk >= 224) break;
         }
@@ -509,17 +681,21 @@ bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, Lau
     }
     if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
     if ((uint64_t)splitk * bm * 128 * 4 >= (1ull << 31)) return false;
-    const void* fn = a.input_dtype == GEMLITE_DT_INT8 ? a8_pick<GEMLITE_DT_INT8>(mi)
-                     : (a.input_dtype == GEMLITE_DT_FP8E4 ? a8_pick<GEMLITE_DT_FP8E4>(mi) : a8_pick<GEMLITE_DT_FP8E5>(mi));
+    const void* fn = lds_b ? (a.input_dtype == GEMLITE_DT_INT8 ? a8_pick_lds<GEMLITE_DT_INT8>(mi)
+                              : (a.input_dtype == GEMLITE_DT_FP8E4 ? a8_pick_lds<GEMLITE_DT_FP8E4>(mi) : a8_pick_lds<GEMLITE_DT_FP8E5>(mi)))
+                           : (a.input_dtype == GEMLITE_DT_INT8 ? a8_pick<GEMLITE_DT_INT8>(mi)
+                              : (a.input_dtype == GEMLITE_DT_FP8E4 ? a8_pick<GEMLITE_DT_FP8E4>(mi) : a8_pick<GEMLITE_DT_FP8E5>(mi)));
     if (!fn) return false;
     g.splitk = splitk;
     g.flags = a.tuning[3];
     lp.fn = fn;
     lp.name = mi == 8 ? "gemm_a8w8_mma_kernel<256x128>" : (mi == 4 ? "gemm_a8w8_mma_kernel<128x128>"
               : (mi == 2 ? "gemm_a8w8_mma_kernel<64x128>" : "gemm_a8w8_mma_kernel<32x128>"));
+    if (lds_b) lp.name = mi == 8 ? "gemm_a8w8_lds_kernel<256x128>" : "gemm_a8w8_lds_kernel<128x128>";
     lp.grid = dim3((unsigned)tiles, splitk, 1);
     lp.block = dim3(512, 1, 1);
-    const size_t stages = (size_t)(mi == 8 ? 2 : (mi == 4 ? 3 : 4)) * bm * 256, xch = (size_t)4 * mi * 64 * 64;
+    const size_t stages = lds_b ? (size_t)(mi == 8 ? 3 : 4) * (bm + 128) * 128 : (size_t)(mi == 8 ? 2 : (mi == 4 ? 3 : 4)) * bm * 256;
+    const size_t xch = (size_t)4 * mi * 64 * 64;
     const size_t c_b = (size_t)(bm < 128 ? bm : 128) * 132 * 4 + 16;
     lp.lds_bytes = stages > xch ? stages : xch;
     if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;

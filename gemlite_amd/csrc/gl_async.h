@@ -28,6 +28,12 @@ __device__ __forceinline__ void req_u16(uint32_t& dst, srd_t rs, uint32_t voff, 
     asm volatile("s_nop 4\n\tbuffer_load_ushort %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 // one LDS-DMA piece: 64 lanes x 16 bytes from buffer offset (voff per lane + soff) to LDS [lds_addr, +1024), lane-linear
+// (m0 is a RESERVED register of the AMDGPU backend: hipcc never keeps a value in it across statements, it writes m0 right
+//  before the few instructions that read it — none of which these kernels contain; `grep m0` on the generated code of the
+//  three files that use this helper shows only the moves below.  The clobber is declared anyway; clang warns that clobbers of
+//  reserved registers are advisory, hence the pragma.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void req_lds16(srd_t rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
     // m0 is declared clobbered, not saved / restored (two SALU + a 5-cycle nop per piece in the round-2 loops); one wait state
     // between the SALU write of M0 and the LDS-DMA that reads it
@@ -39,6 +45,7 @@ __device__ __forceinline__ void req_lds4(srd_t rs, uint32_t lds_addr, uint32_t v
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds"
                  : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void tie(uint32_t& v) { asm volatile("" : "+v"(v)); }

@@ -491,11 +491,13 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
     W = (torch.randn(2048, 4096) / 30).half()
     lin = gemlite_amd.helper.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights(W)
     x = (torch.randn(77, 4096) / 10).half().to(DEV)
-    assert _kernel_name(lin, torch.empty(77, 4096, dtype=torch.int8)).startswith("gemm_a8w8_mma_kernel"), _kernel_name(lin, x)
+    assert _kernel_name(lin, torch.empty(77, 4096, dtype=torch.int8)) == "gemm_a8w8_lds_kernel<128x128>", _kernel_name(lin, x)
     y = lin(x)
     outs = {}
-    # streaming kernel | 4-wave MFMA kernel of round 1 | 8-wave kernel: every tile height, K split 1 / 3 (uneven) / 8
-    for t in ((1, 0, 0, 0), (2, 0, 0, 0), (0, 1, 1, 0), (0, 3, 2, 0), (0, 8, 4, 0), (0, 1, 8, 0), (0, 5, 8, 0)):
+    # streaming kernel | 4-wave MFMA kernel of round 1 | 8-wave kernels: every tile height, K split 1 / 3 (uneven) / 8, weights
+    # through LDS (128 / 256 rows, default) and straight from memory (tuning[3] & 64)
+    for t in ((1, 0, 0, 0), (2, 0, 0, 0), (0, 1, 1, 0), (0, 3, 2, 0), (0, 8, 4, 0), (0, 1, 8, 0), (0, 5, 8, 0), (0, 3, 4, 0),
+              (0, 8, 4, 64), (0, 1, 8, 64), (0, 5, 8, 64)):
         gemlite_amd.core.TUNING_OVERRIDE = t
         try:
             outs[t] = lin(x)

@@ -142,10 +142,13 @@ def test_struct_abi_and_validation():
     (dict(M=17, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # then the 8-wave MFMA kernel
     (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 1, 0)), "gemm_a8w8_mma_kernel<32x128>"),
     (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),
-    (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<64x128>"),   # fp8 x fp8: tallest tile with >= 112 tiles
-    (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<128x128>"),
-    (dict(M=4096, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<256x128>"),
-    (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<256x128>"),  # config 5
+    (dict(M=64, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),   # <= 64 rows: weights straight from memory
+    (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # fp8 x fp8, from 65 rows: both operands through LDS
+    (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 0, 64)), "gemm_a8w8_mma_kernel<128x128>"),   # A/B switch
+    (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),
+    (dict(M=1024, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # 256-row tiles would leave half the chip idle
+    (dict(M=4096, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<256x128>"),
+    (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<256x128>"),  # config 5: 128 tiles x 2 slices of a long K
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(2, 0, 0, 0)), "gemm_a8w8_kernel<64x64>"),  # round-1 kernel
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(1, 0, 0, 0)), "kmajor_matmul_kernel"),
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "kmajor_w8a16_kernel"),   # A16W8 int8, pre-scale
