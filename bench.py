@@ -17,6 +17,7 @@ The JSON line carries BOTH halves of BASELINE.json's metric ("... at M=1 and M=2
                     clock, like rocprofv3's kernel duration, includes a fixed dispatch/completion cost).
   roofline_m256   — cfgA (4096^2) and cfgB (8192^2, BASELINE configs[2]) at M=256 in bf16: TFLOP/s against the dense
                     bf16 MFMA peak, same per-launch event clock, plus the chained (hipGraph) time per launch.
+  roofline_prefill_m2048 — 8192^2 at M=2048 (bf16), the large-M end of the MFMA kernel family, same clock.
   roofline_trend_m1 — the same GEMV family at 8192^2 and 16384^2 (fraction of HBM peak grows with size).
   sustained       — >= 1 s of back-to-back replays of the headline step (an independent observer can see the GPU busy).
   cpu_baseline    — oracle/torch_cpu_path.py (a port of the reference's test oracle: unpack -> dequant -> matmul in
@@ -422,6 +423,11 @@ def main():
                 del r
                 torch.cuda.empty_cache()
             line["roofline_m256"] = m256
+            # the large-M end of the same kernel family (north star: "tiled GEMM for large-M prefill"), same clock
+            r = Runner("a16w4_8192_m2048", device, lib, layers=4, use_graph=not args.no_graph)
+            line["roofline_prefill_m2048"] = r.roofline(min(args.kernel_samples, 32))
+            del r
+            torch.cuda.empty_cache()
             trend = {}
             for key, wname in (("8192", "a16w4_8192_m1"), ("16384", "a16w4_16384_m1")):
                 r = Runner(wname, device, lib, use_graph=not args.no_graph)

@@ -20,3 +20,17 @@ for kn, cs in tot.items():
         for cn in sorted(cs):
             v = cs[cn]
             print(f"    {cn:32s} mean {sum(v) / len(v):16.1f}  n={len(v)}")
+        # derived (MI355X: 32 shader engines, 1024 SIMDs; SQ_BUSY_CYCLES is summed over the SEs, SQ_WAVE_CYCLES and the
+        # SQ_WAIT_* / SQ_ACTIVE_INST_* family count quad-cycles): the clock the kernel actually ran at, and how busy the
+        # matrix pipes were AT THAT CLOCK
+        mean = lambda k: sum(cs[k]) / len(cs[k]) if k in cs and cs[k] else None
+        busy, dur, mf, wc = mean("SQ_BUSY_CYCLES"), mean("_dur_ns"), mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("SQ_WAVE_CYCLES")
+        if busy and dur:
+            cyc = busy / 32.0
+            line = f"    => effective clock {cyc / dur:.2f} GHz ({cyc:.0f} cycles in {dur / 1e3:.1f} us)"
+            if mf:
+                line += f"; MFMA pipes busy {100.0 * mf / (cyc * 1024):.1f} % of the SIMD cycles"
+            for k, nm in (("SQ_WAIT_ANY", "parked (waitcnt / barrier)"), ("SQ_WAIT_INST_ANY", "issue-stalled"), ("SQ_ACTIVE_INST_ANY", "issuing")):
+                if wc and mean(k) is not None:
+                    line += f"; {nm} {100.0 * mean(k) / wc:.0f} %"
+            print(line)
