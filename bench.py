@@ -426,6 +426,7 @@ def main():
             # the large-M end of the same kernel family (north star: "tiled GEMM for large-M prefill"), same clock
             r = Runner("a16w4_8192_m2048", device, lib, layers=4, use_graph=not args.no_graph)
             line["roofline_prefill_m2048"] = r.roofline(min(args.kernel_samples, 32))
+            line["roofline_prefill_m2048"]["traffic"] = _traffic("a16w4_8192_m2048")
             del r
             torch.cuda.empty_cache()
             trend = {}
