@@ -160,9 +160,12 @@ typedef struct gemlite_hip_forward_args {
      *                              [1] K slices   [2] 1 = LDS-staged streaming kernel
      *   tiled (M > 32, MFMA)       [0] 1 = streaming kernel, 2 = the 4-wave tiled kernel of round 1 (4-bit only)
      *                              [1] K slices (any count <= K steps; slices may be uneven)
-     *                              [2] tile rows / 32: 1/2/4/8 (8-wave kernel); with [0] = 2: 4 = one-step-ahead, 8 = 256 rows
-     *   unpacked 8-bit (A8W8)      [0] 1 = streaming (one wave per column), 2 = the 4-wave MFMA kernel of round 1
-     *                              [1] K slices   [2] tile rows / 32
+     *                              [2] tile rows / 32: 1/2/4/8 (8-wave kernel, 128-column tiles); 20 / 24 = 128 / 256 rows x 256
+     *                              columns (4- and 2-bit, 16-bit activations); with [0] = 2: 4 = one-step-ahead, 8 = 256 rows
+     *   unpacked 8-bit (A8W8)      [0] 1 = streaming (one wave per column), 2 = the 4-wave MFMA kernel of round 1,
+     *                              4 = the 16-column few-row kernel (default for 2..16 rows) also at M = 1
+     *                              [1] K slices   [2] tile rows / 32 (forces the 8-wave kernels at any M)
+     *                              [3] & 64: 128- / 256-row tiles with the weights straight from memory (default: through LDS)
      *   [3] & 4: development timeline stamps (needs a workspace)   [3] & 8: XCD-aware (tile, K slice) map (opt-in).
      *   A value that does not apply to the shape makes the planner fall through to its own choice or to another family;
      *   it never produces a wrong result. */
