@@ -250,6 +250,14 @@ class Runner:
         ev = HipEvents()
         pairs = [(ev.create(), ev.create()) for _ in range(samples)]
         with torch.cuda.stream(self.stream):
+            # The sampled launches must run BACK TO BACK like the timed region (and like the run rocprofv3 sees): an eager
+            # launch costs ~13 us of host time, so without a head start the GPU idles between 5-us kernels and each one pays a
+            # wake-up inside its event pair (seen on one box: 6.25 us per event vs 4.78 us per launch chained).  A spin kernel
+            # holds the stream while the host queues all the launches behind it.
+            try:
+                torch.cuda._sleep(int(samples * 25e-6 * 2.0e9))
+            except Exception:
+                pass
             for i, (a, b) in enumerate(pairs):
                 self.lib.gemlite_hip_set_profile_events(a, b)
                 self.call(self.mods[i % self.layers])
