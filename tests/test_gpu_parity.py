@@ -520,6 +520,29 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
         assert torch.equal(ya, yb), M
 
 
+@pytest.mark.parametrize("K", [256, 512, 768, 1280])
+def test_a8w8_lds_kernel_short_and_uneven_k(K):
+    """Weights-through-LDS kernel with fewer K steps than LDS stages (K = 256: two 128-byte steps, 3-4 stages) and step counts
+    that are not a multiple of the unrolled group; int8 is exact, so the streaming kernel is the reference, bit for bit."""
+    torch.manual_seed(K)
+    W = (torch.randn(256, K) / 30).half()
+    lin = gemlite_amd.helper.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights(W)
+    for M in (70, 130, 300):
+        x = (torch.randn(M, K) / 10).half().to(DEV)
+        want = "gemm_a8w8_lds_kernel<128x128>"
+        assert _kernel_name(lin, torch.empty(M, K, dtype=torch.int8)) == want
+        outs = {}
+        for t in (None, (0, 0, 8, 0), (0, 2, 4, 0), (1, 0, 0, 0)):
+            gemlite_amd.core.TUNING_OVERRIDE = t
+            try:
+                outs[t] = lin(x)
+            finally:
+                gemlite_amd.core.TUNING_OVERRIDE = None
+        torch.cuda.synchronize()
+        for t, y in outs.items():
+            assert torch.equal(y, outs[(1, 0, 0, 0)]), (K, M, t)
+
+
 @pytest.mark.parametrize("kind", ["int8", "fp8e4", "fp8e5"])
 def test_a8w8_rows_kernel(kind):
     """2..16 rows of A8W8 (BASELINE config 4, M = 16): 16-column blocks, one 16-row MFMA per 64-k chunk — every M, K = 64 * odd
