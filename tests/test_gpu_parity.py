@@ -709,6 +709,27 @@ def test_mma_kernel_wide_tiles(nbits, tdt):
                          abs_gate=1e-3, extra=dict(kernel=name))
 
 
+@pytest.mark.parametrize("K", [64, 128, 256, 384])
+def test_mma_kernel_fewer_k_steps_than_stages(K):
+    """One to six K steps: fewer than the LDS stages / the register ring of every tile variant (the run-ahead requests repeat the
+    last step and are never consumed), narrow and wide tiles, with and without K slices."""
+    from gemlite_amd.core import _hip_matmul
+    lin = _make_layer(256, K, 4, 64, torch.bfloat16, seed=90 + K)
+    for M in (40, 200):
+        x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(torch.bfloat16).to(DEV)
+        y_or = _oracle_from_layer(lin, x)
+        for tuning in ((0, 1, 1, 0), (0, 1, 2, 0), (0, 1, 4, 0), (0, 1, 8, 0), (0, 2, 4, 0), (0, 1, 20, 0), (0, 1, 24, 0), (0, 2, 24, 0)):
+            try:
+                name = _kernel_name(lin, x, 4, tuning)
+            except Exception:
+                continue  # this K does not divide the variant's step (256-k steps of the small tiles) or has fewer steps than slices
+            if "mma_kernel" not in name:
+                continue
+            y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 4, tuning)
+            torch.cuda.synchronize()
+            _compare(f"mma_short_k/K{K}/M{M}/{tuning}", y, y_or, lin.output_dtype.value, abs_gate=1e-3, extra=dict(kernel=name))
+
+
 def test_mma_kernel_wide_tiles_prefill_shape_and_modes():
     """What the planner picks for prefill (256 x 256 tiles when they alone fill the chip) at 2048 x 4096 x 8192, every
     W_group_mode, checked on column blocks against the oracle and on all outputs against the 128-column tiles."""
