@@ -190,11 +190,22 @@ class Runner:
                 self.step_eager()
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
-        self.graph = None
+        self.graph = self.chain_graph = None
+        self.chain_reps = 1
         if use_graph:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.step_eager()
+            # chained timing: one graph replay costs the host / command processor ~10 us whatever it holds (guide row
+            # graph-replay-floor), so short steps (2 .. 8 launches) are repeated inside ONE graph until it holds >= 32 launches
+            self.chain_reps = max(1, -(-32 // self.layers))
+            if self.chain_reps > 1:
+                self.chain_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.chain_graph, stream=self.stream):
+                    for _ in range(self.chain_reps):
+                        self.step_eager()
+            else:
+                self.chain_graph = self.graph
 
     def call(self, lin):
         if self.dt in PREQUANT:  # the matmul alone: x was quantised once in build_layers
@@ -213,13 +224,21 @@ class Runner:
             with torch.cuda.stream(self.stream):
                 self.step_eager()
 
+    def run_chain(self):
+        if self.chain_graph is not None:
+            self.chain_graph.replay()
+        else:
+            with torch.cuda.stream(self.stream):
+                self.step_eager()
+
     def chained_us_per_launch(self, min_seconds=0.05, min_steps=5):
         """Wall time per launch of back-to-back steps (kernel + the dependent-launch gap), un-profiled."""
-        self.run_step()
+        reps = self.chain_reps if self.chain_graph is not None else 1
+        self.run_chain()
         torch.cuda.synchronize()
         steps, t0 = 0, time.perf_counter()
         while True:
-            self.run_step()
+            self.run_chain()
             steps += 1
             if steps >= min_steps and steps % 5 == 0:
                 torch.cuda.synchronize()
@@ -227,7 +246,7 @@ class Runner:
                     break
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        return el / (steps * self.layers) * 1e6, steps, el
+        return el / (steps * reps * self.layers) * 1e6, steps * reps, el
 
     def eager_us_per_call(self, calls=2000):
         """Host cost of the product path: wall time per eager `layer(x)` call (Python -> ctypes -> one C call -> launch),

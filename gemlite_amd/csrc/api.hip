@@ -16,6 +16,7 @@
 namespace gl {
 // planners (defined next to their kernels)
 bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
@@ -227,6 +228,19 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
             plan_gemv_a8wn(a, p, lp)) {
             r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
         }
+        // Decode on the matrix core (gemv_mfma.hip, round 3), where it measured faster than the dot-product family
+        // (profiles/r03/probe_gemv3_*.log): M = 1 on 32-column tiles (8192 <= N < 16384: 9.9 vs 10.4 us at 8192^2; the 16-column
+        // shapes keep the dot-product decode kernel, 4.8 vs 5.8 us, and 16384^2 its 8-rows-per-lane form, 23.9 vs 25.2), and 2..4
+        // rows (6.4 vs 7.3 us at 4096^2 against gemm_wn_direct).  tuning[3] & 512 = never, & 1024 = wherever it applies (A/B runs).
+        if (x16 && !(a.tuning[3] & 512) && a.tuning[1] == 0 &&
+            ((want_gemv && a.M == 1 && mt != GEMLITE_MATMUL_GEMV_SPLITK) || (a.M >= 2 && a.M <= 4 && mt == GEMLITE_MATMUL_AUTO))) {
+            WnParams pm = p;
+            LaunchPlan lm{};
+            if (plan_gemv_mfma(a, pm, lm) && ((a.tuning[3] & 1024) || a.M >= 2 || a.tuning[0] != 0 || lm.block.x == 0 ||
+                                              (a.N / lm.grid.x) == 32)) {
+                r.kind = K_GEMV_WN; r.wn = pm; r.lp = lm; return;
+            }
+        }
         if (want_gemv && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }
         if (!want_gemv) {
             // Many rows: the 8-wave MFMA kernel (all bit widths) from 33 rows.  tuning[0]: 1 = LDS-staged streaming kernel,
@@ -353,6 +367,9 @@ static int launch(const void* fn, dim3 grid, dim3 block, void** kargs, size_t ld
     return GEMLITE_OK;
 }
 
+static std::atomic<int> g_cu_count{256};
+int gl::resident_block_limit() { return g_cu_count.load(std::memory_order_relaxed); }
+
 // The current device must be a gfx950 part: the code object holds no other ISA.  Checked once per device id.
 static int check_device(int* dev_out) {
     int dev = -1;
@@ -364,6 +381,9 @@ static int check_device(int* dev_out) {
     if (st == 0) {
         hipDeviceProp_t prop;
         st = (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 2;
+        // the smallest CU count seen bounds what the planners may assume co-resident (partitioned / CU-masked devices report fewer)
+        if (st == 1 && prop.multiProcessorCount > 0 && prop.multiProcessorCount < g_cu_count.load(std::memory_order_relaxed))
+            g_cu_count.store(prop.multiProcessorCount, std::memory_order_relaxed);
         state[slot].store(st, std::memory_order_relaxed);
     }
     return st == 1 ? GEMLITE_OK : GEMLITE_ERR_NO_DEVICE;
@@ -390,7 +410,7 @@ extern "C" {
 int gemlite_hip_abi_version(void) { return GEMLITE_HIP_ABI_VERSION; }
 
 const char* gemlite_hip_build_info(void) {
-    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemm_wn_direct, gemm_wn_stream, gemm_wn_mma, gemm_wn_tiled, gemm_a8w8, gemm_mx, kmajor, generic, "
+    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemv_mfma, gemm_wn_direct, gemm_wn_stream, gemm_wn_mma, gemm_wn_tiled, gemm_a8w8, gemm_mx, kmajor, generic, "
            "act_quant_per_token, act_quant_mx, pack/unpack_over_cols";
 }
 
@@ -446,11 +466,11 @@ int gemlite_hip_launch_noop(int32_t blocks, int32_t threads, void* stream) {
 int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
     const int v = validate(args);
     if (v != GEMLITE_OK) return v;
+    int dev = 0;
+    const int dv = check_device(&dev);  // (before planning: the planners ask for the device's CU count)
     Resolved r;
     resolve(*args, r);
     if (r.status != GEMLITE_OK) return r.status;
-    int dev = 0;
-    const int dv = check_device(&dev);
     if (dv != GEMLITE_OK) return dv;
     hipStream_t st = (hipStream_t)stream;
     if (r.kind == K_GEMV_WN || r.kind == K_STREAM_WN || r.kind == K_TILED_WN) {

@@ -665,6 +665,110 @@ __global__ __launch_bounds__(512, 2) void gemm_wn_mma_kernel(const WnParams p) {
     //      wave instruction), and only the last block to arrive goes on: ALL 8 of its waves load the slices' words back
     //      into the same lanes (wave (cg, kh) takes row blocks [kh MIH, kh MIH + MIH)), add them in slice order (run-to-run
     //      deterministic) into the accumulator registers, and hand the sums to the output stage.
+    // ---- epilogue 2x (K split over blocks, round 3): REDUCE-SCATTER between the co-resident slices of a tile.  With the slab +
+    //      ticket protocol below every block writes its whole partial tile and the last block to arrive reads all of them back
+    //      alone (cfgB, 256 x 128 x 4 slices: 4 us of slab stores + 1.5 us ticket + ~9 us of one CU reading 512 KB while its
+    //      three peers have left).  Here slice s keeps the row blocks mi = s (mod S) and sends each of the others straight to
+    //      its owner's inbox as write-through 16-byte rows in fragment order; every block bumps one arrival counter per peer,
+    //      waits until its own counter shows S - 1, pulls the S - 1 partial copies of ITS row blocks into LDS with LDS-DMA (all
+    //      pieces in flight at once, no registers), adds them in slice order (bit-identical to the ticket path) and writes its
+    //      rows of the output.  (S - 1) / S of the tile leaves and enters every block, all blocks work in parallel, nobody
+    //      waits for a ticket round trip.  The wait is a spin: the planner only picks this mode when ALL blocks of the launch
+    //      fit on the device at once (tiles x S <= CUs, one block per CU), so every peer is running or about to be dispatched.
+    if constexpr (KH == 2 && MI >= 2) {
+        if (p.splitk > 1 && p.combine == 1) {
+            const int S = p.splitk, LS = 31 - __builtin_clz((unsigned)S);  // S = 2^LS divides MI
+            const int OWB = MI >> LS;                                      // row blocks this block owns
+            float* inbox = p.slabs + (int64_t)bid * S * NOUT;             // [owner][from][j][cg][e4][lane] float4
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(inbox, (short)0, S * NOUT * 4, 0x00020000);
+            if (kh == 0) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int o = mi & (S - 1), j = mi >> LS;
+                    if (o != slice) {
+                        const int unit = (((o * S + slice) * OWB + j) * 4 + cg) * 4;  // in 1-KiB pieces
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const f32x4 v = {acc[mi][4 * e4], acc[mi][4 * e4 + 1], acc[mi][4 * e4 + 2], acc[mi][4 * e4 + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (unit + e4) * 1024 + lane * 16, 0, 16);  // sc1
+                        }
+                    }
+                }
+            }
+            stamp(5);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left
+            __syncthreads();
+            unsigned* cnt = p.counters + (int64_t)bid * S;    // one arrival counter per owner
+            if (tid < S && tid != slice) __hip_atomic_fetch_add(cnt + tid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt + slice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(S - 1)) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 26)) __builtin_trap();  // seconds: a peer that never runs (see the planner's residency rule)
+                }
+                __hip_atomic_store(cnt + slice, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every peer has arrived: leave it zero
+            }
+            __syncthreads();
+            stamp(6);
+            // the S - 1 partial copies of the owned row blocks -> LDS behind the output staging tile, as 1-KiB DMA pieces
+            const int ct_bytes = (OWB * 32 * C_PITCH * 4 + 1023) & ~1023;
+            const int per_from = OWB * 16;  // pieces one peer sent: [j][cg][e4]
+            const int npieces = (S - 1) * per_from;
+            const srd_t rsI = make_srd(inbox + (int64_t)slice * NOUT, (uint32_t)NOUT * 4u);
+            const uint32_t gaddr = lds_addr_of(smem) + (uint32_t)ct_bytes;
+            for (int q = wave; q < npieces; q += 8) {
+                const int fi = q / per_from, rem = q - fi * per_from, f = fi + (fi >= slice ? 1 : 0);
+                req_lds16_sc1(rsI, gaddr + (uint32_t)q * 1024u, (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((f * per_from + rem) * 1024));
+            }
+            wait_vm<0>();
+            __syncthreads();
+            float* ct = (float*)smem;  // [OWB * 32][C_PITCH]
+            if (kh == 0) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    if ((mi & (S - 1)) != slice) continue;
+                    const int j = mi >> LS;
+                    f32x16 sum;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum[e] = 0.f;
+                    for (int f = 0; f < S; ++f) {  // slice order: bit-identical to the ticket path's sum
+                        if (f == slice) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) sum[e] += acc[mi][e];
+                        } else {
+                            const int fi = f - (f > slice ? 1 : 0);
+                            const unsigned char* src = smem + ct_bytes + (((fi * OWB + j) * 4 + cg) * 4) * 1024 + lane * 16;
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) {
+                                const f32x4 v = *(const f32x4*)(src + e4 * 1024);
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) sum[4 * e4 + t] += v[t];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int r = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        ct[r * C_PITCH + cg * 32 + col] = sum[e];
+                    }
+                }
+            }
+            __syncthreads();
+            const bool typed_out_x = p.epi.out_dt == TR::DT && (p.epi.meta_dt == TR::DT || p.epi.c_mode == 0 || p.epi.c_mode == 2);
+            const int64_t ncol0x = (int64_t)nt * BN;
+            for (int u = tid; u < OWB * 32 * (BN / 4); u += 512) {
+                const int r = u / (BN / 4), c4 = (u % (BN / 4)) * 4;
+                const int m = m0 + ((((r >> 5) << LS) + slice) << 5) + (r & 31);
+                if (m < p.M) {
+                    const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
+                    if (typed_out_x) store_out4_t<Tag>(p.epi, v, m, ncol0x + c4);
+                    else store_out4_any(p.epi, v, m, ncol0x + c4);
+                }
+            }
+            stamp(7);
+            return;
+        }
+    }
     if (p.splitk > 1) {
         float* slab = p.slabs + ((int64_t)bid * p.splitk) * NOUT;  // wave-uniform base of this tile's slabs
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, (short)0, p.splitk * NOUT * 4, 0x00020000);
@@ -1026,6 +1130,11 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if (!fn) return false;
     p.splitk = splitk;
     p.rows_per_slice = rows;  // ALL packed rows: the kernel derives each slice's step range itself
+    // K-slice combine: reduce-scatter between the slices of a tile when they are certain to be co-resident (every block of the
+    // launch fits on the device at once: <= one block per CU) and the slices divide the tile's row blocks; else slabs + ticket.
+    // tuning[3] & 128 forces the ticket protocol (A/B runs, tests of both paths).
+    p.combine = (!wide && splitk > 1 && (splitk & (splitk - 1)) == 0 && mi >= 2 && splitk <= mi && !(a.tuning[3] & 128) &&
+                 tiles * splitk <= resident_block_limit()) ? 1 : 0;
     lp.fn = fn;
     static const char* names[4][4] = {
         {"gemm_w4_mma_kernel<32x128>", "gemm_w4_mma_kernel<64x128>", "gemm_w4_mma_kernel<128x128>", "gemm_w4_mma_kernel<256x128>"},
@@ -1048,6 +1157,11 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * (bn + 4) * 4 + 16;
     lp.lds_bytes = stages > xch ? stages : xch;
     if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
+    if (p.combine == 1) {  // output staging tile of the owned rows + the S - 1 inbound copies of them
+        const size_t owb = (size_t)mi / splitk;
+        const size_t ex = ((owb * 32 * (bn + 4) * 4 + 1023) & ~(size_t)1023) + (size_t)(splitk - 1) * owb * 16 * 1024;
+        if (lp.lds_bytes < ex) lp.lds_bytes = ex;
+    }
     lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * bn * 4 : 0;
     lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
     return true;

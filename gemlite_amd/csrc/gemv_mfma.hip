@@ -1,0 +1,401 @@
+// gemv_mfma.hip — decode (M <= 16) for packed 4- / 2-bit weights ON THE MATRIX CORE (round 3).
+//
+// Replaces gemv_INT_revsplitK_kernel / gemv_INT_kernel (gemlite/triton_kernels/gemv_revsplitK_kernels.py:226-462,
+// gemv_kernels.py:230-388) at M = 1 and gemm_splitK_INT_kernel (gemm_splitK_kernels.py:277-450) for a handful of rows.
+//
+// Why: the round-3 timeline of the dot-product GEMV (scripts/timeline_decode.py, profiles/r03/timeline_decode_v1.log) showed
+// that at 4096 x 4096 a block's first wave has finished its arithmetic 1.2 us after the block started, but the block lives
+// 2.5 us: the weights arrive within ~1.2 us at close to the HBM rate, and then the SIMD still has to issue the ~260 VALU
+// instructions of each of its four waves (unpack, v_dot2c, pairing / pre-scaling x per lane, group epilogue).  The kernel
+// was VALU-bound, not bandwidth-bound.  Here
+//   * one packed word IS one lane's B fragment of v_mfma_f32_16x16x32 (8 consecutive k of one column): 5 VALU turn it into
+//     8 raw integer codes (fp16: the masked bit fields used as subnormals, exact; bf16: 128 + q through OR 0x4300), the
+//     matrix core multiplies and adds, and scale / zero are applied once per quantisation group to the accumulator;
+//   * x is prepared ONCE per block: the rows are pair-permuted / pre-scaled into LDS (16 bytes per packed row and
+//     activation row, the exact A fragment of lane (m, k-quarter)) together with the per-group sums of x that the zero term
+//     needs; the A fragment of a k-step is then one ds_read_b128 — no per-lane x arithmetic, no x traffic per MFMA
+//     (gemm_wn_direct.hip fetches 16 bytes of x per lane and MFMA from L2: 4x the weight bytes through the address path);
+//   * tile = 16 V columns (V = 1 / 2 / 4 packed words per lane: 64- / 128- / 256-byte row segments), K is never split
+//     across blocks; the NW waves of a block deal the quantisation groups round-robin, every wave keeps GB groups of
+//     requests in flight (all of its K range at 4096), non-temporal loads.
+// Numerics: fp32 accumulation in the matrix core, raw codes are exact, scale / zero in fp32 per group.
+#include "gl_common.h"
+
+namespace gl {
+
+namespace gmf {
+
+template <typename Tag>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<half_tag>(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<bf16_tag>(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+template <int V> struct Vec;
+template <> struct Vec<1> { typedef uint32_t W; typedef uint16_t M; };
+template <> struct Vec<2> { typedef u32x2 W; typedef uint32_t M; };
+template <> struct Vec<4> { typedef u32x4 W; typedef u32x2 M; };
+// V packed words / V 16-bit metadata values of one lane: one buffer load each (voffset per lane, soffset per request)
+template <int V>
+__device__ __forceinline__ typename Vec<V>::W ldw(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    if constexpr (V == 1) return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 2);
+    else if constexpr (V == 2) return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 2);
+    else return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 2);
+}
+template <int V>
+__device__ __forceinline__ typename Vec<V>::M ldm(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    if constexpr (V == 1) return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0);
+    else if constexpr (V == 2) return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+    else return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+}
+template <int V>
+__device__ __forceinline__ uint16_t meta_of(const typename Vec<V>::M& m, int j) {
+    if constexpr (V == 1) return m;
+    else if constexpr (V == 2) return (uint16_t)(m >> (16 * j));
+    else return (uint16_t)(m[j >> 1] >> (16 * (j & 1)));
+}
+template <int V>
+__device__ __forceinline__ uint32_t word_of(const typename Vec<V>::W& w, int j) {
+    if constexpr (V == 1) return w; else return w[j];
+}
+
+// Slot order of a lane's 8 (fp16 pairs) k-values.  4-bit word, fields q0..q7:
+//   fp16: d0 = w & 0x000F000F = (q0, q4), d1 = w & 0x00F000F0 = 16 (q1, q5), d2, d3 the same of w >> 8 -> (q2, q6), 16 (q3, q7)
+//         (subnormals: value * 2^-24; two fields per 16-bit half fit the 10-bit mantissa); x slots (x0,x4) (x1,x5)/16 (x2,x6) (x3,x7)/16
+//   bf16: d_i = ((w >> 4 i) & 0x000F000F) | 0x43004300 = (128 + q_i, 128 + q_{i+4}); x slots (x_i, x_{i+4}) unscaled
+// 2-bit word, fields q0..q15, two fragments f = 0, 1 (k-steps): pairs (q_a, q_{a+8}), a = 4 f + dd
+//   fp16: four fields per half fit: d = w & (0x00030003 << 2 a) -> 4^a (q_a, q_{a+8}); x slots (x_a, x_{a+8}) / 4^a ... a < 4,
+//         fragment 1 from w >> 8 (a - 4 < 4)
+//   bf16: ((w >> 2 a) & 0x00030003) | 0x43004300
+template <typename Tag, int NBITS>
+struct Unpack {
+    static constexpr bool SUBN = F16Traits<Tag>::DT == GEMLITE_DT_FP16;
+    static constexpr int E = 32 / NBITS, HALF = E / 2;
+    // fragment f (k-step f of the word) -> 4 dwords
+    static __device__ __forceinline__ u32x4 frag(uint32_t w, int f) {
+        u32x4 r;
+        if constexpr (SUBN) {
+            if constexpr (NBITS == 4) {
+                const uint32_t w8 = w >> 8;
+                r[0] = w & 0x000F000Fu; r[1] = w & 0x00F000F0u; r[2] = w8 & 0x000F000Fu; r[3] = w8 & 0x00F000F0u;
+            } else {
+                const uint32_t v = f ? (w >> 8) : w;
+                r[0] = v & 0x00030003u; r[1] = v & 0x000C000Cu; r[2] = v & 0x00300030u; r[3] = v & 0x00C000C0u;
+            }
+        } else {
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int a = 4 * f + dd;
+                r[dd] = ((w >> (NBITS * a)) & (((1u << NBITS) - 1u) * 0x00010001u)) | F16Traits<Tag>::MAGIC2;
+            }
+        }
+        return r;
+    }
+    // power of two the stored x of slot dd is divided by (fp16 only)
+    static __device__ __forceinline__ constexpr int xshift(int dd) { return SUBN ? (NBITS == 4 ? 4 * (dd & 1) : 2 * dd) : 0; }
+};
+
+}  // namespace gmf
+
+// MB = 1: a single activation row (every lane reads row 0's fragment: LDS broadcast); MB = 4: up to 4 rows.
+// GB = group units of requests a wave keeps in flight per batch; SPG = MFMA k-steps (32 k) per quantisation group (4: >= 128, 2: 64).
+//
+// x never crosses waves: a wave needs exactly the x of ITS k range, 16 bytes per (row, packed row) = CPB <= 64 chunks per batch,
+// so lane L fetches chunk L of the batch (first request of the batch, ahead of the weights), pair-permutes / pre-scales it in
+// registers, drops it into the wave's private LDS slot and reads the A fragments back as broadcasts.  No block barrier before
+// the arithmetic: the first version staged all of x per BLOCK, and its barrier waited 3.3 us — the x requests of the later
+// waves queue in the CU's in-order memory path behind the weight requests of the earlier ones (profiles/r03/timeline_decode_v2.log).
+template <typename Tag, int NBITS, int V, int NW, int MB, int GB, int SPG>
+__global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p) {
+    using namespace gmf;
+    using TR = F16Traits<Tag>;
+    using UP = Unpack<Tag, NBITS>;
+    using WT = typename Vec<V>::W;
+    using MT = typename Vec<V>::M;
+    constexpr bool SUBN = UP::SUBN;
+    constexpr int E = 32 / NBITS, NF = E / 8;  // NF k-steps per packed word
+    static_assert(NBITS == 4, "x staging below: one 16-byte chunk per packed row (4-bit words)");
+    constexpr int TN = 16 * V, NT = NW * 64;
+    constexpr int RSTEPS = SPG / NF;           // wave loads (4 packed rows each) per group unit
+    constexpr int CPG = 4 * SPG;               // x chunks (8 k) per group unit
+    constexpr int CPB = GB * CPG;              // ... per batch: one per lane
+    static_assert(SPG % NF == 0 && RSTEPS >= 1 && CPB <= 64, "a batch's x chunks are dealt one per lane");
+    constexpr float QSCALE = SUBN ? 16777216.0f : 1.0f;
+    constexpr float OFF = SUBN ? 0.0f : TR::OFF;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kg = lane >> 4;
+    const int tile = blockIdx.x;
+    const int n0 = tile * TN + c * V;
+    const int K = p.K, M = p.M;
+    const int ngroups = K >> 5 >> (SPG == 4 ? 2 : 1);  // group units of SPG k-steps
+    unsigned char* xw = smem + (size_t)wave * (2 * MB * 1024);            // this wave's x slots: [2 buffers][MB rows][64 chunks x 16 B]
+    float* red = (float*)(smem + (size_t)NW * (2 * MB * 1024));           // [NW][64][4 V]
+
+    // opt-in timeline (tuning[3] & 4, needs a workspace): wave 0 of every block stores the 100 MHz global clock at
+    // [start, first batch requested, arithmetic done, output stored] (scripts/timeline_decode.py)
+    const bool probe = (p.flags & 4) && p.counters && wave == 0 && lane == 0 && blockIdx.x < 1024;
+    unsigned long long* stamps = (unsigned long long*)(p.counters + MAX_SPLITK_COUNTERS) + blockIdx.x * 4;
+    auto stamp = [&](int i) {
+        if (probe) stamps[i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+
+    const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
+    const uint16_t* sp = need_s ? (const uint16_t*)p.scales : (const uint16_t*)p.w;
+    const uint16_t* zp = need_z ? (const uint16_t*)p.zeros : (const uint16_t*)p.w;
+    const uint32_t mstride = (need_s || need_z) ? (uint32_t)p.stride_meta_g : 0u;
+    const uint32_t sw4 = (uint32_t)p.stride_wk * 4u;
+    // Buffer loads: the per-lane part of every address is ONE register computed once, the per-request part (group unit, wave
+    // load) is a scalar offset — no vector arithmetic per request (the first version computed a 64-bit address per load: ~250
+    // instructions per wave before its last request was out).  Loads are unconditional (a branch around a load makes every
+    // later wait vmcnt(0)); units past the end re-read the wave's last unit and count zero.  aux 2 = nt.
+    const int rows_x = M < MB ? M : MB;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)(((int64_t)(rows_x - 1) * p.stride_xm + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)(uint32_t)((int64_t)(K / E) * sw4), 0x00020000);
+    const int meta_rows = p.gs_shift >= 31 ? 1 : (K >> p.gs_shift);
+    const int meta_bytes = (int)(((int64_t)(meta_rows - 1) * mstride + p.N) * 2);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)sp, (short)0, need_s ? meta_bytes : 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)zp, (short)0, need_z ? meta_bytes : 16, 0x00020000);
+    const uint32_t wvoff = (uint32_t)kg * sw4 + (uint32_t)n0 * 4u;
+    const uint32_t mvoff = (need_s || need_z) ? (uint32_t)n0 * 2u : 0u;
+    // x chunk of lane L in a batch starting at the wave's unit index i0: unit gi = L / CPG of the batch, chunk L % CPG of it;
+    // unit u = wave + NW (i0 + gi) covers chunks [u CPG, (u + 1) CPG) of the row
+    const int xgi = lane / CPG, xwi = lane % CPG;
+    const uint32_t xvoff = lane < CPB ? (uint32_t)(((wave + NW * xgi) * CPG + xwi) * 16) : 0x80000000u;  // (lanes past CPB: no request)
+    const int my_units = (ngroups - wave + NW - 1) / NW;
+
+    struct Batch { u32x4 x[MB]; WT w[GB][RSTEPS]; MT s[GB], z[GB]; };
+    auto load_batch = [&](Batch& b, int i0) {
+        // x of units past the wave's end: offsets beyond K read zeros through the descriptor's range check (rows share one range:
+        // a chunk index past the row's end may land in the next row — harmless, that unit counts zero)
+        const uint32_t xso = (uint32_t)__builtin_amdgcn_readfirstlane(NW * i0 * CPG * 16);
+#pragma unroll
+        for (int r = 0; r < MB; ++r) {
+            const uint32_t rso = (uint32_t)__builtin_amdgcn_readfirstlane((int)((int64_t)(r < rows_x ? r : rows_x - 1) * p.stride_xm * 2));
+            b.x[r] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff, xso + rso, 0);
+        }
+#pragma unroll
+        for (int gi = 0; gi < GB; ++gi) {
+            const int iu = i0 + gi < my_units ? i0 + gi : my_units - 1;
+            const int u = wave + NW * iu;
+            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(u * (4 * RSTEPS)) * sw4;
+#pragma unroll
+            for (int rs = 0; rs < RSTEPS; ++rs) b.w[gi][rs] = gmf::ldw<V>(rsW, wvoff, so + (uint32_t)(4 * rs) * sw4);
+            const uint32_t mo = (uint32_t)__builtin_amdgcn_readfirstlane(group_of(u * 32 * SPG, p.gs_shift)) * mstride * 2u;
+            b.s[gi] = gmf::ldm<V>(rsS, mvoff, (need_s || need_z) ? mo : 0u);
+            b.z[gi] = gmf::ldm<V>(rsZ, mvoff, (need_s || need_z) ? mo : 0u);
+        }
+    };
+    // pair-permute (+ pre-scale) the lane's chunk into A-fragment order, store it in buffer `buf`; returns the sum of the TRUE
+    // x over the chunk's group unit (butterfly over the CPG lanes of the unit: fixed order, every lane of the unit gets it)
+    auto stage = [&](const u32x4 v, int buf, int r) -> float {
+        uint32_t q[4];
+        q[0] = __builtin_amdgcn_perm(v[2], v[0], 0x05040100u);
+        q[1] = __builtin_amdgcn_perm(v[2], v[0], 0x07060302u);
+        q[2] = __builtin_amdgcn_perm(v[3], v[1], 0x05040100u);
+        q[3] = __builtin_amdgcn_perm(v[3], v[1], 0x07060302u);
+        float sm = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) sm = TR::dot2(q[dd], TR::ONES2, sm);
+        if constexpr (SUBN) {
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd)
+                if (UP::xshift(dd)) {
+                    const _Float16 sc = (_Float16)(1.0f / (float)(1 << UP::xshift(dd)));
+                    q[dd] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2_t, q[dd]) * (h2_t){sc, sc});
+                }
+        }
+        *(u32x4*)(xw + (size_t)(buf * MB + r) * 1024 + (size_t)lane * 16) = (u32x4){q[0], q[1], q[2], q[3]};
+        sm += gmf::dppf<0xB1>(sm);   // quad_perm [1,0,3,2]
+        sm += gmf::dppf<0x4E>(sm);   // quad_perm [2,3,0,1]: every lane holds its quad's sum
+        sm += gmf::dppf<0x141>(sm);  // row_half_mirror: + the other quad of the 8-lane half
+        if constexpr (CPG == 16) sm += gmf::dppf<0x140>(sm);  // row_mirror: + the other half
+        return sm;
+    };
+
+    f32x4 tot[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) tot[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
+    const float bz = (p.w_mode == 1 || p.w_mode == 3) ? -1.f : (p.w_mode == 4 ? 1.f : 0.f);
+    const bool b_times_s = p.w_mode == 3;
+    const int mrow = MB == 1 ? 0 : (c < MB ? c : MB - 1);  // A row of this lane (rows past the tile repeat the last one; never stored)
+
+    // sums of x per (row, group unit of the batch): wave-uniform -> scalar registers
+    float gs[MB][GB];
+    auto stage_batch = [&](const Batch& b, int buf) {
+#pragma unroll
+        for (int r = 0; r < MB; ++r) {
+            const float sm = stage(b.x[r], buf, r);
+#pragma unroll
+            for (int gi = 0; gi < GB; ++gi)
+                gs[r][gi] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sm), gi * CPG));
+        }
+    };
+    auto compute = [&](const Batch& b, int i0, int buf) {
+        f32x4 acc[GB][V];
+        float live[GB];
+#pragma unroll
+        for (int gi = 0; gi < GB; ++gi) live[gi] = i0 + gi < my_units ? 1.f : 0.f;
+        const unsigned char* xa = xw + (size_t)(buf * MB + mrow) * 1024 + (size_t)kg * 16;
+        // k-step-major over the GB group units: consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int rs = 0; rs < RSTEPS; ++rs)
+#pragma unroll
+            for (int gi = 0; gi < GB; ++gi) {
+                const u32x4 a = *(const u32x4*)(xa + (gi * CPG + rs * 4) * 16);  // chunk (unit gi, k-step rs, quarter kg)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const u32x4 bf = UP::frag(word_of<V>(b.w[gi][rs], j), 0);
+                    const f32x4 cin = rs == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[gi][j];
+                    acc[gi][j] = mfma16<Tag>(a, bf, cin);
+                }
+            }
+#pragma unroll
+        for (int gi = 0; gi < GB; ++gi) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float s = need_s ? TR::to_float(gmf::meta_of<V>(b.s[gi], j)) : 1.f;
+                const float z = need_z ? TR::to_float(gmf::meta_of<V>(b.z[gi], j)) : scalar_zero;
+                const float a = s * QSCALE * live[gi];
+                const float bb = (bz * z * (b_times_s ? s : 1.f) - s * OFF) * live[gi];
+                // C layout: rows 4 kg + r — the tile's rows (< MB <= 4) live in the registers of the kg = 0 lanes
+#pragma unroll
+                for (int r = 0; r < MB; ++r) tot[j][r] += a * acc[gi][j][r] + bb * gs[r][gi];
+            }
+        }
+    };
+
+    Batch cur, nxt;
+    load_batch(cur, 0);
+    stamp(1);
+    stage_batch(cur, 0);
+    int buf = 0;
+#pragma unroll 1
+    for (int i0 = 0; i0 < my_units; i0 += GB) {
+        const bool more = i0 + GB < my_units;
+        if (more) load_batch(nxt, i0 + GB);
+        compute(cur, i0, buf);
+        if (more) {
+            cur = nxt;
+            buf ^= 1;
+            stage_batch(cur, buf);
+        }
+    }
+    stamp(2);
+
+    // ---- the NW waves (disjoint K) meet in LDS; C layout of 16x16: column c, rows 4 kg + r ----------------------------------
+#pragma unroll
+    for (int j = 0; j < V; ++j) *(f32x4*)(red + ((wave * 64 + lane) * V + j) * 4) = tot[j];
+    __syncthreads();
+    for (int o = tid; o < MB * TN; o += NT) {
+        // output (m, n): column n = cc V + j lives in lane cc (kg = 0), register m
+        const int m = o / TN, n = o - m * TN;
+        const int cc = n / V, j = n - cc * V;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[((w * 64 + cc) * V + j) * 4 + m];
+        if (m < M) store_out_t<Tag>(p.epi, v, m, (int64_t)tile * TN + n);
+    }
+    stamp(3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host-side planning.  tuning[0]: 0 auto | 21 / 22 / 24 = 1 / 2 / 4 words per lane (16 / 32 / 64 columns);  tuning[2]: 0 auto | 4 / 8 / 16 waves
+// ---------------------------------------------------------------------------------------------------------------------
+typedef void (*gmf_fn)(const WnParams);
+template <typename Tag, int V, int MB, int SPG>
+static gmf_fn gmf_pick_nw(int nw) {
+    constexpr int GB = V == 4 ? 2 : 4;
+    switch (nw) {
+        case 4: return gemv_mfma_kernel<Tag, 4, V, 4, MB, GB, SPG>;
+        case 8: return gemv_mfma_kernel<Tag, 4, V, 8, MB, GB, SPG>;
+        case 16:  // 1024 threads: 128 registers per lane — only the one-word tile fits without spilling
+            if constexpr (V == 1) return gemv_mfma_kernel<Tag, 4, V, 16, MB, GB, SPG>;
+            else return nullptr;
+        default: return nullptr;
+    }
+}
+template <typename Tag, int MB, int SPG>
+static gmf_fn gmf_pick_v(int v, int nw) {
+    switch (v) {
+        case 1: return gmf_pick_nw<Tag, 1, MB, SPG>(nw);
+        case 2: return gmf_pick_nw<Tag, 2, MB, SPG>(nw);
+        case 4: return gmf_pick_nw<Tag, 4, MB, SPG>(nw);
+        default: return nullptr;
+    }
+}
+template <typename Tag>
+static gmf_fn gmf_pick(int v, int nw, int mb, int spg) {
+    if (spg == 4) return mb == 1 ? gmf_pick_v<Tag, 1, 4>(v, nw) : gmf_pick_v<Tag, 4, 4>(v, nw);
+    return mb == 1 ? gmf_pick_v<Tag, 1, 2>(v, nw) : gmf_pick_v<Tag, 4, 2>(v, nw);
+}
+
+bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
+    if (a.W_nbits != 4) return false;
+    if (a.M < 1 || a.M > 4) return false;
+    if (a.output_dtype != a.input_dtype) return false;  // typed epilogue / metadata
+    if (a.input_dtype != GEMLITE_DT_FP16 && a.input_dtype != GEMLITE_DT_BF16) return false;
+    const bool uses_s = a.W_group_mode >= 2 || a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
+    if (uses_s && a.meta_dtype != a.input_dtype) return false;
+    if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
+    if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
+    if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte x chunks
+    if (((uintptr_t)a.w_q % 16) != 0 || (a.stride_wk % 4) != 0) return false;      // vector weight loads
+    const int64_t gs = p.group_size;
+    int spg;
+    if (gs % 128 == 0) spg = 4;
+    else if (gs == 64) spg = 2;
+    else return false;
+    if (a.K % (32 * spg) != 0) return false;
+    const int64_t rows = a.K / 8;
+    if (rows * a.stride_wk * 4 + a.N * 4 >= (1ll << 32) || (int64_t)(a.K / gs) * p.stride_meta_g + a.N >= (1ll << 32)) return false;  // 32-bit offsets
+    const int mb = a.M == 1 ? 1 : 4;
+    const int ngroups = (int)(a.K / (32 * spg));
+    // tile width: the widest tile that gives >= 256 blocks (one per CU) — K is never split across blocks
+    int v = 0;
+    if (a.tuning[0] == 21 || a.tuning[0] == 22 || a.tuning[0] == 24) v = a.tuning[0] - 20;
+    else if (a.tuning[0] != 0) return false;  // the dot-product family's tile codes (2 / 3 / 4)
+    else {
+        for (int cand : {4, 2, 1})
+            if (a.N % (16 * cand) == 0 && a.N / (16 * cand) >= 256) { v = cand; break; }
+        if (!v) return false;  // narrower matrices: the K-splitting kernels
+    }
+    if (a.N % (16 * v) != 0) return false;
+    int nw = a.tuning[2] == 4 || a.tuning[2] == 8 || a.tuning[2] == 16 ? a.tuning[2] : 8;
+    if (a.tuning[2] != 0 && nw != a.tuning[2]) return false;
+    if (nw == 16 && v != 1) nw = 8;
+    while (nw > 4 && ngroups < nw) nw >>= 1;
+    const size_t lds = (size_t)nw * 2 * mb * 1024 + (size_t)nw * 64 * 4 * v * 4;
+    const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
+    gmf_fn fn = f16 ? gmf_pick<half_tag>(v, nw, mb, spg) : gmf_pick<bf16_tag>(v, nw, mb, spg);
+    if (!fn) return false;
+    p.splitk = 1;
+    p.rows_per_slice = (int)rows;
+    lp.fn = (const void*)fn;
+    static const char* names[2][3] = {{"gemv_mfma_kernel<tile16>", "gemv_mfma_kernel<tile32>", "gemv_mfma_kernel<tile64>"},
+                                      {"gemv_mfma_kernel<tile16,rows4>", "gemv_mfma_kernel<tile32,rows4>", "gemv_mfma_kernel<tile64,rows4>"}};
+    lp.name = names[mb == 1 ? 0 : 1][v == 1 ? 0 : (v == 2 ? 1 : 2)];
+    lp.grid = dim3((unsigned)(a.N / (16 * v)), 1, 1);
+    lp.block = dim3(64 * nw, 1, 1);
+    lp.lds_bytes = lds;
+    lp.slab_bytes = 0;
+    lp.ws_bytes = 0;
+    return true;
+}
+
+}  // namespace gl

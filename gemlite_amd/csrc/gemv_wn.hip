@@ -27,6 +27,10 @@
 //     fixed slice order (run-to-run deterministic), applies the epilogue and stores.
 #include "gl_common.h"
 
+#ifndef GL_GEMV_NT
+#define GL_GEMV_NT 1  // -DGL_GEMV_NT=0: default-policy weight loads (A/B builds)
+#endif
+
 namespace gl {
 
 // Unpack geometry.  One AND turns packed bits into two 16-bit floats q * 2^(NBITS*i) (i = position of the
@@ -129,7 +133,10 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
         }
         const uint32_t co = (uint32_t)(chunk * CSTRIDE) * sw4;  // uniform
 #pragma unroll
-        for (int i = 0; i < R; ++i) ck.w[i] = *(const u32x4*)(wb + (wo[i] + co));
+        for (int i = 0; i < R; ++i) {  // streamed once by one CU: non-temporal (guide row nt-weights; strip reads 23.6 -> 20.7 us at 16384^2 with R = 8)
+            const u32x4* src = (const u32x4*)(wb + (wo[i] + co));
+            ck.w[i] = GL_GEMV_NT ? __builtin_nontemporal_load(src) : *src;
+        }
         ck.s = *(const u32x2*)((const char*)sp + mo);
         ck.z = *(const u32x2*)((const char*)zp + mo);
     };
@@ -397,6 +404,193 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Decode kernel for the short-K 4-bit shapes (round 3): 16-column tiles, K not split, NW waves of one or two chunks each.
+// Same arithmetic as gemv_wn_kernel<Tag, 4, 1, R, 2, true, NW> (bit-identical partial sums per lane), rebuilt around what the
+// round-2 timeline of that kernel showed (profiles/r01_gemv_timeline.json: 1.7k of a block's 6.3k cycles go into ISSUING its
+// requests — the CU's address path moves 64 B per clock and the direct x loads asked for as many bytes as the weights — and
+// 0.9k into the 16 ds_bpermute + 16-thread tail after the last wave's data has arrived):
+//   * x: lane (g, c) loads only DWORD c of its packed row's 16 bytes (4 B per lane instead of 16: the four lanes of a quad own
+//     the four column groups of the SAME row) and the quad exchanges them with DPP quad_perm broadcasts — no LDS, no barrier;
+//   * weights: non-temporal loads (every byte is read once by one CU; guide row nt-weights: -18 % issue-to-landed);
+//   * reduction: the 4 row sub-groups of a 16-lane DPP row are summed with two row_ror adds per value (VALU, no LDS pipe), the
+//     4 DPP rows of every wave go to LDS as one 16-byte store per quad leader, and after the only barrier ONE wave sums the
+//     4 NW partials of the 16 outputs (16 conflict-free reads per lane + two cross-row shuffles) and stores.
+// Measured (profiles/r03/probe_gemv3_*.log, timeline_decode_*.log): 5.14-5.19 -> 4.80 us per launch in the bench's replayed
+// graph.  What the per-block timelines then showed: every variant tried afterwards — 8 waves x 4 rows with x / scales / zeros
+// fetched once per wave through LDS (half the memory instructions and half the VALU work per CU), the matrix-core kernel of
+// gemv_mfma.hip — leaves a block alive for the same 2.5 us: blocks start within 0.3 us, the first bytes come back ~0.9 us
+// later and the CU's 40 KB are complete ~1.3 us after that (6.8 TB/s chip-wide while it streams); the launch boundary in the
+// graph is another 1.5 us.  At this size the kernel is bound by HBM LATENCY + the launch boundary, not by issue or arithmetic.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_movf(float v) {
+    return __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(uint32_t, v)));
+}
+
+template <typename Tag, int R, int NW, bool NT>
+__global__ __launch_bounds__(NW * 64, 1) void gemv_w4_decode_kernel(const WnParams p) {
+    using TR = F16Traits<Tag>;
+    using WN = Window<Tag, 4>;
+    constexpr bool SUBN = WN::SUBN;
+    constexpr int WP = WN::WP;
+    constexpr int G = 16, CHUNK = G * R, TC = 16, CSTRIDE = NW * CHUNK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = (float*)smem;  // [NW * 4 DPP rows][16 columns]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 3, g = lane >> 2;
+    int tile = blockIdx.x;
+    {  // adjacent half-line tiles on one XCD (speed only; any mapping is correct)
+        const int nb = gridDim.x;
+        if ((nb & 15) == 0) {
+            const int xcd = tile & 7, idx = tile >> 3;
+            tile = (((idx >> 1) << 3) + xcd) * 2 + (idx & 1);
+        }
+    }
+    const int n0 = tile * TC + c * 4;
+    const int nch_total = p.rows_per_slice / CHUNK;          // K is not split: rows_per_slice = all packed rows
+    const int nchunks = (nch_total - wave + NW - 1) / NW;    // chunks wave, wave + NW, ...
+
+    const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
+    const uint16_t* sp = need_s ? (const uint16_t*)p.scales : (const uint16_t*)p.w;
+    const uint16_t* zp = need_z ? (const uint16_t*)p.zeros : (const uint16_t*)p.w;
+    const uint32_t mstride = (need_s || need_z) ? (uint32_t)p.stride_meta_g : 0u;
+    const uint32_t sw4 = (uint32_t)p.stride_wk * 4u;
+    const char* wb = (const char*)p.w;
+    const char* xb = (const char*)p.x;
+    const uint32_t row0 = (uint32_t)(wave * CHUNK + g * R);  // this lane's first row of chunk 0
+    const uint32_t wo0 = row0 * sw4 + (uint32_t)n0 * 4u;
+    const uint32_t xo0 = row0 * 16u + (uint32_t)c * 4u;      // 8 k x 2 bytes per packed row; dword c of it
+
+    struct Chunk { u32x4 w[R]; u32x2 s, z; uint32_t xq[R]; };
+    auto load_chunk = [&](Chunk& ck, int chunk) {
+        const uint32_t row = row0 + (uint32_t)(chunk * CSTRIDE);
+        const uint32_t mo = ((uint32_t)group_of((int)row * 8, p.gs_shift) * mstride + (uint32_t)n0) * 2u;
+        const uint32_t xo = xo0 + (uint32_t)(chunk * CSTRIDE) * 16u;
+#pragma unroll
+        for (int i = 0; i < R; ++i) ck.xq[i] = *(const uint32_t*)(xb + (xo + (uint32_t)i * 16u));
+        ck.s = *(const u32x2*)((const char*)sp + mo);
+        ck.z = *(const u32x2*)((const char*)zp + mo);
+        const uint32_t wo = wo0 + (uint32_t)(chunk * CSTRIDE) * sw4;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const u32x4* src = (const u32x4*)(wb + (wo + (uint32_t)i * sw4));
+            ck.w[i] = NT ? __builtin_nontemporal_load(src) : *src;
+        }
+    };
+
+    // opt-in timeline (tuning[3] & 4, needs a workspace): wave 0 of EVERY block stores the constant-rate global clock
+    // (s_memrealtime, 100 MHz) at four points, slot [block][i] — when blocks start, how long they wait for their data, when the
+    // last one leaves
+    const bool probe = (p.flags & 4) && p.counters && wave == 0 && lane == 0 && blockIdx.x < 1024;
+    unsigned long long* stamps = (unsigned long long*)(p.counters + MAX_SPLITK_COUNTERS) + blockIdx.x * 4;
+    auto stamp = [&](int i) {
+        if (probe && i < 4) stamps[i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    Chunk cur, nxt;  // the wave's first two chunks are requested up front (all there is at K <= 8192)
+    if (nchunks > 0) load_chunk(cur, 0);
+    if (nchunks > 1) load_chunk(nxt, 1);
+    stamp(1);
+
+    float tot[4] = {0.f, 0.f, 0.f, 0.f};
+    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
+    const float bz = (p.w_mode == 1 || p.w_mode == 3) ? -1.f : (p.w_mode == 4 ? 1.f : 0.f);
+    const bool b_times_s = p.w_mode == 3;
+    constexpr float QSCALE = SUBN ? 16777216.0f : 1.0f;
+    uint32_t wmask[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) wmask[i] = (15u * 0x00010001u) << (4 * i);
+
+    auto compute = [&](const Chunk& ck) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float xsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            // the quad's four dwords = the row's 8 x values (x0x1)(x2x3)(x4x5)(x6x7) -> pairs (x0,x4)(x1,x5)(x2,x6)(x3,x7)
+            const uint32_t d0 = dpp_mov<0x00>(ck.xq[i]), d1 = dpp_mov<0x55>(ck.xq[i]);
+            const uint32_t d2 = dpp_mov<0xAA>(ck.xq[i]), d3 = dpp_mov<0xFF>(ck.xq[i]);
+            uint32_t xr[4];
+            xr[0] = __builtin_amdgcn_perm(d2, d0, 0x05040100u);
+            xr[1] = __builtin_amdgcn_perm(d2, d0, 0x07060302u);
+            xr[2] = __builtin_amdgcn_perm(d3, d1, 0x05040100u);
+            xr[3] = __builtin_amdgcn_perm(d3, d1, 0x07060302u);
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) xsum = TR::dot2(xr[dd], TR::ONES2, xsum);
+            if constexpr (WP > 1) {  // fp16: odd pairs * 2^-4 (exact), the matching fields are read 4 bits up
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd)
+                    if (dd % WP) {
+                        const h2_t v = __builtin_bit_cast(h2_t, xr[dd]) * (h2_t){(_Float16)(1.0f / (1 << (4 * (dd % WP)))), (_Float16)(1.0f / (1 << (4 * (dd % WP))))};
+                        xr[dd] = __builtin_bit_cast(uint32_t, v);
+                    }
+            }
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int win = dd / WP, wi = dd % WP;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t h = (ck.w[i][j] >> (4 * WP * win)) & wmask[wi];
+                    if constexpr (!SUBN) h |= TR::MAGIC2;
+                    acc[j] = TR::dot2(h, xr[dd], acc[j]);
+                }
+            }
+        }
+        const uint32_t s0 = ck.s[0], s1 = ck.s[1], z0 = ck.z[0], z1 = ck.z[1];
+        float s[4] = {TR::to_float((uint16_t)(s0 & 0xFFFFu)), TR::to_float((uint16_t)(s0 >> 16)), TR::to_float((uint16_t)(s1 & 0xFFFFu)), TR::to_float((uint16_t)(s1 >> 16))};
+        float z[4] = {TR::to_float((uint16_t)(z0 & 0xFFFFu)), TR::to_float((uint16_t)(z0 >> 16)), TR::to_float((uint16_t)(z1 & 0xFFFFu)), TR::to_float((uint16_t)(z1 >> 16))};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!need_s) s[j] = 1.f;
+            if (!need_z) z[j] = scalar_zero;
+            const float a = s[j] * QSCALE;
+            const float b = bz * z[j] * (b_times_s ? s[j] : 1.f);
+            float v = acc[j];
+            if constexpr (!SUBN) v -= TR::OFF * xsum;
+            tot[j] += a * v + b * xsum;
+        }
+    };
+    // (a wave has 1 .. 3 chunks on the shapes this kernel takes); ONE copy of the arithmetic in the binary —
+    // the five inlined copies of the generic two-buffer pipeline needed > 128 registers at 16 waves per block
+#pragma unroll 1
+    for (int ch = 0; ch < nchunks; ++ch) {
+        compute(cur);
+        if (ch + 1 < nchunks) {
+            cur = nxt;
+            if (ch + 2 < nchunks) load_chunk(nxt, ch + 2);
+        }
+    }
+    stamp(2);
+
+    // ---- the 4 row sub-groups of every 16-lane DPP row (lane bits 2, 3): two rotations, every lane ends with the row's sum --
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = tot[j];
+        v += dpp_movf<0x124>(v);  // row_ror:4
+        v += dpp_movf<0x128>(v);  // row_ror:8
+        tot[j] = v;
+    }
+    if ((lane & 12) == 0) *(f32x4*)(red + ((wave * 4 + (lane >> 4)) * TC + c * 4)) = (f32x4){tot[0], tot[1], tot[2], tot[3]};
+    __syncthreads();
+    if (wave == 0) {
+        constexpr int PER = NW;  // partial rows per lane quarter: 4 NW rows over 4 quarters
+        const int o = lane & 15, part = lane >> 4;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) v += red[(part * PER + r) * TC + o];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) store_out_t<Tag>(p.epi, v, 0, (int64_t)tile * TC + o);
+    }
+    stamp(3);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side planning
 // ---------------------------------------------------------------------------------------------
 template <typename Tag, int NBITS, int MB, int R, int CQ, bool XD = false, int NW = 4>
@@ -404,7 +598,7 @@ static const void* inst() {
     // only the (bits, rows, tile) combinations the planner can pick are instantiated
     constexpr bool used = (CQ == 2 && R == 4 && (NBITS == 4 || NBITS == 2)) ||
                           (CQ == 3 && ((R == 4 && (NBITS == 4 || NBITS == 2)) || (R == 2 && NBITS == 2))) ||
-                          (CQ == 4 && ((R == 8 && NBITS == 8) || (R == 4 && (NBITS == 4 || NBITS == 2)) ||
+                          (CQ == 4 && ((R == 8 && (NBITS == 8 || NBITS == 4)) || (R == 4 && (NBITS == 4 || NBITS == 2)) ||
                                        (R == 2 && NBITS == 2) || (R == 1 && NBITS == 1)));
     if constexpr (used && (R * (32 / NBITS)) % 32 == 0 && NBITS <= F16Traits<Tag>::MAX_QBITS) {
         return (const void*)gemv_wn_kernel<Tag, NBITS, MB, R, CQ, XD, NW>;
@@ -493,7 +687,10 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
             const int rr = cand[ci];
             if (cq == 2 && rr != 4) continue;
             if (cq == 3 && rr != 4 && rr != 2) continue;
-            if (rr == 8 && cq == 4 && nbits != 8) continue;       // 8 rows in flight only where they are needed
+            // 8 rows per lane: 8-bit words always; 4-bit long K (>= 16 chunks per wave) — more bytes in flight per CU is what
+            // the strip reads gain from (scripts/ubench/graph_floor.hip); tuning[2] = 48 forces, 44 forbids
+            if (rr == 8 && cq == 4 && nbits != 8 &&
+                !(nbits == 4 && a.tuning[2] != 44 && a.tuning[2] != 8 && (a.tuning[2] == 48 || rows / (G * 8) >= 64))) continue;
             if (nbits == 1 && rr != 1) continue;                   // 16 x-dwords per packed row
             if ((rr * e) % 32 != 0 || rpg % rr != 0 || rows % (G * rr) != 0) continue;
             r = rr;
@@ -569,6 +766,25 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         p.splitk = splitk;
         p.rows_per_slice = rows / splitk;
         lp.fn = fn;
+        // round 3: the short-K decode kernel (quad-shared x dwords, non-temporal weights, DPP + one-wave reduction) takes the
+        // direct-x 16-column shapes; tuning[3] & 16 keeps the round-2 kernel (A/B runs), & 32 = default-policy weight loads
+        if (xd && cq == 2 && splitk == 1 && mb == 1 && nbits == 4 && !(a.tuning[3] & 16) && ((nw == 16 && r == 2) || (nw == 8 && r == 4))) {
+            const bool f16 = a.input_dtype == GEMLITE_DT_FP16, nt = !(a.tuning[3] & 32);
+            typedef void (*kfn)(const WnParams);
+            kfn k;
+            if (nw == 16) k = f16 ? (nt ? gemv_w4_decode_kernel<half_tag, 2, 16, true> : gemv_w4_decode_kernel<half_tag, 2, 16, false>)
+                                  : (nt ? gemv_w4_decode_kernel<bf16_tag, 2, 16, true> : gemv_w4_decode_kernel<bf16_tag, 2, 16, false>);
+            else k = f16 ? (nt ? gemv_w4_decode_kernel<half_tag, 4, 8, true> : gemv_w4_decode_kernel<half_tag, 4, 8, false>)
+                         : (nt ? gemv_w4_decode_kernel<bf16_tag, 4, 8, true> : gemv_w4_decode_kernel<bf16_tag, 4, 8, false>);
+            lp.fn = (const void*)k;
+            lp.name = nw == 16 ? "gemv_w4_decode_kernel<tile16,16w>" : "gemv_w4_decode_kernel<tile16,8w>";
+            lp.grid = dim3(tiles, 1, 1);
+            lp.block = dim3(64 * nw, 1, 1);
+            lp.lds_bytes = (size_t)nw * 4 * 16 * 4;
+            lp.slab_bytes = 0;
+            lp.ws_bytes = 0;
+            return true;
+        }
         lp.name = (xd && nw == 16) ? "gemv_wn_kernel<tile16,xdirect,16w>"
                   : (xd && nw == 8) ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect,8w>" : "gemv_wn_kernel<tile32,xdirect,8w>")
                   : xd ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect>" : (cq == 3 ? "gemv_wn_kernel<tile32,xdirect>" : "gemv_wn_kernel<tile64,xdirect>"))

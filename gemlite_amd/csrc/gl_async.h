@@ -40,6 +40,11 @@ __device__ __forceinline__ void req_lds16(srd_t rs, uint32_t lds_addr, uint32_t 
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory", "m0");
 }
+// the same reading around the (non-coherent) L1 / XCD L2: the consumer side of a write-through (sc1) hand-off
+__device__ __forceinline__ void req_lds16_sc1(srd_t rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen sc1 lds"
+                 : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory", "m0");
+}
 // the same with 4 bytes per lane: 64 lanes x 4 bytes to LDS [lds_addr, +256)
 __device__ __forceinline__ void req_lds4(srd_t rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds"

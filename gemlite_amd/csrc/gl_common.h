@@ -358,6 +358,8 @@ struct WnParams {
     int rows_per_slice;  // packed rows per K slice
     int64_t stride_xm, stride_xk, stride_wk, stride_meta_g;
     int64_t stride_wn_b, stride_meta_n;  // block-scaled K-contiguous weights (gemm_wn_mma.hip MXW): bytes between weight rows / scale columns
+    int combine;         // K-slice combine: 0 = slabs + arrival ticket (last block sums), 1 = reduce-scatter between co-resident
+                         // slices (gemm_wn_mma.hip; needs every block of the launch resident at once)
     int flags;           // experiment switches forwarded from tuning[3] (kernel-specific)
     int gs_shift;        // log2(group_size); 31 when one metadata row spans all of K; -1 (not a power of two)
                          // sends the problem to the coverage kernel — an integer division per metadata load costs
@@ -424,6 +426,10 @@ struct GenericParams {
 enum { MX_F16 = 1, MX_BF16 = 2, MX_FP8 = 3, MX_FP4 = 4 };
 
 // host-side launch description produced by the dispatcher
+// How many blocks of a one-block-per-CU kernel are resident at once on the current device (its CU count; 256 until a device
+// has been seen).  Kernels whose blocks WAIT for each other (reduce-scatter combine) are only planned within this limit.
+int resident_block_limit();
+
 struct LaunchPlan {
     const void* fn;
     const char* name;

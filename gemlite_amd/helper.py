@@ -255,8 +255,8 @@ class A8W8_int8_dynamic(A8W8_dynamic):
 
 
 class A8W8_fp8_dynamic(A8W8_dynamic):
-    def __init__(self, device="cuda:0", dtype=None):
-        super().__init__(device=device, dtype=dtype, fp8=default_fp8)
+    def __init__(self, device="cuda:0", dtype=None, fp8=default_fp8):  # reference: helper.py:491-496 (its AMD default is the
+        super().__init__(device=device, dtype=dtype, fp8=fp8)          # MI300X fnuz format; gfx950 MFMA is OCP e4m3fn)
 
 
 A8W8_INT8_dynamic, A8W8_FP8_dynamic = A8W8_int8_dynamic, A8W8_fp8_dynamic

@@ -13,14 +13,13 @@ lib = _hip.load()
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 CASES = {
-    # (tile, K slices, waves, flags)   flags: 16 = round-2 kernel, 32 = default-policy weight loads
-    "a16w4_4096_m1": [(0, 0, 0, 16), (0, 0, 0, 0), (0, 0, 0, 32), (2, 1, 8, 0), (2, 1, 8, 16)],
-    "a16w4_4096_m1_bf16": [(0, 0, 0, 16), (0, 0, 0, 0)],
-    "a16w4_11008_m1": [(0, 0, 0, 16), (0, 0, 0, 0)],
-    "a16w4_8192_m1": [(0, 0, 0, 0), (0, 0, 8, 0), (2, 1, 16, 2), (4, 2, 8, 0), (4, 2, 0, 0), (4, 1, 8, 0), (4, 1, 0, 0)],
-    "a16w4_16384_m1": [(0, 0, 0, 0), (0, 0, 8, 0)],
-    "a16w2_16384_m1": [(0, 0, 0, 0), (0, 0, 4, 0)],
+    # flags: 512 = dot-product family (& 16: round-2 kernel, & 64: first decode form; default: second form), else MFMA decode
+    "a16w4_4096_m1": [(0, 0, 0, 512 | 16), (0, 0, 0, 512 | 64), (0, 0, 0, 512), (0, 0, 16, 512), (0, 0, 0, 0)],
+    "a16w4_4096_m1_bf16": [(0, 0, 0, 512 | 16), (0, 0, 0, 512), (0, 0, 16, 512)],
+    "a16w4_11008_m1": [(0, 0, 0, 512 | 16), (0, 0, 0, 512), (0, 0, 16, 512), (0, 0, 0, 0)],
+    "a16w4_8192_m1": [(0, 0, 0, 512), (2, 1, 8, 512 | 2), (0, 0, 0, 0)],
 }
+bench.WORKLOADS.update({"a16w4_4096_m2": (4096, 4096, 4, 128, 2, "fp16", 32, "hbm"), "a16w4_4096_m4": (4096, 4096, 4, 128, 4, "fp16", 32, "hbm"), "a16w4_8192_m4": (8192, 8192, 4, 128, 4, "fp16", 8, "hbm")})
 only = [a for a in sys.argv[1:] if not a.startswith("-")]
 for name, tunings in CASES.items():
     if only and name not in only:

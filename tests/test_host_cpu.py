@@ -82,19 +82,25 @@ def test_struct_abi_and_validation():
 
 
 @pytest.mark.parametrize("kw,kernel", [
-    (dict(M=1), "gemv_wn_kernel<tile16,xdirect,16w>"),  # cfgA: 256 tiles of 16 columns, K not split, x from L2,
-    (dict(M=1, in_dt=2), "gemv_wn_kernel<tile16,xdirect,16w>"),  # 16 waves x one chunk each
+    (dict(M=1), "gemv_w4_decode_kernel<tile16,16w>"),  # cfgA: 256 tiles of 16 columns, K not split; round-3 decode kernel
+    (dict(M=1, in_dt=2), "gemv_w4_decode_kernel<tile16,16w>"),  # (quad-shared x dwords, nt weights, DPP + one-wave reduction)
+    (dict(M=1, tuning=(0, 0, 0, 16)), "gemv_wn_kernel<tile16,xdirect,16w>"),  # tuning[3] & 16: the round-2 kernel (A/B runs)
     (dict(M=1, tuning=(0, 0, 4, 0)), "gemv_wn_kernel<tile16,xdirect>"),
-    (dict(M=1, N=8192, K=8192), "gemv_wn_kernel<tile32>"),
+    (dict(M=1, N=8192, K=8192), "gemv_mfma_kernel<tile32>"),   # 32-column tiles: decode on the matrix core (9.9 vs 10.4 us)
+    (dict(M=1, N=8192, K=8192, tuning=(0, 0, 0, 512)), "gemv_wn_kernel<tile32>"),   # tuning[3] & 512: the dot-product family
+    (dict(M=1, tuning=(0, 0, 0, 1024)), "gemv_mfma_kernel<tile16>"),   # tuning[3] & 1024: the matrix-core kernel wherever it applies
     (dict(M=1, N=16384, K=16384), "gemv_wn_kernel<tile64>"),
-    (dict(M=2), "gemm_wn_direct_kernel<tile16>"),     # 2 <= M <= 32: registers-only MFMA kernel, K not split
-    (dict(M=4), "gemm_wn_direct_kernel<tile16>"),
+    (dict(M=2), "gemv_mfma_kernel<tile16,rows4>"),    # 2..4 rows: the decode MFMA kernel (x staged once per wave in LDS)
+    (dict(M=4), "gemv_mfma_kernel<tile16,rows4>"),
+    (dict(M=4, tuning=(0, 0, 0, 512)), "gemm_wn_direct_kernel<tile16>"),   # 2 <= M <= 32: registers-only MFMA kernel, K not split
+    (dict(M=5), "gemm_wn_direct_kernel<tile16>"),
     (dict(M=8), "gemm_wn_direct_kernel<tile32>"),     # >= 8 rows: 32-column tiles x split-K 2 (less x traffic)
     (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile32>"),
     (dict(M=16, N=16384, K=16384), "gemm_wn_direct_kernel<tile64>"),
     (dict(M=24, N=16384, K=16384), "gemm_w4_mma_kernel<32x128>"),   # 17..32 rows over K >= 8192: LDS-staged x wins
     (dict(M=8, tuning=(0, 0, 1, 0)), "gemm_wn_stream_kernel"),  # tuning[2] = 1: LDS-staged streaming kernel
-    (dict(M=4, gs=64), "gemm_wn_direct_kernel<tile16>"),   # group size 64: registers-only kernel up to 16 rows
+    (dict(M=4, gs=64), "gemv_mfma_kernel<tile16,rows4>"),
+    (dict(M=8, gs=64), "gemm_wn_direct_kernel<tile32>"),   # group size 64: registers-only kernel up to 16 rows
     (dict(M=24, gs=64), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32
     (dict(M=4, gs=32), "gemm_wn_stream_kernel"),
     (dict(M=48), "gemm_w4_mma_kernel<32x128>"),       # from 33 rows: the 8-wave MFMA kernel; 4096^2: 32-row tiles x 4 slices (15.8 us vs 16.4)
@@ -108,10 +114,11 @@ def test_struct_abi_and_validation():
     (dict(M=48, tuning=(2, 0, 0, 0)), "gemm_w4_tiled_kernel<128x128>"),  # tuning[0] = 2: the 4-wave kernel of round 1
     (dict(M=48, gs=32), "gemm_wn_stream_kernel"),     # group size 32: two groups per 64-k sub-block
     # K = 11008 / 8960 (Llama-2-7B down_proj, Qwen2.5-1.5B): specialised kernels at every M, never the coverage kernel
-    (dict(M=1, N=4096, K=11008), "gemv_wn_kernel<tile16,xdirect,16w>"),
-    (dict(M=1, N=4096, K=11008, gs=64), "gemv_wn_kernel<tile16,xdirect,16w>"),
+    (dict(M=1, N=4096, K=11008), "gemv_w4_decode_kernel<tile16,16w>"),
+    (dict(M=1, N=4096, K=11008, gs=64), "gemv_w4_decode_kernel<tile16,16w>"),
     (dict(M=1, N=1536, K=8960), "gemv_wn_kernel<tile32>"),
-    (dict(M=4, N=4096, K=11008), "gemm_w4_mma_kernel<32x128>"),
+    (dict(M=4, N=4096, K=11008), "gemv_mfma_kernel<tile16,rows4>"),
+    (dict(M=8, N=4096, K=11008), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=32, N=4096, K=11008, gs=64), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=16, N=1536, K=8960), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=64, N=4096, K=11008), "gemm_w4_mma_kernel<64x128>"),
@@ -351,7 +358,7 @@ def test_shipped_mi355x_table_is_well_formed_and_every_entry_selects_a_specialis
                 a = _args(M=M, N=N, K=K, tuning=tuple(t))
                 assert lib.gemlite_hip_query(C.byref(a)) == 0
                 name = lib.gemlite_hip_kernel_name(C.byref(a)).decode()
-                assert name.startswith(("gemv_wn", "gemm_wn_direct", "gemm_wn_stream", "gemm_w4_mma", "gemm_w4_tiled")), (key, t, M, name)
+                assert name.startswith(("gemv_wn", "gemv_w4_decode", "gemv_mfma", "gemm_wn_direct", "gemm_wn_stream", "gemm_w4_mma", "gemm_w4_tiled")), (key, t, M, name)
             n += 1
     assert n >= 10
 
@@ -526,7 +533,7 @@ def test_c_consumer_links_and_queries(tmp_path):
                     os.path.join(ROOT, "tests", "c_abi", "abi_smoke.c"), "-o", exe, "-L", libdir, "-lgemlite_hip",
                     f"-Wl,-rpath,{libdir}"], check=True, capture_output=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    assert "gemv_wn_kernel<tile16,xdirect,16w>" in out and "libgemlite_hip gfx950" in out
+    assert "gemv_w4_decode_kernel<tile16,16w>" in out and "libgemlite_hip gfx950" in out
 
 
 def _from_bits(arr, dtype_str):
