@@ -17,19 +17,20 @@ bench.WORKLOADS.update({
     "a16w4_4096_m512": (4096, 4096, 4, 128, 512, "bf16", 32, "mfma"), "a16w4_4096_m1024": (4096, 4096, 4, 128, 1024, "bf16", 32, "mfma"),
     "a16w4_11008x4096_m256": (11008, 4096, 4, 128, 256, "bf16", 12, "mfma"), "a16w4_4096x14336_m256": (4096, 14336, 4, 128, 256, "bf16", 10, "mfma"),
 })
-T = 128
+T, R = 128, 256   # tuning[3]: 128 = slab + ticket combine, 256 = weights through registers (round-2 path)
 CASES = {
-    "cfgA": ("a16w4_4096_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 2, 0), (0, 2, 2, T), (0, 2, 4, 0), (0, 4, 4, 0), (0, 4, 4, T), (0, 2, 8, 0),
-                                 (0, 4, 8, 0), (0, 4, 8, T), (0, 8, 8, 0), (0, 8, 8, T)]),
-    "cfgB": ("a16w4_8192_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 4, 0), (0, 2, 4, T), (0, 4, 4, 0), (0, 2, 8, 0), (0, 4, 8, 0), (0, 4, 8, T),
-                                 (0, 8, 8, 0)]),
-    "m64": ("a16w4_4096_m64", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 2, 0), (0, 4, 2, 0)]),
-    "m128": ("a16w4_4096_m128", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 2, 0), (0, 2, 4, 0), (0, 4, 4, 0)]),
-    "m512": ("a16w4_4096_m512", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 4, 0), (0, 2, 8, 0), (0, 4, 8, 0)]),
-    "m1024": ("a16w4_4096_m1024", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 8, 0)]),
+    "cfgA": ("a16w4_4096_m256", [(0, 0, 0, 0), (0, 0, 0, R), (0, 0, 0, R | T), (0, 2, 2, 0), (0, 2, 2, R), (0, 4, 4, 0), (0, 4, 4, R), (0, 2, 4, 0),
+                                 (0, 4, 8, 0), (0, 4, 8, R), (0, 8, 8, 0), (0, 4, 2, 0), (0, 4, 2, T)]),
+    "cfgB": ("a16w4_8192_m256", [(0, 0, 0, 0), (0, 0, 0, R), (0, 0, 0, R | T), (0, 2, 4, 0), (0, 2, 4, R), (0, 4, 4, 0), (0, 4, 8, 0), (0, 4, 8, R),
+                                 (0, 2, 8, 0), (0, 4, 2, 0), (0, 8, 2, 0)]),
+    "m64": ("a16w4_4096_m64", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 2, 0), (0, 4, 2, 0)]),
+    "m128": ("a16w4_4096_m128", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 2, 0), (0, 2, 4, 0), (0, 4, 4, 0)]),
+    "m512": ("a16w4_4096_m512", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 4, 0), (0, 2, 8, 0), (0, 4, 8, 0), (0, 1, 4, 0)]),
+    "m1024": ("a16w4_4096_m1024", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 8, 0), (0, 1, 8, 0)]),
     "w2": ("a16w2_16384_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 4, 8, 0)]),
-    "n11008": ("a16w4_11008x4096_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 8, 0), (0, 2, 4, 0)]),
-    "k14336": ("a16w4_4096x14336_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 8, 8, 0), (0, 4, 4, 0), (0, 4, 8, 0)]),
+    "n11008": ("a16w4_11008x4096_m256", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 8, 0), (0, 2, 4, 0)]),
+    "k14336": ("a16w4_4096x14336_m256", [(0, 0, 0, 0), (0, 0, 0, R), (0, 8, 8, 0), (0, 4, 4, 0), (0, 4, 8, 0)]),
+    "pre": ("a16w4_8192_m2048", [(0, 0, 0, 0), (0, 1, 8, 0), (0, 1, 8, R)]),
 }
 for key in (sys.argv[1:] or ["cfgA", "cfgB"]):
     name, tunings = CASES[key]
@@ -42,14 +43,14 @@ for key in (sys.argv[1:] or ["cfgA", "cfgB"]):
             torch.cuda.synchronize()
             kn = r.kernel_name()
             c_us, n, el = r.chained_us_per_launch(min_seconds=0.2)
-            tw = (t[0], t[1], t[2], t[3] & ~T)
+            tw = (t[0], t[1], t[2], 0)
             same = None
             if tw in outs:
                 same = bool(np.array_equal(outs[tw], y))
             outs.setdefault(tw, y)
-            print(json.dumps(dict(workload=name, tuning=t, kernel=kn, combine="ticket" if t[3] & T else "auto", chained_us=round(c_us, 3),
+            print(json.dumps(dict(workload=name, tuning=t, kernel=kn, combine="ticket" if t[3] & T else "auto", wpath="regs" if t[3] & R else "auto", chained_us=round(c_us, 3),
                                   tflops=round(r.flops / c_us / 1e6, 1), frac=round(r.flops / c_us / 1e6 / 2500, 4),
-                                  bitwise_equal_other_protocol=same, finite=bool(np.isfinite(y).all()))), flush=True)
+                                  bitwise_equal_first_of_same_tile=same, finite=bool(np.isfinite(y).all()))), flush=True)
             del r
         except Exception as e:
             print(json.dumps(dict(workload=name, tuning=t, error=f"{type(e).__name__}: {e}"[:200])), flush=True)

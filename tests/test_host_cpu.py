@@ -615,3 +615,14 @@ def test_launch_templates_are_immutable_and_keyed_by_everything_they_hold():
         assert core.lookup_tuning(-1, 1, a) == (2, 1, 16, 3)  # development bits of tuning[3] are not loadable from a table
     finally:
         core.GemLiteLinear.reset_config()
+
+
+def test_isa_guard_no_scratch_or_spills_in_the_built_kernels():
+    """scripts/isa_guard.py over the resource remarks of the build (gemlite_amd/csrc/build/*.remarks): only the known fallback
+    kernels may touch scratch memory."""
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, "gemlite_amd", "csrc", "build")):
+        pytest.skip("no build directory (prebuilt library only)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "isa_guard.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 new" in out.stdout
