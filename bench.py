@@ -8,18 +8,20 @@ Infinity Cache, so every layer's stream comes from HBM (cache-cold rotation, SUR
 The step is captured once as a hipGraph (the launch-bound regime the reference itself addresses with CUDA
 graphs, config.py:17) and replayed; `value` is whole-job algorithmic GB/s over all ranks.
 
-The JSON line carries BOTH halves of BASELINE.json's metric ("... at M=1 and M=256"), measured in this process:
-  roofline        — M=1 (the `value` workload): the dominant kernel's ALGORITHMIC bytes per launch / its device
-                    duration, measured live with HIP events attached to individual launches (hipExtLaunchKernel
-                    start/stop events through gemlite_hip_set_profile_events) over the same rotating layers;
-                    `gap_inclusive` = the timed region's wall time / launches (kernel + launch gaps);
-                    `event_clock_floor_us` = an EMPTY kernel timed the same way (~4 us on MI355X: the per-launch event
-                    clock, like rocprofv3's kernel duration, includes a fixed dispatch/completion cost).
-  roofline_m256   — cfgA (4096^2) and cfgB (8192^2, BASELINE configs[2]) at M=256 in bf16: TFLOP/s against the dense
-                    bf16 MFMA peak, same per-launch event clock, plus the chained (hipGraph) time per launch.
-  roofline_prefill_m2048 — 8192^2 at M=2048 (bf16), the large-M end of the MFMA kernel family, same clock.
+The JSON line carries BOTH halves of BASELINE.json's metric ("... at M=1 and M=256") and all five BASELINE configs, measured in this
+process.  Every block uses ONE clock: wall time of a replayed hipGraph that holds >= 32 back-to-back launches of the workload over
+rotating (cache-cold) layers, divided by the launches — the same quantity as the timed region of `value`, and the one that
+reproduces from `rocprofv3 --kernel-trace --stats` of this command (profiles/r03/official/: the kernel's average duration agrees
+within a few percent; the graph's dependent-launch boundary, ~1.5 us, is inside it).  Per-launch HIP events are reported as a
+secondary figure only (`event_us`; an EMPTY kernel reads ~4 us through them: `event_clock_floor_us`).
+  roofline        — M=1 (the `value` workload): algorithmic bytes per launch / time per launch of the TIMED REGION.
+  roofline_m256   — cfgA (4096^2) and cfgB (8192^2, BASELINE configs[2]) at M=256 in bf16: TFLOP/s against the dense bf16 MFMA peak;
+                    `mfma_util` = matrix-pipe busy share from the committed SQ counter passes (profiles/mfma_util.json), or null.
+  roofline_cfg4   — BASELINE configs[3]: A8W8 int8 4096^2 at M = 1 / 16 / 256 (x pre-quantised outside the timed matmul).
+  roofline_cfg5   — BASELINE configs[4]: A16W2 g128 and FP8 x FP8 16384^2 at M = 1 / 256.
+  roofline_prefill_m2048 — 8192^2 at M=2048 (bf16), the large-M end of the MFMA kernel family.
   roofline_trend_m1 — the same GEMV family at 8192^2 and 16384^2 (fraction of HBM peak grows with size).
-  sustained       — >= 1 s of back-to-back replays of the headline step (an independent observer can see the GPU busy).
+  sustained       — >= 6 s of back-to-back replays of the headline step (an outside sampler sees the GPU busy).
   cpu_baseline    — oracle/torch_cpu_path.py (a port of the reference's test oracle: unpack -> dequant -> matmul in
                     torch CPU ops; thread count swept, best reported, plus the matmul-only variant), rank 0, N=1 only.
 
@@ -310,35 +312,41 @@ class Runner:
                 a.tuning[i] = int(t[i])
         return self.lib.gemlite_hip_kernel_name(ctypes.byref(a)).decode()
 
-    def roofline(self, samples, chained=True):
-        k_us = self.kernel_us(samples)
-        out = {"workload": self.name, "bound": self.bound, "kernel": self.kernel_name(),
-               "kernel_us": None if k_us != k_us else round(k_us, 3)}
-        if chained:
-            c_us, _, _ = self.chained_us_per_launch()
-            out["us_per_launch_chained"] = round(c_us, 3)
-        t = k_us if k_us == k_us else out.get("us_per_launch_chained", float("nan"))
+    def roofline(self, samples=0, min_seconds=0.25):
+        """One clock for every block: graph-replayed wall time per launch (>= 32 launches per replay).  `samples` > 0 adds the
+        per-launch HIP-event figure as `event_us` (secondary)."""
+        c_us, launches, el = self.chained_us_per_launch(min_seconds=min_seconds)
+        out = {"workload": self.name, "bound": self.bound, "kernel": self.kernel_name(), "kernel_us": round(c_us, 3),
+               "clock": f"hipGraph replay, {launches} launches in {el:.2f} s"}
+        if samples > 0:
+            try:
+                e_us = self.kernel_us(samples)
+                out["event_us"] = None if e_us != e_us else round(e_us, 3)
+            except Exception:
+                out["event_us"] = None
         if self.bound == "hbm":
             peak, unit, work = HBM_PEAK_GBS, "GB/s", self.bytes / 1e9
         else:
             peak = {"int8": INT8_MFMA_PEAK_TOPS, "fp8": INT8_MFMA_PEAK_TOPS, "fp8w8": INT8_MFMA_PEAK_TOPS, "mxa8": MXFP8_MFMA_PEAK_TFLOPS,
                     "mxa4": MXFP4_MFMA_PEAK_TFLOPS}.get(self.dt, MFMA_PEAK_TFLOPS)
             unit, work = "TFLOP/s", self.flops / 1e12
-        ach = work / (t * 1e-6)
+        ach = work / (c_us * 1e-6)
         out.update({"achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "algorithmic_bytes_per_launch": self.bytes, "flops_per_launch": self.flops})
-        if chained:
-            out["gap_inclusive"] = round(work / (out["us_per_launch_chained"] * 1e-6), 3)
         return out
+
+
+def _committed(fname, name):
+    """Per-workload figure from a committed profile summary under profiles/ (PMC passes are separate runs), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", fname))).get(name)
+    except Exception:
+        return None
 
 
 def _traffic(name):
     """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), or None."""
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        return json.load(open(tpath)).get(name)
-    except Exception:
-        return None
+    return _committed("pmc_traffic.json", name)
 
 
 def event_clock_floor_us(lib, stream, samples=64):
@@ -367,6 +375,7 @@ def main():
     ap.add_argument("--single", action="store_true", help="only the named workload (no M=256 / trend / sustained blocks)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="profiler runs: short blocks (0.03 s each), sustained leg 0.2 s")
     ap.add_argument("--kernel-samples", type=int, default=256, help="launches timed individually for roofline")
     ap.add_argument("--tuning", default="", help="development: comma-separated tuning[] override, e.g. 4,8")
     ap.add_argument("--matmul-type", default="", help="development: force a kernel family (forward_manual)")
@@ -396,26 +405,29 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     gap_us = elapsed / launches * 1e6
 
-    roof = {"kernel_us": None}
-    try:
-        roof = main_run.roofline(min(args.kernel_samples, 1024), chained=False)
-        roof["event_clock_floor_us"] = round(event_clock_floor_us(lib, main_run.stream), 3)
-    except Exception as e:  # keep the bench line even if the event path is unavailable
-        print(f"[bench] per-kernel event timing unavailable: {e}", file=sys.stderr)
     work = main_run.bytes / 1e9 if bound == "hbm" else main_run.flops / 1e12
     unit = "GB/s" if bound == "hbm" else "TFLOP/s"
     peak = HBM_PEAK_GBS if bound == "hbm" else {"int8": INT8_MFMA_PEAK_TOPS, "fp8": INT8_MFMA_PEAK_TOPS, "fp8w8": INT8_MFMA_PEAK_TOPS, "mxa8": MXFP8_MFMA_PEAK_TFLOPS,
                                                   "mxa4": MXFP4_MFMA_PEAK_TFLOPS}.get(dt, MFMA_PEAK_TFLOPS)
     value = whole_job_rate(layers * work, args.steps, world, elapsed)
-    if roof.get("kernel_us") is None:  # fall back to the gap-inclusive figure
-        roof.update({"bound": bound, "achieved": round(work / (gap_us * 1e-6), 3), "peak": peak, "unit": unit,
-                     "frac": round(work / (gap_us * 1e-6) / peak, 4)})
-    roof["gap_inclusive"] = round(work / (gap_us * 1e-6), 3)
-    roof["us_per_launch_in_timed_region"] = round(gap_us, 3)
+    # the headline roofline IS the timed region: algorithmic bytes (flops) per launch / (elapsed / launches)
+    ach = work / (gap_us * 1e-6)
+    roof = {"bound": bound, "kernel": main_run.kernel_name(), "kernel_us": round(gap_us, 3),
+            "clock": f"the timed region: {launches} launches in {elapsed * 1e3:.3f} ms of hipGraph replays" if main_run.graph is not None else "the timed region (eager launches)",
+            "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+            "algorithmic_bytes_per_launch": main_run.bytes, "flops_per_launch": main_run.flops}
+    if args.kernel_samples > 0:
+        try:  # secondary: per-launch HIP events (their own floor printed next to them)
+            e_us = main_run.kernel_us(min(args.kernel_samples, 1024))
+            roof["event_us"] = None if e_us != e_us else round(e_us, 3)
+            roof["event_clock_floor_us"] = round(event_clock_floor_us(lib, main_run.stream), 3)
+        except Exception as e:
+            print(f"[bench] per-kernel event timing unavailable: {e}", file=sys.stderr)
     if bound == "hbm":
         roof["frac_vs_measured_copy_6290"] = round(roof["achieved"] / 6290.0, 4)
+    else:
+        roof["mfma_util"] = _committed("mfma_util.json", name)
     roof["traffic"] = _traffic(name)
-    roof.pop("workload", None)
 
     metric = ("HBM GB/s (algorithmic bytes) vs roofline at M=1 [value], TFLOP/s vs bf16 MFMA roofline at M=256 [roofline_m256]; "
               "A16W4 gs=128 4096x4096" if name == "a16w4_4096_m1" else f"{unit} {name}")
@@ -437,32 +449,30 @@ def main():
             h_us, e_us = main_run.eager_us_per_call()
             line["eager"] = {"host_us_per_call": round(h_us, 3), "us_per_call_incl_device": round(e_us, 3), "calls": 2000,
                              "what": "layer(x) eager, no graph: Python + ctypes + gemlite_hip_forward per call"}
-            # >= 1 s of back-to-back replays of the headline step
-            us, steps, el = main_run.chained_us_per_launch(min_seconds=1.2, min_steps=50)
-            line["sustained"] = {"seconds": round(el, 3), "replays": steps, "value": round(main_run.bytes / 1e9 / (us * 1e-6), 3),
+            # >= 6 s of back-to-back replays of the headline step
+            us, nl, el = main_run.chained_us_per_launch(min_seconds=0.2 if args.quick else 6.0, min_steps=50)
+            line["sustained"] = {"seconds": round(el, 3), "launches": nl, "value": round(main_run.bytes / 1e9 / (us * 1e-6), 3),
                                  "unit": "GB/s", "us_per_launch": round(us, 3)}
-            # the M=256 half of the headline metric, same process, bf16
-            m256 = {}
-            for key, wname, nl in (("cfgA_4096", "a16w4_4096_m256", 32), ("cfgB_8192", "a16w4_8192_m256", 8)):
+
+            def block(wname, nl=None, samples=0):
                 r = Runner(wname, device, lib, layers=nl, use_graph=not args.no_graph)
-                m256[key] = r.roofline(min(args.kernel_samples, 128))
-                m256[key]["traffic"] = _traffic(wname)
+                out = r.roofline(0 if args.quick else samples, min_seconds=0.03 if args.quick else 0.25)
+                out["traffic"] = _traffic(wname)
+                if out["bound"] == "mfma":
+                    out["mfma_util"] = _committed("mfma_util.json", wname)
                 del r
                 torch.cuda.empty_cache()
-            line["roofline_m256"] = m256
+                return out
+            # the M=256 half of the headline metric, same process, bf16
+            line["roofline_m256"] = {"cfgA_4096": block("a16w4_4096_m256", 32, samples=64), "cfgB_8192": block("a16w4_8192_m256", 8, samples=32)}
+            # BASELINE configs[3]: A8W8 int8 channel-wise 4096^2, M in {1, 16, 256}
+            line["roofline_cfg4"] = {f"a8w8_int8_4096_m{m}": block(f"a8w8_4096_m{m}") for m in (1, 16, 256)}
+            # BASELINE configs[4]: A16W2 g128 and FP8 x FP8, 16384^2, M in {1, 256}
+            line["roofline_cfg5"] = {"a16w2_16384_m1": block("a16w2_16384_m1"), "a16w2_16384_m256": block("a16w2_16384_m256"),
+                                     "fp8_16384_m1": block("fp8_16384_m1"), "fp8_16384_m256": block("fp8_16384_m256")}
             # the large-M end of the same kernel family (north star: "tiled GEMM for large-M prefill"), same clock
-            r = Runner("a16w4_8192_m2048", device, lib, layers=4, use_graph=not args.no_graph)
-            line["roofline_prefill_m2048"] = r.roofline(min(args.kernel_samples, 32))
-            line["roofline_prefill_m2048"]["traffic"] = _traffic("a16w4_8192_m2048")
-            del r
-            torch.cuda.empty_cache()
-            trend = {}
-            for key, wname in (("8192", "a16w4_8192_m1"), ("16384", "a16w4_16384_m1")):
-                r = Runner(wname, device, lib, use_graph=not args.no_graph)
-                trend[key] = r.roofline(min(args.kernel_samples, 64))
-                del r
-                torch.cuda.empty_cache()
-            line["roofline_trend_m1"] = trend
+            line["roofline_prefill_m2048"] = block("a16w4_8192_m2048", 4)
+            line["roofline_trend_m1"] = {"8192": block("a16w4_8192_m1"), "16384": block("a16w4_16384_m1")}
         except Exception as e:
             print(f"[bench] extra blocks failed: {type(e).__name__}: {e}", file=sys.stderr)
 

@@ -61,8 +61,9 @@ def pack_weights_over_cols(W_q: torch.Tensor, W_nbits: int, packing_bitwidth: in
         assert K % e == 0
         src = W_q if (W_q.dtype == torch.uint8 and W_q.stride(1) == 1) else W_q.to(torch.uint8).contiguous()
         out = torch.empty((K // e, N), dtype=PACKING_BITWIDTH_TO_TORCH_DTYPE[packing_bitwidth], device=W_q.device)
-        rc = _hip.load().gemlite_hip_pack_over_cols(src.data_ptr(), out.data_ptr(), N, K, src.stride(0), W_nbits,
-                                                    packing_bitwidth, _hip.current_stream_handle(W_q.device))
+        with _hip.on_device(W_q.device):
+            rc = _hip.load().gemlite_hip_pack_over_cols(src.data_ptr(), out.data_ptr(), N, K, src.stride(0), W_nbits,
+                                                        packing_bitwidth, _hip.current_stream_handle(W_q.device))
         _hip.raise_for_status(rc, "pack_over_cols")
         return (out if transpose else out.t().contiguous()), e
     packed = _pack_lastdim_cpu(W_q, W_nbits, packing_bitwidth)
@@ -78,8 +79,9 @@ def unpack_over_cols(W_q_packed: torch.Tensor, W_nbits: int, num_output_cols: in
         N, K = W_q_packed.shape[0], num_output_cols
         src = W_q_packed.t().contiguous()  # the kernel reads the [K/e, N] layout
         out = torch.empty((N, K), dtype=torch.uint8, device=W_q_packed.device)
-        rc = _hip.load().gemlite_hip_unpack_over_cols(src.data_ptr(), out.data_ptr(), N, K, W_nbits, pb,
-                                                      _hip.current_stream_handle(W_q_packed.device))
+        with _hip.on_device(W_q_packed.device):
+            rc = _hip.load().gemlite_hip_unpack_over_cols(src.data_ptr(), out.data_ptr(), N, K, W_nbits, pb,
+                                                          _hip.current_stream_handle(W_q_packed.device))
         _hip.raise_for_status(rc, "unpack_over_cols")
         return out.to(dtype)
     return _unpack_lastdim_cpu(W_q_packed, W_nbits, pb).to(dtype)

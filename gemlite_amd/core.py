@@ -177,8 +177,8 @@ def _static_args(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> _hip.
     t = _TEMPLATES.get(key)
     if t is None:
         t = _build_template(W_q, scales, zeros, meta_args)
-        if len(_TEMPLATES) > 8192:
-            _TEMPLATES.clear()
+        while len(_TEMPLATES) >= 8192:  # oldest entry out (dicts keep insertion order), not the whole table
+            _TEMPLATES.pop(next(iter(_TEMPLATES)), None)
         _TEMPLATES[key] = t
     return _hip.ForwardArgs.from_buffer_copy(t)
 
@@ -252,11 +252,7 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
     if tuning is not None:
         for i in range(4):
             a.tuning[i] = int(tuning[i])
-    dev_idx = x.device.index
-    guard = torch.cuda.device(dev_idx) if dev_idx != torch.cuda.current_device() else None
-    if guard is not None:
-        guard.__enter__()  # launches go to the tensor's device, not the thread's current one
-    try:
+    with _hip.on_device(x.device):  # launches go to the tensor's device, not the thread's current one
         stream = _hip.current_stream_handle(x.device)
         ws = _hip.workspace(x.device, stream, 0)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -266,9 +262,6 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
             ws = _hip.workspace(x.device, stream, need)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             rc = lib.gemlite_hip_forward(_hip.C.byref(a), stream)
-    finally:
-        if guard is not None:
-            guard.__exit__(None, None, None)
     if rc != 0:
         _hip.raise_for_status(rc, "gemlite_hip_forward")
     # a shape that only the coverage kernel takes is correct but orders of magnitude slower: say so, once per shape
@@ -276,10 +269,11 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
     if wkey not in _COVERAGE_CHECKED:
         _COVERAGE_CHECKED.add(wkey)
         name = lib.gemlite_hip_kernel_name(_hip.C.byref(a))
-        if name and name.startswith(b"generic_matmul_kernel"):
+        if name and name.startswith((b"generic_matmul_kernel", b"mx_generic_kernel")):
             logger.warning(f"gemlite_amd: no specialised MI355X kernel for N={a.N} K={a.K} W_nbits={a.W_nbits} "
                            f"group_size={a.group_size} input_dtype={DType(a.input_dtype).name} M={M}: running on the coverage "
-                           "kernel (correct, slow).  Group sizes that are a power of two and N % 64 == 0 avoid it.")
+                           "kernel (correct, slow).  Group sizes that are a power of two and N % 64 == 0 avoid it; block-scaled "
+                           "layers need a K-contiguous W_q (as pack() lays it out) and N % 128 == 0, NVFP4 has no fast path yet.")
     return out
 
 
@@ -319,7 +313,15 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
     x2 = x if x.dim() == 2 else x.view(-1, x.shape[-1])
     # matmul_type < 0 (auto) is resolved inside the library: the HIP kernel families have their own M
     # thresholds (GEMV <= 4 rows, streaming MFMA above), unlike the Triton ones of get_matmul_type()
-    out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type)
+    try:
+        out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type)
+    except (NotImplementedError, ValueError):
+        # the fused-quantisation kernel has stricter preconditions than the two-launch path (K % 16, 16-byte aligned views,
+        # K <= 65536: api.hip): a layer that runs at M = 2 must not fail at M = 1 — quantise separately and launch again
+        if not (bool(meta_args[0]) and scales_x is None and DType(in_code) in FP8_INT8_DTYPES and x2.dtype in (torch.float16, torch.bfloat16)):
+            raise
+        xq, scales_x = scale_activations_per_token(x2, w_dtype=DTYPE_TO_TORCH[in_code])
+        out = _hip_matmul(xq, W_q, scales, zeros, scales_x, meta_args, matmul_type)
     if len(out_shape) != 2:
         out = out.view(out_shape)
     if bias is not None:

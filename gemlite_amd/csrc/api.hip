@@ -334,7 +334,8 @@ coverage:
     const int esz = dtype_size(a.w_dtype);
     if (!packed && a.W_group_mode == 0 && a.stride_wk == 1 && a.stride_xk == 1 && a.w_dtype == a.input_dtype &&
         esz > 0 && (a.K % (16 / esz) == 0) && ((a.stride_wn * esz) % 16 == 0) && ((a.stride_xm * esz) % 16 == 0) &&
-        (((uintptr_t)a.w_q | (uintptr_t)a.x) % 16 == 0)) {
+        (((uintptr_t)a.w_q | (uintptr_t)a.x) % 16 == 0) &&
+        !(a.M > 1 && (a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5))) {  // fp8 rows > 1: MFMA kernels / coverage
         const int mb = a.M == 1 ? 1 : 4;
         r.kind = K_KMAJOR;
         r.lp.fn = kmajor_kernel_fn(mb);

@@ -687,10 +687,10 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
             const int rr = cand[ci];
             if (cq == 2 && rr != 4) continue;
             if (cq == 3 && rr != 4 && rr != 2) continue;
-            // 8 rows per lane: 8-bit words always; 4-bit long K (>= 16 chunks per wave) — more bytes in flight per CU is what
-            // the strip reads gain from (scripts/ubench/graph_floor.hip); tuning[2] = 48 forces, 44 forbids
-            if (rr == 8 && cq == 4 && nbits != 8 &&
-                !(nbits == 4 && a.tuning[2] != 44 && a.tuning[2] != 8 && (a.tuning[2] == 48 || rows / (G * 8) >= 64))) continue;
+            // 8 rows per lane: 8-bit words.  4-bit only on request (tuning[2] = 48): a pure strip read gains from the deeper
+            // queue (scripts/ubench/graph_floor.hip: 23.6 -> 20.8 us at 16384^2), the real kernel LOSES (27.4 vs 23.8 us with
+            // 4 rows + non-temporal loads: 185 registers, one wave per SIMD — profiles/r03/probe_gemv3_v3)
+            if (rr == 8 && cq == 4 && nbits != 8 && !(nbits == 4 && a.tuning[2] == 48)) continue;
             if (nbits == 1 && rr != 1) continue;                   // 16 x-dwords per packed row
             if ((rr * e) % 32 != 0 || rpg % rr != 0 || rows % (G * rr) != 0) continue;
             r = rr;

@@ -487,6 +487,10 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
     from ._hip import GemliteHipError
     from .bench_utils import kernel_device_us
 
+    if _core.is_mx_dtype(layer.input_dtype.value):
+        # the block-scaled kernels have no tuning candidates yet (their planner takes tuning[1] / [2] only), and their entries live
+        # under the `mx` config families: say so instead of filing a result where lookup_tuning() never looks
+        raise NotImplementedError("autotune_layer: block-scaled (MXFP / NVFP4) layers are not tunable yet")
     dev = layer.W_q.device
     in_t = _core.DTYPE_TO_TORCH[layer.input_dtype.value if not layer.scaled_activations else layer.output_dtype.value]
     meta = layer.get_meta_args()

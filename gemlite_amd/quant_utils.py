@@ -39,9 +39,10 @@ def scale_activations_per_token(tensor: torch.Tensor, w_dtype: torch.dtype, fp32
     M, K = x2.shape
     y = torch.empty((M, K), dtype=w_dtype, device=tensor.device)
     scales = torch.empty((M, 1), dtype=torch.float32, device=tensor.device)
-    rc = _hip.load().gemlite_hip_scale_activations_per_token(
-        x2.data_ptr(), y.data_ptr(), scales.data_ptr(), M, K, x2.stride(0), TORCH_TO_DTYPE[x2.dtype].value,
-        TORCH_TO_DTYPE[w_dtype].value, _hip.current_stream_handle(tensor.device))
+    with _hip.on_device(tensor.device):
+        rc = _hip.load().gemlite_hip_scale_activations_per_token(
+            x2.data_ptr(), y.data_ptr(), scales.data_ptr(), M, K, x2.stride(0), TORCH_TO_DTYPE[x2.dtype].value,
+            TORCH_TO_DTYPE[w_dtype].value, _hip.current_stream_handle(tensor.device))
     _hip.raise_for_status(rc, "scale_activations_per_token")
     if not fp32_scale:
         scales = scales.to(tensor.dtype)
@@ -180,8 +181,9 @@ def _scale_activations_mx(tensor: torch.Tensor, mode: str):
         y = torch.empty((M, K // 2), dtype=torch.uint8, device=tensor.device)
         fn = lib.gemlite_hip_scale_activations_mxfp4 if mode == "mxfp4" else lib.gemlite_hip_scale_activations_nvfp4
     scales = torch.empty((m_pad, K // group), dtype=torch.uint8, device=tensor.device)
-    rc = fn(x2.data_ptr(), y.data_ptr(), scales.data_ptr(), M, K, x2.stride(0), TORCH_TO_DTYPE[x2.dtype].value,
-            _hip.current_stream_handle(tensor.device))
+    with _hip.on_device(tensor.device):
+        rc = fn(x2.data_ptr(), y.data_ptr(), scales.data_ptr(), M, K, x2.stride(0), TORCH_TO_DTYPE[x2.dtype].value,
+                _hip.current_stream_handle(tensor.device))
     _hip.raise_for_status(rc, "scale_activations_" + mode)
     if mode == "nvfp4":
         scales = scales.view(torch.float8_e4m3fn)

@@ -3,6 +3,7 @@ outputs, the C-ABI library (loads, exports every symbol of include/gemlite_hip.h
 selection, and loud failure without a GPU.  No compute is launched here."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np

@@ -58,7 +58,10 @@ def test_hip_matches_reference_outputs_from_the_mi355x(name):
         assert np.array_equal(got, ref), (name, rel)
     else:
         assert rel < bound, (name, rel, bound)
-        assert np.abs(got - ref).max() / scale < 80 * max(bound, 1e-4), name
+        # a single output may differ by one rounding step of the output type where the two summation orders straddle a rounding
+        # boundary: 2^-8 (bf16) / 2^-11 (fp16) of the LARGEST output, plus the reference's own accumulation noise for that path
+        ulp = 2.0 ** -7 if dt == "torch.bfloat16" else 2.0 ** -10
+        assert np.abs(got - ref).max() <= ulp * np.abs(ref).max() + 80 * max(bound, 1e-4) * scale, name
 
 
 def test_fixture_is_the_reference_run_recorded_in_profiles():
