@@ -228,17 +228,21 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
             plan_gemv_a8wn(a, p, lp)) {
             r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
         }
-        // Decode on the matrix core (gemv_mfma.hip, round 3), where it measured faster than the dot-product family
-        // (profiles/r03/probe_gemv3_*.log): M = 1 on 32-column tiles (8192 <= N < 16384: 9.9 vs 10.4 us at 8192^2; the 16-column
-        // shapes keep the dot-product decode kernel, 4.8 vs 5.8 us, and 16384^2 its 8-rows-per-lane form, 23.9 vs 25.2), and 2..4
-        // rows (6.4 vs 7.3 us at 4096^2 against gemm_wn_direct).  tuning[3] & 512 = never, & 1024 = wherever it applies (A/B runs).
+        // Decode on the matrix core (gemv_mfma.hip, round 3) where it measured faster than the dot-product family
+        // (profiles/r03/probe_gemv3_*.log, us per launch in a replayed graph):
+        //   4-bit, M = 1: 32-column tiles over a long K (8192^2: 9.9 vs 10.4).  Not the 16-column shapes (4096^2: 5.8 vs 4.8 for the
+        //     dot-product decode kernel), not 64-column tiles (16384^2: 25.3 vs 23.7), not 32-column tiles over K = 4096 (9.3 vs 8.9);
+        //   2-bit, M = 1: 16- and 32-column tiles (4096^2 4.4 vs 4.9, 8192^2 7.4 vs 8.6, 11008 x 4096 6.1 vs 8.2; 16384^2 18.0 vs 17.4: no);
+        //   4-bit, 2..4 rows: always (4096^2: 6.4 vs 7.3 for gemm_wn_direct, 8192^2 M = 4: 10.7 vs 11.2).
+        // tuning[3] & 512 = never, & 1024 = wherever it applies (A/B runs).
         if (x16 && !(a.tuning[3] & 512) && a.tuning[1] == 0 &&
             ((want_gemv && a.M == 1 && mt != GEMLITE_MATMUL_GEMV_SPLITK) || (a.M >= 2 && a.M <= 4 && mt == GEMLITE_MATMUL_AUTO))) {
             WnParams pm = p;
             LaunchPlan lm{};
-            if (plan_gemv_mfma(a, pm, lm) && ((a.tuning[3] & 1024) || a.M >= 2 || a.tuning[0] != 0 || lm.block.x == 0 ||
-                                              (a.N / lm.grid.x) == 32)) {
-                r.kind = K_GEMV_WN; r.wn = pm; r.lp = lm; return;
+            if (plan_gemv_mfma(a, pm, lm)) {
+                const int cols = (int)(a.N / lm.grid.x);
+                const bool wins = a.M >= 2 || (a.W_nbits == 4 ? (cols == 32 && a.K >= 8192) : cols <= 32);
+                if ((a.tuning[3] & 1024) || a.tuning[0] != 0 || wins) { r.kind = K_GEMV_WN; r.wn = pm; r.lp = lm; return; }
             }
         }
         if (want_gemv && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
     using MT = typename Vec<V>::M;
     constexpr bool SUBN = UP::SUBN;
     constexpr int E = 32 / NBITS, NF = E / 8;  // NF k-steps per packed word
-    static_assert(NBITS == 4, "x staging below: one 16-byte chunk per packed row (4-bit words)");
+    static_assert(NBITS == 4 || NBITS == 2, "x staging below: 4-bit words (one chunk per packed row) or 2-bit words (two)");
     constexpr int TN = 16 * V, NT = NW * 64;
     constexpr int RSTEPS = SPG / NF;           // wave loads (4 packed rows each) per group unit
     constexpr int CPG = 4 * SPG;               // x chunks (8 k) per group unit
@@ -174,7 +174,11 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
     // x chunk of lane L in a batch starting at the wave's unit index i0: unit gi = L / CPG of the batch, chunk L % CPG of it;
     // unit u = wave + NW (i0 + gi) covers chunks [u CPG, (u + 1) CPG) of the row
     const int xgi = lane / CPG, xwi = lane % CPG;
-    const uint32_t xvoff = lane < CPB ? (uint32_t)(((wave + NW * xgi) * CPG + xwi) * 16) : 0x80000000u;  // (lanes past CPB: no request)
+    // 4-bit: chunk xwi of the unit = the 8 k of packed row xwi, 16 contiguous bytes.  2-bit: chunk (k-step ks = xwi >> 2, quarter kq)
+    // = fragment f = ks & 1 of packed row (ks >> 1) 4 + kq (16 k): its k are {4 f .. 4 f + 3} and {8 + 4 f .. 8 + 4 f + 3} — two 8-byte pieces
+    const uint32_t xvoff = lane >= CPB ? 0x80000000u  // (lanes past CPB: no request)
+                           : (NBITS == 4 ? (uint32_t)(((wave + NW * xgi) * CPG + xwi) * 16)
+                                         : (uint32_t)((wave + NW * xgi) * CPG * 16 + (((xwi >> 3) * 4 + (xwi & 3)) * 32) + ((xwi >> 2) & 1) * 8));
     const int my_units = (ngroups - wave + NW - 1) / NW;
 
     struct Batch { u32x4 x[MB]; WT w[GB][RSTEPS]; MT s[GB], z[GB]; };
@@ -185,7 +189,12 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
 #pragma unroll
         for (int r = 0; r < MB; ++r) {
             const uint32_t rso = (uint32_t)__builtin_amdgcn_readfirstlane((int)((int64_t)(r < rows_x ? r : rows_x - 1) * p.stride_xm * 2));
-            b.x[r] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff, xso + rso, 0);
+            if constexpr (NBITS == 4) b.x[r] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff, xso + rso, 0);
+            else {
+                const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rsX, xvoff, xso + rso, 0);
+                const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rsX, xvoff + 16u, xso + rso, 0);
+                b.x[r] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
         }
 #pragma unroll
         for (int gi = 0; gi < GB; ++gi) {
@@ -202,6 +211,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
     // pair-permute (+ pre-scale) the lane's chunk into A-fragment order, store it in buffer `buf`; returns the sum of the TRUE
     // x over the chunk's group unit (butterfly over the CPG lanes of the unit: fixed order, every lane of the unit gets it)
     auto stage = [&](const u32x4 v, int buf, int r) -> float {
+        // 4-bit: v = the row's 8 k (x0x1)(x2x3)(x4x5)(x6x7) -> pairs (x_a, x_{a+4});  2-bit: v = {low piece (x0x1)(x2x3), high piece
+        // (x8x9)(x10x11)} of the fragment -> pairs (x_a, x_{a+8}): the same four permutes
         uint32_t q[4];
         q[0] = __builtin_amdgcn_perm(v[2], v[0], 0x05040100u);
         q[1] = __builtin_amdgcn_perm(v[2], v[0], 0x07060302u);
@@ -255,15 +266,17 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
 #pragma unroll
         for (int rs = 0; rs < RSTEPS; ++rs)
 #pragma unroll
-            for (int gi = 0; gi < GB; ++gi) {
-                const u32x4 a = *(const u32x4*)(xa + (gi * CPG + rs * 4) * 16);  // chunk (unit gi, k-step rs, quarter kg)
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    const u32x4 bf = UP::frag(word_of<V>(b.w[gi][rs], j), 0);
-                    const f32x4 cin = rs == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[gi][j];
-                    acc[gi][j] = mfma16<Tag>(a, bf, cin);
+                for (int gi = 0; gi < GB; ++gi) {
+                    const u32x4 a = *(const u32x4*)(xa + (gi * CPG + (rs * NF + f) * 4) * 16);  // chunk (unit gi, k-step rs NF + f, quarter kg)
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        const u32x4 bf = UP::frag(word_of<V>(b.w[gi][rs], j), f);
+                        const f32x4 cin = (rs == 0 && f == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[gi][j];
+                        acc[gi][j] = mfma16<Tag>(a, bf, cin);
+                    }
                 }
-            }
 #pragma unroll
         for (int gi = 0; gi < GB; ++gi) {
 #pragma unroll
@@ -317,35 +330,41 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
 // host-side planning.  tuning[0]: 0 auto | 21 / 22 / 24 = 1 / 2 / 4 words per lane (16 / 32 / 64 columns);  tuning[2]: 0 auto | 4 / 8 / 16 waves
 // ---------------------------------------------------------------------------------------------------------------------
 typedef void (*gmf_fn)(const WnParams);
-template <typename Tag, int V, int MB, int SPG>
+template <typename Tag, int NB, int V, int MB, int SPG>
 static gmf_fn gmf_pick_nw(int nw) {
-    constexpr int GB = V == 4 ? 2 : 4;
+    // group units per batch: what keeps >= 64 KB of weight requests in flight per CU (8 waves) within the register budget —
+    // a unit is RSTEPS = 4 (4-bit) / 2 (2-bit) wave loads of V words
+    constexpr int GB = V == 4 ? 2 : 4;  // (4 units with 2-bit 64-column tiles measured slower: 20.1 vs 18.0 us at 16384^2)
     switch (nw) {
-        case 4: return gemv_mfma_kernel<Tag, 4, V, 4, MB, GB, SPG>;
-        case 8: return gemv_mfma_kernel<Tag, 4, V, 8, MB, GB, SPG>;
+        case 4: return gemv_mfma_kernel<Tag, NB, V, 4, MB, GB, SPG>;
+        case 8: return gemv_mfma_kernel<Tag, NB, V, 8, MB, GB, SPG>;
         case 16:  // 1024 threads: 128 registers per lane — only the one-word tile fits without spilling
-            if constexpr (V == 1) return gemv_mfma_kernel<Tag, 4, V, 16, MB, GB, SPG>;
+            if constexpr (V == 1 && NB == 4) return gemv_mfma_kernel<Tag, NB, V, 16, MB, GB, SPG>;
             else return nullptr;
         default: return nullptr;
     }
 }
-template <typename Tag, int MB, int SPG>
+template <typename Tag, int NB, int MB, int SPG>
 static gmf_fn gmf_pick_v(int v, int nw) {
     switch (v) {
-        case 1: return gmf_pick_nw<Tag, 1, MB, SPG>(nw);
-        case 2: return gmf_pick_nw<Tag, 2, MB, SPG>(nw);
-        case 4: return gmf_pick_nw<Tag, 4, MB, SPG>(nw);
+        case 1: return gmf_pick_nw<Tag, NB, 1, MB, SPG>(nw);
+        case 2: return gmf_pick_nw<Tag, NB, 2, MB, SPG>(nw);
+        case 4: return gmf_pick_nw<Tag, NB, 4, MB, SPG>(nw);
         default: return nullptr;
     }
 }
 template <typename Tag>
-static gmf_fn gmf_pick(int v, int nw, int mb, int spg) {
-    if (spg == 4) return mb == 1 ? gmf_pick_v<Tag, 1, 4>(v, nw) : gmf_pick_v<Tag, 4, 4>(v, nw);
-    return mb == 1 ? gmf_pick_v<Tag, 1, 2>(v, nw) : gmf_pick_v<Tag, 4, 2>(v, nw);
+static gmf_fn gmf_pick(int nbits, int v, int nw, int mb, int spg) {
+    if (nbits == 2) {  // 2-bit words: groups of >= 128 only (a 64-k group is half a wave load), one activation row
+        if (spg != 4 || mb != 1) return nullptr;
+        return gmf_pick_v<Tag, 2, 1, 4>(v, nw);
+    }
+    if (spg == 4) return mb == 1 ? gmf_pick_v<Tag, 4, 1, 4>(v, nw) : gmf_pick_v<Tag, 4, 4, 4>(v, nw);
+    return mb == 1 ? gmf_pick_v<Tag, 4, 1, 2>(v, nw) : gmf_pick_v<Tag, 4, 4, 2>(v, nw);
 }
 
 bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
-    if (a.W_nbits != 4) return false;
+    if (a.W_nbits != 4 && a.W_nbits != 2) return false;
     if (a.M < 1 || a.M > 4) return false;
     if (a.output_dtype != a.input_dtype) return false;  // typed epilogue / metadata
     if (a.input_dtype != GEMLITE_DT_FP16 && a.input_dtype != GEMLITE_DT_BF16) return false;
@@ -362,7 +381,7 @@ bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& 
     else if (gs == 64) spg = 2;
     else return false;
     if (a.K % (32 * spg) != 0) return false;
-    const int64_t rows = a.K / 8;
+    const int64_t rows = a.K / (32 / a.W_nbits);
     if (rows * a.stride_wk * 4 + a.N * 4 >= (1ll << 32) || (int64_t)(a.K / gs) * p.stride_meta_g + a.N >= (1ll << 32)) return false;  // 32-bit offsets
     const int mb = a.M == 1 ? 1 : 4;
     const int ngroups = (int)(a.K / (32 * spg));
@@ -382,14 +401,16 @@ bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& 
     while (nw > 4 && ngroups < nw) nw >>= 1;
     const size_t lds = (size_t)nw * 2 * mb * 1024 + (size_t)nw * 64 * 4 * v * 4;
     const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
-    gmf_fn fn = f16 ? gmf_pick<half_tag>(v, nw, mb, spg) : gmf_pick<bf16_tag>(v, nw, mb, spg);
+    gmf_fn fn = f16 ? gmf_pick<half_tag>(a.W_nbits, v, nw, mb, spg) : gmf_pick<bf16_tag>(a.W_nbits, v, nw, mb, spg);
     if (!fn) return false;
     p.splitk = 1;
     p.rows_per_slice = (int)rows;
     lp.fn = (const void*)fn;
+    static const char* names2[3] = {"gemv_w2_mfma_kernel<tile16>", "gemv_w2_mfma_kernel<tile32>", "gemv_w2_mfma_kernel<tile64>"};
     static const char* names[2][3] = {{"gemv_mfma_kernel<tile16>", "gemv_mfma_kernel<tile32>", "gemv_mfma_kernel<tile64>"},
                                       {"gemv_mfma_kernel<tile16,rows4>", "gemv_mfma_kernel<tile32,rows4>", "gemv_mfma_kernel<tile64,rows4>"}};
     lp.name = names[mb == 1 ? 0 : 1][v == 1 ? 0 : (v == 2 ? 1 : 2)];
+    if (a.W_nbits == 2) lp.name = names2[v == 1 ? 0 : (v == 2 ? 1 : 2)];
     lp.grid = dim3((unsigned)(a.N / (16 * v)), 1, 1);
     lp.block = dim3(64 * nw, 1, 1);
     lp.lds_bytes = lds;

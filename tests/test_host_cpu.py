@@ -126,7 +126,9 @@ def test_struct_abi_and_validation():
     (dict(M=8, N=4864, K=896), "gemm_w4_mma_kernel<128x128>"),   # K = 128 * 7 (Qwen2.5-0.5B): only the 128-k-step tiles divide it
     (dict(M=1, N=1024, K=896), "gemv_wn_kernel<tile64,xdirect>"),
     (dict(M=256, N=4096, K=11008), "gemm_w4_mma_kernel<128x128>"),   # block-time model: 128 rows x 4 slices (40.5 vs 42.3 us for 64 x 2)
-    (dict(M=1, nbits=2), "gemv_wn_kernel<tile16>"),
+    (dict(M=1, nbits=2), "gemv_w2_mfma_kernel<tile16>"),   # 2-bit decode on the matrix core up to 32-column tiles (4.4 vs 4.9 us)
+    (dict(M=1, nbits=2, tuning=(0, 0, 0, 512)), "gemv_wn_kernel<tile16>"),
+    (dict(M=1, N=11008, K=4096), "gemv_wn_kernel<tile32>"),   # 4-bit, 32-column tiles over a short K: the dot-product family (8.9 vs 9.3)
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64,8w>"),   # 2-bit, long K: two waves per SIMD
     (dict(M=16), "gemm_wn_direct_kernel<tile32>"),
