@@ -13,11 +13,14 @@ lib = _hip.load()
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 CASES = {
-    # flags: 512 = dot-product family, 1024 = MFMA decode wherever it applies; tile codes 21 / 22 / 24 = 16 / 32 / 64 columns (MFMA decode)
-    "a16w2_16384_m1": [(0, 0, 0, 512), (0, 0, 0, 1024), (0, 0, 4, 1024), (22, 0, 8, 1024)],
+    "a16w2_16384_m1": [(0, 0, 0, 512), (0, 0, 0, 1024)],
+    "a16w4_16384_m1": [(0, 0, 0, 512), (0, 0, 0, 1024)],
+    "a16w4_8192_m1": [(0, 0, 0, 512), (0, 0, 0, 1024)],
     "a16w2_8192_m1": [(0, 0, 0, 512), (0, 0, 0, 1024)],
-    "a16w2_11008_m1": [(0, 0, 0, 512), (0, 0, 0, 1024)],
     "a16w4_11008n_m1": [(0, 0, 0, 512), (0, 0, 0, 1024)],
+    "a16w4_11008_m1": [(0, 0, 0, 512), (0, 0, 0, 1024)],
+    "a16w4_4096_m1": [(0, 0, 0, 512), (0, 0, 0, 1024)],
+    "a16w4_8192_m4": [(0, 0, 0, 512), (0, 0, 0, 0)],
 }
 bench.WORKLOADS.update({"a16w2_8192_m1": (8192, 8192, 2, 128, 1, "fp16", 16, "hbm"), "a16w2_4096_m1": (4096, 4096, 2, 128, 1, "fp16", 32, "hbm"), "a16w2_11008_m1": (11008, 4096, 2, 128, 1, "fp16", 24, "hbm"), "a16w4_11008n_m1": (11008, 4096, 4, 128, 1, "fp16", 12, "hbm")})
 bench.WORKLOADS.update({"a16w4_4096_m2": (4096, 4096, 4, 128, 2, "fp16", 32, "hbm"), "a16w4_4096_m4": (4096, 4096, 4, 128, 4, "fp16", 32, "hbm"), "a16w4_8192_m4": (8192, 8192, 4, 128, 4, "fp16", 8, "hbm")})
