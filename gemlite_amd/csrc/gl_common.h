@@ -375,28 +375,21 @@ __device__ __forceinline__ int group_of(int k, int gs_shift) { return k >> gs_sh
 // last (up to three) units are peeled.
 template <typename Buf, typename Load>
 __device__ __forceinline__ void pipeline2_prime(int n, Buf& A, Buf& B, Load&& load) {
-    // both buffers are requested UNCONDITIONALLY (n == 1 requests unit 0 twice; the second copy is never consumed): with `if (n > 1)`
-    // around the second request hipcc cannot tell at the head of the steady-state loop whether B is outstanding and waits with
-    // s_waitcnt vmcnt(0) there — both buffers drained in every iteration (scripts/isa_loops.py, round 3; every gemv_wn_kernel
-    // variant had run that way since round 1)
     load(A, 0);
-    load(B, n > 1 ? 1 : 0);
+    if (n > 1) load(B, 1);
 }
 template <typename Buf, typename Load, typename Compute>
 __device__ __forceinline__ void pipeline2_run(int n, Buf& A, Buf& B, Load&& load, Compute&& compute) {
     int i = 0;
     for (; i + 4 <= n; i += 2) {
-        // sched_barrier pins the four phases: left alone, hipcc's scheduler clusters the two request groups in the middle of the
-        // body and waits for BOTH buffers (s_waitcnt vmcnt(0)) at the loop head — requests then overlap half of the arithmetic
-        // instead of all of it (scripts/isa_loops.py, round 3)
+        // (round 3, scripts/isa_loops.py: hipcc 7.2 waits with s_waitcnt vmcnt(0) at the head of this loop in every gemv_wn_kernel
+        // variant, i.e. both buffers are drained per iteration, and its scheduler makes up for it by hoisting the next requests above
+        // the arithmetic.  Pinning the four phases with sched_barrier(0) and priming unconditionally removed neither the drain nor
+        // its cause and took the hoisting away: 16384^2 M = 1 went 23.7 -> 27.9 us, 8192^2 10.4 -> 11.3 us.  Left to the compiler.)
         compute(A, i);
-        __builtin_amdgcn_sched_barrier(0);
         load(A, i + 2);
-        __builtin_amdgcn_sched_barrier(0);
         compute(B, i + 1);
-        __builtin_amdgcn_sched_barrier(0);
         load(B, i + 3);
-        __builtin_amdgcn_sched_barrier(0);
     }
     const int rem = n - i;  // 1, 2 or 3
     compute(A, i);
