@@ -151,6 +151,7 @@ __device__ __forceinline__ void tiled_epilogue(const WnParams& p, f32x16 (&acc)[
     if (tid == 0) splitk_reset(p.counters + tile_lin);
 }
 
+#ifdef GL_AB_KERNELS  // the one-step-ahead kernel of round 1: only built for A/B runs (make AB=1)
 // MI = 32-row blocks per wave: tile = (32*MI) x 128, 4 waves, wave w owns all rows x columns [32w, 32w+32)
 template <typename Tag, int MI>
 __global__ __launch_bounds__(256, (MI <= 4 ? 2 : 1)) void gemm_w4_tiled_kernel(const WnParams p) {
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256, (MI <= 4 ? 2 : 1)) void gemm_w4_tiled_kernel(c
 
     tiled_epilogue<Tag, MI>(p, acc, smem, bid, nt, m0, slice);
 }
+#endif  // GL_AB_KERNELS
 
 // ---------------------------------------------------------------------------------------------------------------
 // Software-pipelined tiled kernel (default).  Same tile (128 x 128), wave layout (wave w: all rows x 32 columns) and
@@ -618,6 +620,10 @@ bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPl
     // tuning[2]: 0 auto = the deep-pipelined kernel | 4 = the one-step-ahead kernel it replaced (kept for A/B runs)
     //            8 = the software-pipelined kernel with 256-row tiles, one block per CU (default: 128-row tiles)
     const bool legacy = a.tuning[2] == 4;
+#ifndef GL_AB_KERNELS
+    // the one-step-ahead kernel and the 256-row variant lost their A/B runs in round 1 / 2 and are built only with `make AB=1`
+    if (a.tuning[2] == 4 || a.tuning[2] == 8) return false;
+#endif
     // (256-row tiles: 52.6 us per 4096-deep K at one block per CU vs 39.8 us for two 128-row blocks, and their
     //  split-K needs twice the slices for the same block count — opt-in until the loop is under the issue budget)
     const int mi = legacy ? 4 : (a.tuning[2] == 8 ? 8 : 4);
@@ -647,12 +653,18 @@ bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPl
     p.splitk = splitk;
     p.rows_per_slice = rows / splitk;
     const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
+#ifdef GL_AB_KERNELS
     if (legacy) {
         lp.fn = f16 ? (const void*)gemm_w4_tiled_kernel<half_tag, 4> : (const void*)gemm_w4_tiled_kernel<bf16_tag, 4>;
         lp.name = "gemm_w4_tiled_kernel<legacy>";
-    } else {
-        lp.fn = mi == 8 ? (f16 ? (const void*)gemm_w4_pipe_kernel<half_tag, 8> : (const void*)gemm_w4_pipe_kernel<bf16_tag, 8>)
-                        : (f16 ? (const void*)gemm_w4_pipe_kernel<half_tag, 4> : (const void*)gemm_w4_pipe_kernel<bf16_tag, 4>);
+    } else
+#endif
+    {
+#ifdef GL_AB_KERNELS
+        if (mi == 8) lp.fn = f16 ? (const void*)gemm_w4_pipe_kernel<half_tag, 8> : (const void*)gemm_w4_pipe_kernel<bf16_tag, 8>;
+        else
+#endif
+        lp.fn = f16 ? (const void*)gemm_w4_pipe_kernel<half_tag, 4> : (const void*)gemm_w4_pipe_kernel<bf16_tag, 4>;
 #ifdef GL_TILED_EXPERIMENTS
         if (mi == 8 && !f16) switch (a.tuning[3] >> 8) {
             case 1: lp.fn = (const void*)gemm_w4_pipe_kernel<bf16_tag, 8, 1>; break;

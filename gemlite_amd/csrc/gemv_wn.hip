@@ -198,22 +198,18 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
         xsum_s[task] = sum_s;
     };
 
-    // development timeline (-DGL_GEMV_TIMELINE + tuning[3] & 4, needs a workspace): lane 0 of every wave of block (0,0) stores
-    // s_memtime stamps.  NOT compiled into the product: every stamp is a conditional global STORE, stores count in vmcnt on gfx9,
-    // and with "maybe a store outstanding" between the first requests and the steady-state loop hipcc waits with vmcnt(0) at the
-    // loop head (both chunk buffers drained every iteration — scripts/isa_loops.py, round 3).
-#ifdef GL_GEMV_TIMELINE
+    // opt-in timeline (tuning[3] & 4, needs a workspace): lane 0 of every wave of block (0,0) stores s_memtime stamps
+    // (round 3: scripts/isa_loops.py shows hipcc waiting with s_waitcnt vmcnt(0) at the head of the steady-state loop below, and
+    //  these conditional stamp STORES are one of its reasons (stores count in vmcnt on gfx9).  Compiling them out, moving the
+    //  scalar-zero load above the priming and dropping the in-loop stamp turned the wait into vmcnt(6) + a vmcnt(0) a few
+    //  instructions later AND changed the schedule for the worse: 16384^2 23.7 -> 28.0 us, 8192^2 10.4 -> 11.3 us, 4096^2 4.80 ->
+    //  4.95 us (profiles/r03/probe_gemv3_v8*.log).  The version with the stamps is the one that ships.)
     const bool probe = (p.flags & 4) && p.counters && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0;
     unsigned long long* stamps = (unsigned long long*)(p.counters + MAX_SPLITK_COUNTERS) + wave * 16;
     auto stamp = [&](int i) {
         if (probe) stamps[i] = __builtin_readcyclecounter();
     };
-#else
-    auto stamp = [](int) {};
-#endif
     stamp(0);
-    // (the scalar zero, if any, is fetched BEFORE the weight stream is primed: its wait must not drain that queue)
-    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
     Chunk A, B;
     if constexpr (XD) {
         if (nchunks > 0) pipeline2_prime(nchunks, A, B, load_chunk);
@@ -236,6 +232,7 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
 #pragma unroll
         for (int j = 0; j < 4; ++j) tot[m][j] = 0.f;
 
+    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
     // (a, b) of group_affine() without per-column branches: a = s (s == 1 when unused),
     // b = bz * z * (mode 3 ? s : 1) with bz = -1 (modes 1, 3), +1 (mode 4), 0 otherwise
     const float bz = (p.w_mode == 1 || p.w_mode == 3) ? -1.f : (p.w_mode == 4 ? 1.f : 0.f);
@@ -341,10 +338,10 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
     };
 
     if (nchunks > 0)
-        // (no timeline stamp inside this loop: a conditional STORE in the loop body makes hipcc's vmcnt bookkeeping ambiguous — stores
-        //  count in vmcnt on gfx9 — and it answered with s_waitcnt vmcnt(0) at the loop head, draining both chunk buffers every
-        //  iteration.  Found by scripts/isa_loops.py in round 3; the A16W2 16384^2 decode kernel had run that way since round 1.)
-        pipeline2_run(nchunks, A, B, load_chunk, [&](const Chunk& ck, int ch) { compute(ck, ch); });
+        pipeline2_run(nchunks, A, B, load_chunk, [&](const Chunk& ck, int ch) {
+            compute(ck, ch);
+            if (ch == 0) stamp(2);  // first chunk consumed (its data had arrived)
+        });
     stamp(3);  // all chunks consumed
 
     // ---- reduce over the G row sub-groups of the wave (lane bits CQ..5) --------------------------------

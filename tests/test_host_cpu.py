@@ -137,8 +137,8 @@ def test_struct_abi_and_validation():
     (dict(M=256), "gemm_w4_mma_kernel<64x128>"),       # cfgA: 128 tiles x 2 K slices (18.6 us vs 30.4 for 256-row tiles x 8)
     (dict(M=256, N=8192, K=8192, in_dt=2), "gemm_w4_mma_kernel<128x128>"),   # cfgB
     (dict(M=256, tuning=(0, 0, 8, 0)), "gemm_w4_mma_kernel<256x128>"),   # tuning[2]: tile rows / 32
-    (dict(M=256, tuning=(2, 0, 8, 0)), "gemm_w4_tiled_kernel<256x128>"),
-    (dict(M=256, tuning=(2, 0, 4, 0)), "gemm_w4_tiled_kernel<legacy>"),
+    (dict(M=256, tuning=(2, 0, 8, 0)), "gemm_w4_tiled_kernel<256x128>|ab"),   # built with `make AB=1` only
+    (dict(M=256, tuning=(2, 0, 4, 0)), "gemm_w4_tiled_kernel<legacy>|ab"),
     (dict(M=2048, N=8192, K=8192, in_dt=2), "gemm_w4_mma_kernel<256x256>"),   # prefill: 256 x 256 tiles alone fill the chip
     (dict(M=1024, N=8192, K=8192, in_dt=2), "gemm_w4_mma_kernel<256x128>"),   # 128 wide tiles do not
     (dict(M=256, N=8192, K=8192, in_dt=2, tuning=(0, 4, 20, 0)), "gemm_w4_mma_kernel<128x256>"),   # tuning[2] = 16 + rows / 32
@@ -188,6 +188,13 @@ def test_kernel_selection(kw, kernel):
     if kw.get("c_mode", 0) in (2, 3):
         a.scales_x = 0x1000
     assert lib.gemlite_hip_query(C.byref(a)) == 0
+    if kernel.endswith("|ab"):  # A/B-only variants: present when the library was built with GL_AB_KERNELS, else never chosen
+        got = lib.gemlite_hip_kernel_name(C.byref(a)).decode()
+        if "+ab_kernels" in lib.gemlite_hip_build_info().decode():
+            assert got == kernel[:-3]
+        else:
+            assert got != kernel[:-3] and "tiled_kernel<" not in got.replace("gemm_w4_tiled_kernel<128x128>", ""), got
+        return
     assert lib.gemlite_hip_kernel_name(C.byref(a)).decode() == kernel
 
 
