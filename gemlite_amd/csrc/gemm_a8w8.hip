@@ -750,10 +750,12 @@ bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
 // check.  The eight partial 16 x 16 tiles are added through LDS (int32: exact), then the reference's epilogue
 // (channel_scale_mode 0..3) runs per output.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DT>
+// MT = row tiles of 16 (round 3: 17..64 rows used to fall to the 32-row tile of the 8-wave kernel — 17.4 us at 4096^2 int8, M = 32,
+// against 6.7 us for 16 rows here): the weight fragment of a chunk is loaded once and multiplied with MT x fragments.
+template <int DT, int MT>
 __global__ __launch_bounds__(512) void a8w8_rows_kernel(const GenericParams p) {
     typedef typename std::conditional<DT == GEMLITE_DT_INT8, i32x4, f32x4>::type acc_t;
-    __shared__ __attribute__((aligned(16))) uint32_t red[8][64][4];
+    __shared__ __attribute__((aligned(16))) uint32_t red[MT][8][64][4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, kg = lane >> 4;
@@ -762,29 +764,38 @@ __global__ __launch_bounds__(512) void a8w8_rows_kernel(const GenericParams p) {
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + p.K), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((int64_t)(p.M - 1) * p.stride_xm + p.K), 0x00020000);
     const uint32_t wvoff = (uint32_t)((n0 + c) * p.stride_wn + kg * 16);
-    const uint32_t xvoff = c < p.M ? (uint32_t)((int64_t)c * p.stride_xm + kg * 16) : 0x80000000u;  // rows >= M: zeros
-    acc_t acc = {0, 0, 0, 0};
-    constexpr int D = 8;  // chunks in flight per wave (2 x 16 bytes per lane each)
-    u32x4 wb[D], xb[D];
+    uint32_t xvoff[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+        xvoff[t] = c + 16 * t < p.M ? (uint32_t)((int64_t)(c + 16 * t) * p.stride_xm + kg * 16) : 0x80000000u;  // rows >= M: zeros
+    acc_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+    constexpr int D = MT == 1 ? 8 : (MT == 2 ? 6 : 4);  // chunks in flight per wave ((1 + MT) x 16 bytes per lane each)
+    u32x4 wb[D], xb[D][MT];
     const int mine = (nchunks - wave + 7) >> 3;  // chunks wave, wave + 8, ...
     auto load = [&](int slot, int i) __attribute__((always_inline)) {
         const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((wave + 8 * i) * 64);
         wb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, so, 0);
-        xb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff, so, 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) xb[slot][t] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], so, 0);
     };
     auto mma = [&](int slot) __attribute__((always_inline)) {
-        if constexpr (DT == GEMLITE_DT_INT8) {
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, xb[slot]), __builtin_bit_cast(i32x4, wb[slot]), acc, 0, 0, 0);
-        } else {
-            const u32x4 a = xb[slot], b = wb[slot];
-            const long a0 = (long)(((uint64_t)a[1] << 32) | a[0]), a1 = (long)(((uint64_t)a[3] << 32) | a[2]);
-            const long b0 = (long)(((uint64_t)b[1] << 32) | b[0]), b1 = (long)(((uint64_t)b[3] << 32) | b[2]);
-            if constexpr (DT == GEMLITE_DT_FP8E4) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            if constexpr (DT == GEMLITE_DT_INT8) {
+                acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, xb[slot][t]), __builtin_bit_cast(i32x4, wb[slot]), acc[t], 0, 0, 0);
             } else {
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(a0, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(a1, b1, acc, 0, 0, 0);
+                const u32x4 a = xb[slot][t], b = wb[slot];
+                const long a0 = (long)(((uint64_t)a[1] << 32) | a[0]), a1 = (long)(((uint64_t)a[3] << 32) | a[2]);
+                const long b0 = (long)(((uint64_t)b[1] << 32) | b[0]), b1 = (long)(((uint64_t)b[3] << 32) | b[2]);
+                if constexpr (DT == GEMLITE_DT_FP8E4) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc[t], 0, 0, 0);
+                } else {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(a0, b0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(a1, b1, acc[t], 0, 0, 0);
+                }
             }
         }
     };
@@ -802,40 +813,52 @@ __global__ __launch_bounds__(512) void a8w8_rows_kernel(const GenericParams p) {
     }
     // one 16-byte store of the fragment (storing it element by element through bit_cast<uint32_t>(acc[r]) made hipcc 7.2
     // overwrite acc[1..3] with acc[0] after the loop — every output row read row 4 (m / 4); found with structured inputs)
-    *(acc_t*)&red[wave][lane][0] = acc;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *(acc_t*)&red[t][wave][lane][0] = acc[t];
     __syncthreads();
-    if (tid < 256) {
-        const int l = tid & 63, r = tid >> 6;
-        const int m = 4 * (l >> 4) + r;  // C fragment of a 16 x 16 MFMA: column lane & 15, rows 4 (lane >> 4) + r
+    for (int u = tid; u < MT * 256; u += 512) {
+        const int t = u >> 8, l = u & 63, r = (u >> 6) & 3;
+        const int m = 16 * t + 4 * (l >> 4) + r;  // C fragment of a 16 x 16 MFMA: column lane & 15, rows 4 (lane >> 4) + r
         float v;
         if constexpr (DT == GEMLITE_DT_INT8) {
             int sum = 0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) sum += (int)red[w][l][r];
+            for (int w = 0; w < 8; ++w) sum += (int)red[t][w][l][r];
             v = (float)sum;
         } else {
             v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += __builtin_bit_cast(float, red[w][l][r]);
+            for (int w = 0; w < 8; ++w) v += __builtin_bit_cast(float, red[t][w][l][r]);
         }
         if (m < p.M) epilogue_store(p.epi, v, m, n0 + (l & 15));
     }
 }
 
-// 2 <= M <= 16 (M = 1 too when forced with tuning[2] = 16), same-dtype 8-bit operands, both K-contiguous
+// 2 <= M <= 64 (M = 1 too when forced with tuning[0] = 4), same-dtype 8-bit operands, both K-contiguous.  17..64 rows: 2 / 4 row
+// tiles per block while every block's re-read of x from L2 (M K bytes) stays below the 8-wave kernel's fixed cost — measured
+// crossover in profiles/r03/probe_a8w8_rows_mt.log
 bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
-    if (a.elements_per_sample != 1 || a.W_group_mode != 0 || a.M > 16 || a.M < 1) return false;
+    if (a.elements_per_sample != 1 || a.W_group_mode != 0 || a.M > 64 || a.M < 1) return false;
     if (a.w_dtype != a.input_dtype) return false;
     if (!(a.input_dtype == GEMLITE_DT_INT8 || a.input_dtype == GEMLITE_DT_FP8E4 || a.input_dtype == GEMLITE_DT_FP8E5)) return false;
     if (a.stride_wk != 1 || a.stride_xk != 1 || a.N % 16 != 0 || a.K % 64 != 0) return false;
     if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
     if ((int64_t)a.M * a.stride_xm + a.K >= (1ll << 31) || (int64_t)a.N * a.stride_wn + a.K >= (1ll << 31)) return false;
+    const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    // every block re-reads its M rows of x from L2: M K bytes x N / 16 blocks.  Up to ~90 MB of that the 16-column blocks beat the
+    // 8-wave tiles (4096^2: 7.5 / 8.8 / 13.4 us at M = 17 / 32 / 64 against 16.9 / 17.4 / 18.3; 8192^2 M = 17: 21.3 vs 24.7), beyond
+    // they lose (8192^2 M = 32: 28.1 vs 24.9; M = 64: 43.9 vs 27.7) — profiles/r03/probe_a8w8_rows_mt.log.  tuning[0] = 4 forces them.
+    if (mt > 1 && a.tuning[0] != 4 && (int64_t)a.M * a.K * (a.N / 16) > (88ll << 20)) return false;
+    auto pick = [&](auto dt) -> const void* {
+        constexpr int DT = decltype(dt)::value;
+        return mt == 1 ? (const void*)a8w8_rows_kernel<DT, 1> : (mt == 2 ? (const void*)a8w8_rows_kernel<DT, 2> : (const void*)a8w8_rows_kernel<DT, 4>);
+    };
     switch (a.input_dtype) {
-        case GEMLITE_DT_INT8: lp.fn = (const void*)a8w8_rows_kernel<GEMLITE_DT_INT8>; break;
-        case GEMLITE_DT_FP8E4: lp.fn = (const void*)a8w8_rows_kernel<GEMLITE_DT_FP8E4>; break;
-        default: lp.fn = (const void*)a8w8_rows_kernel<GEMLITE_DT_FP8E5>; break;
+        case GEMLITE_DT_INT8: lp.fn = pick(std::integral_constant<int, GEMLITE_DT_INT8>{}); break;
+        case GEMLITE_DT_FP8E4: lp.fn = pick(std::integral_constant<int, GEMLITE_DT_FP8E4>{}); break;
+        default: lp.fn = pick(std::integral_constant<int, GEMLITE_DT_FP8E5>{}); break;
     }
-    lp.name = "a8w8_rows_kernel<16x16>";
+    lp.name = mt == 1 ? "a8w8_rows_kernel<16x16>" : (mt == 2 ? "a8w8_rows_kernel<32x16>" : "a8w8_rows_kernel<64x16>");
     lp.grid = dim3((unsigned)(a.N / 16), 1, 1);
     lp.block = dim3(512, 1, 1);
     lp.lds_bytes = 0;

@@ -217,8 +217,12 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     const void* fn = f16 ? mma_lookup_f16(wide ? 1 : 0, nbits, mi, xdt, 0) : mma_lookup_bf16(wide ? 1 : 0, nbits, mi, xdt, 0);
     // K-slice combine: reduce-scatter between the slices of a tile when they are certain to be co-resident (every block of the
     // launch fits on the device at once: <= one block per CU), the slices divide the tile's row blocks, and the variant exists
-    // (4- / 2-bit words, 16-bit activations); else slabs + ticket.  tuning[3] & 128 forces the ticket protocol.
+    // (4- / 2-bit words, 16-bit activations); else slabs + ticket.  From 4 slices on: with 2 slices the ticket protocol is as fast
+    // or faster (cfgA 64x128 x 2: 19.6 vs 21.2 us, cfgB 128x128 x 2: 43.9 vs 43.4; with 4 slices of 256-row tiles 27.5 -> 25.1 and
+    // 47.9 -> 44.9, profiles/r03/probe_mma3_v3*.log).  tuning[3]: & 128 forces the ticket protocol, & 2048 takes the reduce-scatter
+    // with 2 slices too, & 256 = & 2048 + every block hands its rows over after one poll (tests of that path).
     const bool use_xch = !wide && splitk > 1 && (splitk & (splitk - 1)) == 0 && mi >= 2 && splitk <= mi && !(a.tuning[3] & 128) &&
+                     (splitk >= 4 || (a.tuning[3] & (2048 | 256))) &&
                      xdt == 0 && (nbits == 4 || nbits == 2) && tiles * splitk <= resident_block_limit();
     if (use_xch) fn = f16 ? mma_lookup_f16(4, nbits, mi, 0, 1) : mma_lookup_bf16(4, nbits, mi, 0, 1);
     if (!fn) return false;

@@ -155,15 +155,25 @@ typedef struct gemlite_hip_forward_args {
     /* Planner overrides (0 = library default everywhere; what helper.autotune_layer() searches and the tuning table
      * stores — the counterpart of the reference's per-shape Triton autotune configs).  Meaning per kernel family:
      *   packed GEMV (M = 1)        [0] 2/3/4 = 16-/32-/64-column tiles   [1] K slices   [2] 4/8/16 waves per block
-     *                              (82 = 8 waves, 2 rows per lane)       [3] & 3: 1 = x through LDS, 2 = x direct
+     *                              (82 = 8 waves, 2 rows per lane; 48 = 4 waves, 8 rows per lane)   [3] & 3: 1 = x through LDS,
+     *                              2 = x direct; & 16 = the round-2 kernel instead of the 16-column decode kernel,
+     *                              & 32 = default-policy (not non-temporal) weight loads in the decode kernel
+     *   MFMA GEMV (M = 1..4, 4- and 2-bit words under 16-bit activations; default where it measured faster)
+     *                              [0] 21/22/24 = 16-/32-/64-column tiles   [2] 4/8/16 waves per block
+     *                              [3] & 512 = never, & 1024 = wherever it applies
      *   few rows (2..32, MFMA)     [0] 1/2/4 = 16-/32-/64-column tiles, 3 = the 8-wave tiled kernel instead
      *                              [1] K slices   [2] 1 = LDS-staged streaming kernel
-     *   tiled (M > 32, MFMA)       [0] 1 = streaming kernel, 2 = the 4-wave tiled kernel of round 1 (4-bit only)
+     *   tiled (M > 32, MFMA)       [0] 1 = streaming kernel, 2 = the 4-wave tiled kernel of round 1 (4-bit only; the planner's
+     *                              fallback for K = 64 * odd)
      *                              [1] K slices (any count <= K steps; slices may be uneven)
      *                              [2] tile rows / 32: 1/2/4/8 (8-wave kernel, 128-column tiles); 20 / 24 = 128 / 256 rows x 256
      *                              columns (4- and 2-bit, 16-bit activations); with [0] = 2: 4 = one-step-ahead, 8 = 256 rows
-     *   unpacked 8-bit (A8W8)      [0] 1 = streaming (one wave per column), 2 = the 4-wave MFMA kernel of round 1,
-     *                              4 = the 16-column few-row kernel (default for 2..16 rows) also at M = 1
+     *                              (both only in a library built with `make AB=1`)
+     *                              [3] K-slice combine: & 128 = slabs + ticket always, & 2048 = reduce-scatter with 2 slices too
+     *                              (default: from 4 slices), & 256 = reduce-scatter with immediate hand-over (test switch)
+     *   unpacked 8-bit (A8W8)      [0] 1 = streaming (one wave per column), 2 = the 4-wave MFMA kernel of round 1 (the planner's
+     *                              fallback for K % 256 != 0), 4 = the 16-column few-row kernel (default for 2..64 rows while
+     *                              M K N / 16 <= 88 MiB) at any M <= 64 and at M = 1
      *                              [1] K slices   [2] tile rows / 32 (forces the 8-wave kernels at any M)
      *                              [3] & 64: 128- / 256-row tiles with the weights straight from memory (default: through LDS)
      *   [3] & 4: development timeline stamps (needs a workspace)   [3] & 8: XCD-aware (tile, K slice) map (opt-in).

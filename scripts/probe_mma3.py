@@ -17,20 +17,19 @@ bench.WORKLOADS.update({
     "a16w4_4096_m512": (4096, 4096, 4, 128, 512, "bf16", 32, "mfma"), "a16w4_4096_m1024": (4096, 4096, 4, 128, 1024, "bf16", 32, "mfma"),
     "a16w4_11008x4096_m256": (11008, 4096, 4, 128, 256, "bf16", 12, "mfma"), "a16w4_4096x14336_m256": (4096, 14336, 4, 128, 256, "bf16", 10, "mfma"),
 })
-T, R = 128, 256   # tuning[3]: 128 = slab + ticket combine, 256 = weights through registers (round-2 path)
+T, H = 128, 256   # tuning[3]: 128 = slab + ticket combine, 256 = reduce-scatter with immediate hand-over (every block polls once)
 CASES = {
-    "cfgA": ("a16w4_4096_m256", [(0, 0, 0, 0), (0, 0, 0, R), (0, 0, 0, R | T), (0, 2, 2, 0), (0, 2, 2, R), (0, 4, 4, 0), (0, 4, 4, R), (0, 2, 4, 0),
-                                 (0, 4, 8, 0), (0, 4, 8, R), (0, 8, 8, 0), (0, 4, 2, 0), (0, 4, 2, T)]),
-    "cfgB": ("a16w4_8192_m256", [(0, 0, 0, 0), (0, 0, 0, R), (0, 0, 0, R | T), (0, 2, 4, 0), (0, 2, 4, R), (0, 4, 4, 0), (0, 4, 8, 0), (0, 4, 8, R),
-                                 (0, 2, 8, 0), (0, 4, 2, 0), (0, 8, 2, 0)]),
-    "m64": ("a16w4_4096_m64", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 2, 0), (0, 4, 2, 0)]),
-    "m128": ("a16w4_4096_m128", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 2, 0), (0, 2, 4, 0), (0, 4, 4, 0)]),
-    "m512": ("a16w4_4096_m512", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 4, 0), (0, 2, 8, 0), (0, 4, 8, 0), (0, 1, 4, 0)]),
-    "m1024": ("a16w4_4096_m1024", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 8, 0), (0, 1, 8, 0)]),
+    "cfgA": ("a16w4_4096_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 0, 0, H), (0, 2, 2, 0), (0, 2, 2, T), (0, 4, 4, 0), (0, 4, 4, T), (0, 4, 4, H), (0, 2, 4, 0), (0, 2, 4, T),
+                                 (0, 4, 8, 0), (0, 4, 8, T), (0, 8, 8, 0)]),
+    "cfgB": ("a16w4_8192_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 0, 0, H), (0, 2, 4, 0), (0, 2, 4, T), (0, 4, 4, 0), (0, 4, 8, 0), (0, 4, 8, T), (0, 2, 8, 0), (0, 2, 8, T)]),
+    "m64": ("a16w4_4096_m64", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 2, 0), (0, 2, 2, T)]),
+    "m128": ("a16w4_4096_m128", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 2, 0), (0, 2, 4, 0), (0, 4, 4, 0), (0, 4, 4, T)]),
+    "m512": ("a16w4_4096_m512", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 4, 0), (0, 2, 8, 0), (0, 4, 8, 0), (0, 1, 4, 0)]),
+    "m1024": ("a16w4_4096_m1024", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 8, 0), (0, 1, 8, 0)]),
     "w2": ("a16w2_16384_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 4, 8, 0)]),
-    "n11008": ("a16w4_11008x4096_m256", [(0, 0, 0, 0), (0, 0, 0, R), (0, 2, 8, 0), (0, 2, 4, 0)]),
-    "k14336": ("a16w4_4096x14336_m256", [(0, 0, 0, 0), (0, 0, 0, R), (0, 8, 8, 0), (0, 4, 4, 0), (0, 4, 8, 0)]),
-    "pre": ("a16w4_8192_m2048", [(0, 0, 0, 0), (0, 1, 8, 0), (0, 1, 8, R)]),
+    "n11008": ("a16w4_11008x4096_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 2, 8, 0), (0, 2, 4, 0)]),
+    "k14336": ("a16w4_4096x14336_m256", [(0, 0, 0, 0), (0, 0, 0, T), (0, 8, 8, 0), (0, 4, 4, 0), (0, 4, 8, 0)]),
+    "pre": ("a16w4_8192_m2048", [(0, 0, 0, 0), (0, 1, 8, 0)]),
 }
 for key in (sys.argv[1:] or ["cfgA", "cfgB"]):
     name, tunings = CASES[key]
@@ -48,7 +47,7 @@ for key in (sys.argv[1:] or ["cfgA", "cfgB"]):
             if tw in outs:
                 same = bool(np.array_equal(outs[tw], y))
             outs.setdefault(tw, y)
-            print(json.dumps(dict(workload=name, tuning=t, kernel=kn, combine="ticket" if t[3] & T else "auto", wpath="regs" if t[3] & R else "auto", chained_us=round(c_us, 3),
+            print(json.dumps(dict(workload=name, tuning=t, kernel=kn, combine="ticket" if t[3] & T else ("hand-over" if t[3] & H else "auto"), chained_us=round(c_us, 3),
                                   tflops=round(r.flops / c_us / 1e6, 1), frac=round(r.flops / c_us / 1e6 / 2500, 4),
                                   bitwise_equal_first_of_same_tile=same, finite=bool(np.isfinite(y).all()))), flush=True)
             del r

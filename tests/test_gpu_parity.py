@@ -506,9 +506,9 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
     torch.cuda.synchronize()
     for t, y2 in outs.items():
         assert torch.equal(y, y2), t
-    for M in (2, 5, 16, 17, 31):  # few rows: 16-column blocks up to 16 rows, then the 32-row tile of the 8-wave kernel
+    for M in (2, 5, 16, 17, 31, 40, 64):  # few rows: 16-column blocks with 1 / 2 / 4 row tiles (round 3: up to 64 rows at this size)
         xs = (torch.randn(M, 4096) / 10).half().to(DEV)
-        want = "a8w8_rows_kernel<16x16>" if M <= 16 else "gemm_a8w8_mma_kernel<32x128>"
+        want = "a8w8_rows_kernel<16x16>" if M <= 16 else ("a8w8_rows_kernel<32x16>" if M <= 32 else "a8w8_rows_kernel<64x16>")
         assert _kernel_name(lin, torch.empty(M, 4096, dtype=torch.int8)) == want
         ya = lin(xs)
         gemlite_amd.core.TUNING_OVERRIDE = (1, 0, 0, 0)
@@ -545,7 +545,7 @@ def test_a8w8_lds_kernel_short_and_uneven_k(K):
 
 @pytest.mark.parametrize("kind", ["int8", "fp8e4", "fp8e5"])
 def test_a8w8_rows_kernel(kind):
-    """2..16 rows of A8W8 (BASELINE config 4, M = 16): 16-column blocks, one 16-row MFMA per 64-k chunk — every M, K = 64 * odd
+    """2..64 rows of A8W8 (BASELINE config 4, M = 16): 16-column blocks, one 16-row MFMA per 64-k chunk and row tile — every M, K = 64 * odd
     (uneven chunk counts per wave), long K (several ring passes), against the oracle on the kernel's own quantised inputs, and
     bit-exact against the 8-wave MFMA kernel for int8."""
     from gemlite_amd.core import _hip_matmul
@@ -558,12 +558,12 @@ def test_a8w8_rows_kernel(kind):
         proc = H.A8W8_int8_dynamic(device=DEV, dtype=torch.float16) if kind == "int8" else \
             H.A8W8_dynamic(device=DEV, dtype=torch.float16, fp8=qdt)
         lin = proc.from_weights(W)
-        for M in (2, 3, 7, 16) + ((1,) if N == 512 else ()):
+        for M in (2, 3, 7, 16, 17, 29, 32, 33, 50, 64) + ((1,) if N == 512 else ()):
             x = (torch.randn(M, K, generator=g) / 10).half().to(DEV)
             xq, sx = scale_activations_per_token(x, qdt)
-            tun = (4, 0, 0, 0) if M == 1 else None
+            tun = (4, 0, 0, 0) if (M == 1 or M > 16) else None   # (forced: the x re-read rule sends 256 x 16384 at M > 21 elsewhere)
             name = _kernel_name(lin, xq, -1, tun or (0, 0, 0, 0))
-            assert name == "a8w8_rows_kernel<16x16>", (M, name)
+            assert name == ("a8w8_rows_kernel<16x16>" if M <= 16 else ("a8w8_rows_kernel<32x16>" if M <= 32 else "a8w8_rows_kernel<64x16>")), (M, name)
             y = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, tun)
             torch.cuda.synchronize()
             xq_o, sx_o = O.scale_activations_per_token(x, code)
@@ -578,7 +578,7 @@ def test_a8w8_rows_kernel(kind):
 
 @pytest.mark.parametrize("M", [1, 64])
 def test_fp8_e5m2_dynamic(M):
-    """e5m2 x e5m2 (FP8e5, dtype code 8): streaming kernel at M = 1, v_mfma_f32_32x32x16_bf8_bf8 at M = 64."""
+    """e5m2 x e5m2 (FP8e5, dtype code 8): streaming kernel at M = 1, v_mfma_f32_16x16x32_bf8_bf8 (16-column blocks, 4 row tiles) at M = 64."""
     torch.manual_seed(M + 9)
     W = (torch.randn(1024, 2048) / 30).half()
     lin = gemlite_amd.helper.A8W8_dynamic(device=DEV, dtype=torch.float16, fp8=torch.float8_e5m2).from_weights(W)

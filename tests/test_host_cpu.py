@@ -149,10 +149,15 @@ def test_struct_abi_and_validation():
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
     (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),  # A8W8 int8, 2..16 rows: 16-column blocks
     (dict(M=2, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),
-    (dict(M=17, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # then the 8-wave MFMA kernel
+    (dict(M=17, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<32x16>"),  # round 3: 2 / 4 row tiles while the x re-reads stay < 88 MB
+    (dict(M=32, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<32x16>"),
+    (dict(M=17, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<32x16>"),
+    (dict(M=32, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # ... then the 8-wave MFMA kernel
     (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 1, 0)), "gemm_a8w8_mma_kernel<32x128>"),
-    (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),
-    (dict(M=64, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),   # <= 64 rows: weights straight from memory
+    (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<64x16>"),
+    (dict(M=64, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<64x16>"),
+    (dict(M=64, N=8192, K=8192, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),   # <= 64 rows: weights straight from memory
+    (dict(M=65, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # fp8 x fp8, from 65 rows: both operands through LDS
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 0, 64)), "gemm_a8w8_mma_kernel<128x128>"),   # A/B switch
     (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),

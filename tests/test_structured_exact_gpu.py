@@ -118,11 +118,11 @@ WN_FAMILIES = [
     ("stream", 3, 8, (0, 0, 1, 0), "gemm_wn_stream_kernel"),
     ("mma32", 4, 29, (0, 1, 1, 0), "gemm_w{b}_mma_kernel<32x128>"),
     ("mma64_sk3", 4, 64, (0, 3, 2, 0), "gemm_w{b}_mma_kernel<64x128>"),
-    ("mma64_xch2", 4, 64, (0, 2, 2, 0), "gemm_w{b}_mma_kernel<64x128>"),
+    ("mma64_xch2", 4, 64, (0, 2, 2, 2048), "gemm_w{b}_mma_kernel<64x128>"),
     ("mma128_xch4", 4, 128, (0, 4, 4, 0), "gemm_w{b}_mma_kernel<128x128>"),
     ("mma128_ticket4", 4, 128, (0, 4, 4, 128), "gemm_w{b}_mma_kernel<128x128>"),
     ("mma256", 4, 256, (0, 1, 8, 0), "gemm_w{b}_mma_kernel<256x128>"),
-    ("mma256_xch2", 4, 256, (0, 2, 8, 0), "gemm_w{b}_mma_kernel<256x128>"),
+    ("mma256_xch2", 4, 256, (0, 2, 8, 2048), "gemm_w{b}_mma_kernel<256x128>"),
     ("mma_wide128_sk2", 4, 128, (0, 2, 20, 0), "gemm_w{b}_mma_kernel<128x256>"),
     ("mma_wide256", 4, 256, (0, 1, 24, 0), "gemm_w{b}_mma_kernel<256x256>"),
     ("auto_m2", -1, 2, (0, 0, 0, 0), ""),
@@ -202,6 +202,7 @@ def _coded_a8w8(N, K, kind, tdt):
 
 
 A8_FAMILIES = [("streaming", 1, (1, 0, 0, 0)), ("rows_m1", 1, (4, 0, 0, 0)), ("rows", 2, (0, 0, 0, 0)), ("rows", 16, (0, 0, 0, 0)),
+               ("rows32", 17, (0, 0, 0, 0)), ("rows32", 32, (0, 0, 0, 0)), ("rows64", 33, (0, 0, 0, 0)), ("rows64", 64, (4, 0, 0, 0)),
                ("mfma_r1", 64, (2, 0, 0, 0)), ("mma32", 29, (0, 1, 1, 0)), ("mma64_sk3", 64, (0, 3, 2, 0)),
                ("mma128", 128, (0, 1, 4, 0)), ("mma128_direct_b", 128, (0, 2, 4, 64)), ("mma256_sk5", 256, (0, 5, 8, 0)),
                ("auto_m1", 1, (0, 0, 0, 0)), ("auto_m100", 100, (0, 0, 0, 0)), ("auto_m256", 256, (0, 0, 0, 0))]
@@ -224,7 +225,8 @@ def test_a8w8_families_one_hot_times_position_coded_is_exact(kind, tdt):
         Y = _sweep(lambda x: _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, tuning), M, K, qdt)
         _exact(f"a8w8 {kind} {label} [{name}] {tdt}", Y, E)
         ran.append(name)
-    assert any("rows" in r for r in ran) and any("lds" in r or "mma" in r for r in ran), ran
+    assert {"a8w8_rows_kernel<16x16>", "a8w8_rows_kernel<32x16>", "a8w8_rows_kernel<64x16>"} <= set(ran), ran
+    assert any("lds" in r for r in ran) and any("mma" in r for r in ran), ran
 
 
 @pytest.mark.parametrize("tdt", TDTS, ids=IDS)
@@ -290,7 +292,7 @@ def test_mx_families_one_hot_is_exact(proc_name, M, tuning):
 @pytest.mark.parametrize("nbits", [4, 2])
 def test_reduce_scatter_combine_equals_the_ticket_combine_bit_for_bit(nbits, tdt):
     """8-wave MFMA kernel, K split S ways: peers write the row blocks they do not own into the owner's inbox and the owner adds
-    the copies in slice order (default when tiles x S fit one wave of resident blocks) — the same additions in the same order as
+    the copies in slice order (default from 4 slices on when tiles x S fit one wave of resident blocks; tuning[3] & 2048: with 2 too) — the same additions in the same order as
     the slab + ticket protocol (tuning[3] & 128).  Random data, ragged M, every (tile rows, S) pair, repeated calls on one
     workspace (the arrival counters must come back to zero)."""
     from oracle import gemlite_oracle as O
@@ -305,12 +307,12 @@ def test_reduce_scatter_combine_equals_the_ticket_combine_bit_for_bit(nbits, tdt
         x = torch.from_numpy(O.gen_x(M, K, seed=M + S).astype(np.float32)).to(tdt).to(DEV)
         meta = lin.get_meta_args()
         y_t = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, meta, 4, (0, S, mi, 128))
-        outs = [_hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, meta, 4, (0, S, mi, 0)) for _ in range(3)]
+        outs = [_hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, meta, 4, (0, S, mi, 2048)) for _ in range(3)]  # (2 slices: opt-in)
         # tuning[3] & 256: every block polls once and then hands its rows over (own partial into its inbox, "left" bit): the
         # peer that delivers last finishes them — or the block itself when everybody had delivered by then.  Same bits again,
         # and the arrival words are back at zero (the plain launches in between would otherwise miscount).
         outs += [_hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, meta, 4, (0, S, mi, 256)) for _ in range(3)]
-        outs += [_hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, meta, 4, (0, S, mi, 0))]
+        outs += [_hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, meta, 4, (0, S, mi, 2048))]
         torch.cuda.synchronize()
         for i, y in enumerate(outs):
             assert torch.equal(y, y_t), (mi, S, M, i, float((y.float() - y_t.float()).abs().max()))
