@@ -36,6 +36,7 @@ const void* kmajor_kernel_fn(int mb);
 const void* kmajor_w8a16_kernel_fn(int mb);
 const void* kmajor_fused_quant_kernel_fn(int qdt);
 const void* act_quant_kernel_fn();
+const void* act_quant_vec_kernel_fn(int in_dt, int out_dt, int64_t K, int64_t stride_xm, const void* x, const void* y);
 const void* pack_kernel_fn();
 const void* unpack_kernel_fn();
 
@@ -518,6 +519,11 @@ int gemlite_hip_scale_activations_per_token(const void* x, void* y, float* scale
     if (!(out_dtype == GEMLITE_DT_INT8 || out_dtype == GEMLITE_DT_FP8E4 || out_dtype == GEMLITE_DT_FP8E5)) return GEMLITE_ERR_UNSUPPORTED;
     if (M > 0x7FFFFFFF) return GEMLITE_ERR_BAD_SHAPE;
     int in_dt = in_dtype, out_dt = out_dtype;
+    if (const void* vec = act_quant_vec_kernel_fn(in_dt, out_dt, K, stride_xm, x, y)) {  // row in registers: one memory round trip
+        int k32 = (int)K;
+        void* vargs[] = {(void*)&x, (void*)&y, (void*)&scales, (void*)&k32, (void*)&stride_xm};
+        return launch(vec, dim3((unsigned)M, 1, 1), dim3(256, 1, 1), vargs, 0, (hipStream_t)stream);
+    }
     void* kargs[] = {(void*)&x, (void*)&y, (void*)&scales, (void*)&K, (void*)&stride_xm, (void*)&in_dt, (void*)&out_dt};
     return launch(act_quant_kernel_fn(), dim3((unsigned)M, 1, 1), dim3(256, 1, 1), kargs, 0, (hipStream_t)stream);
 }

@@ -338,6 +338,85 @@ __global__ __launch_bounds__(256) void act_quant_per_token_kernel(const void* x,
 }
 const void* act_quant_kernel_fn() { return (const void*)act_quant_per_token_kernel; }
 
+// Round 3: the same arithmetic with the row held in registers.  The kernel above walks a row with 2-byte loads, twice, one
+// element per thread and iteration — ~10 us for M = 16 .. 256 rows of 4096 (two chains of 16 dependent memory round trips); the
+// dynamic A8W8 processors (helper.py:420-500) pay that in front of EVERY matmul (same-method comparison with the reference on the
+// MI355X, profiles/r03/: int8 4096^2 M = 16 layer(x) 17.4 us of which the matmul is 7).  Here a thread loads R x 16 bytes of its row
+// once (R = K / 2048 <= 8), the block reduces |x| max through LDS, and the quantised bytes leave as 8-byte stores: one memory round
+// trip per row.  16-bit inputs, K % 8 == 0, K <= 16384, 16-byte aligned rows; anything else takes the kernel above.
+template <typename Tag, int ODT, int R>
+__global__ __launch_bounds__(256) void act_quant_per_token_vec_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y,
+                                                                     float* __restrict__ scales, int K, int64_t stride_xm) {
+    __shared__ float wmax[4];
+    const int64_t m = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint16_t* row = x + m * stride_xm;
+    u32x4 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = (r * 256 + tid) * 8;
+        v[r] = k < K ? *(const u32x4*)(row + k) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            amax = fmaxf(amax, fabsf(F16Traits<Tag>::to_float((uint16_t)(v[r][e >> 1] >> (16 * (e & 1))))));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if ((tid & 63) == 0) wmax[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    constexpr float qmin = ODT == GEMLITE_DT_INT8 ? -128.f : (ODT == GEMLITE_DT_FP8E4 ? -448.f : -57344.f);
+    constexpr float qmax = ODT == GEMLITE_DT_INT8 ? 127.f : (ODT == GEMLITE_DT_FP8E4 ? 448.f : 57344.f);
+    const float s = fmaxf(__fdiv_rn(amax, qmax), 1e-6f);
+    if (tid == 0) scales[m] = s;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = (r * 256 + tid) * 8;
+        if (k < K) {
+            uint32_t q[2] = {0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = F16Traits<Tag>::to_float((uint16_t)(v[r][e >> 1] >> (16 * (e & 1))));
+                const float t = fminf(fmaxf(__fdiv_rn(f, s), qmin), qmax);
+                uint32_t b;
+                if (ODT == GEMLITE_DT_INT8) b = (uint32_t)(uint8_t)(int8_t)floorf(t + 0.5f);
+                else if (ODT == GEMLITE_DT_FP8E4) b = float_to_fp8e4m3(t);
+                else b = float_to_fp8e5m2(t);
+                q[e >> 2] |= b << (8 * (e & 3));
+            }
+            *(u32x2*)(y + m * K + k) = (u32x2){q[0], q[1]};
+        }
+    }
+}
+typedef void (*act_quant_vec_fn)(const uint16_t*, uint8_t*, float*, int, int64_t);
+template <typename Tag, int ODT>
+static act_quant_vec_fn act_quant_vec_pick_r(int r) {
+    switch (r) {
+        case 1: return act_quant_per_token_vec_kernel<Tag, ODT, 1>;
+        case 2: return act_quant_per_token_vec_kernel<Tag, ODT, 2>;
+        case 4: return act_quant_per_token_vec_kernel<Tag, ODT, 4>;
+        default: return act_quant_per_token_vec_kernel<Tag, ODT, 8>;
+    }
+}
+// nullptr when the vector form does not apply
+const void* act_quant_vec_kernel_fn(int in_dt, int out_dt, int64_t K, int64_t stride_xm, const void* x, const void* y) {
+    if (!(in_dt == GEMLITE_DT_FP16 || in_dt == GEMLITE_DT_BF16) || K % 8 != 0 || K > 16384 || stride_xm % 8 != 0) return nullptr;
+    if (((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 8) != 0) return nullptr;
+    const int need = (int)((K + 2047) / 2048), r = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 8));
+    act_quant_vec_fn f = nullptr;
+    if (in_dt == GEMLITE_DT_FP16) {
+        f = out_dt == GEMLITE_DT_INT8 ? act_quant_vec_pick_r<half_tag, GEMLITE_DT_INT8>(r)
+            : (out_dt == GEMLITE_DT_FP8E4 ? act_quant_vec_pick_r<half_tag, GEMLITE_DT_FP8E4>(r) : act_quant_vec_pick_r<half_tag, GEMLITE_DT_FP8E5>(r));
+    } else {
+        f = out_dt == GEMLITE_DT_INT8 ? act_quant_vec_pick_r<bf16_tag, GEMLITE_DT_INT8>(r)
+            : (out_dt == GEMLITE_DT_FP8E4 ? act_quant_vec_pick_r<bf16_tag, GEMLITE_DT_FP8E4>(r) : act_quant_vec_pick_r<bf16_tag, GEMLITE_DT_FP8E5>(r));
+    }
+    return (const void*)f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // bit packing along K, output transposed [K/e, N]  (layout spec: gemlite/bitpack.py:36-60 + core.py:384-398)
 // thread = one packed word; consecutive threads = consecutive n (coalesced stores; the uint8 reads of a

@@ -265,6 +265,29 @@ def test_a8w8_int8_dynamic_is_exact(M):
     assert np.array_equal(xq_g.cpu().numpy().astype(np.float64), xq) and np.array_equal(sx_g.cpu().numpy(), sx)
 
 
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16, torch.float32], ids=["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("qdt", [torch.int8, torch.float8_e4m3fn, torch.float8_e5m2], ids=["int8", "e4m3", "e5m2"])
+def test_activation_quantiser_register_and_fallback_paths_are_bit_exact(qdt, tdt):
+    """Per-token quantiser (quant_utils.py:231-305): the row-in-registers kernel (16-bit x, K % 8 == 0, K <= 16384: 1 / 2 / 4 / 8
+    16-byte loads per thread, ragged last load) and the scalar kernel everything else takes (fp32 x, K % 8 != 0, K > 16384, rows
+    that are not 16-byte aligned) — codes and scales bit for bit against the oracle, rows of a strided view, an all-zero row, an
+    outlier row."""
+    code = {torch.int8: O.INT8, torch.float8_e4m3fn: O.FP8E4, torch.float8_e5m2: O.FP8E5}[qdt]
+    g = torch.Generator().manual_seed(17)
+    for K in (8, 64, 100, 2040, 2048, 2056, 4096, 11008, 16384, 16392):
+        for M in (1, 5, 67):
+            wide = (torch.randn(M, K + 24, generator=g) * torch.rand(M, 1, generator=g) * 4).to(tdt)
+            if M > 1:
+                wide[1] = 0
+                wide[2, K // 2] = 900.0
+            for x in (wide[:, :K].contiguous(), wide[:, :K], wide[:, 4:K + 4]):   # contiguous | row stride K + 24 | + rows off 16-byte alignment
+                xq, sx = scale_activations_per_token(x.to(DEV) if x.is_contiguous() else wide.to(DEV)[:, x.storage_offset() % (K + 24):][:, :K], qdt)
+                torch.cuda.synchronize()
+                xq_o, sx_o = O.scale_activations_per_token(x.contiguous(), code)
+                assert np.array_equal(sx.cpu().numpy().reshape(-1), sx_o.reshape(-1)), (K, M, "scales")
+                assert np.array_equal(O.to_f64(xq), xq_o), (K, M, tuple(x.stride()), "codes")
+
+
 @pytest.mark.parametrize("M", [1, 16, 200])
 def test_fp8_fp8_dynamic(M):
     torch.manual_seed(M + 5)
