@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void act_quant_mx_kernel(const void* x, uint8_
 #pragma unroll
         for (int e = 0; e < G; ++e) v[e] = 0.f;
     }
-    float s;
+    float s, rinv = 1.f;
+    bool use_mul = false;
     if (MODE == 2) {
         const float s32 = fminf(__fdiv_rn(amax, 0.3f), 448.f);  // 6 * 0.05 folded to the fp32 constant 0.3f
         const uint8_t s8 = float_to_fp8e4m3(s32);
@@ -95,16 +96,24 @@ __global__ __launch_bounds__(256) void act_quant_mx_kernel(const void* x, uint8_
         ex = ex > 254 ? 254 : (ex < 97 ? 97 : ex);
         scales[idx] = (uint8_t)ex;
         s = __builtin_bit_cast(float, (uint32_t)ex << 23);
+        // (round 3) x / 2^k == x * 2^-k bit for bit — one exact real value, one rounding — so the IEEE division (~12 VALU per
+        // element) becomes a multiplication whenever 2^-k is a normal float (ex <= 253; 254 keeps the division)
+        rinv = __builtin_bit_cast(float, (uint32_t)(254 - (ex > 253 ? 253 : ex)) << 23);
+        use_mul = ex <= 253;
     }
     if (m >= M) return;
     if (MODE == 0) {
         uint32_t o[8];
+        // hardware e4m3 converter (RNE, subnormals kept; the clamp keeps it away from overflow): two values per instruction
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const float q = fminf(fmaxf(__fdiv_rn(v[e], s), -448.f), 448.f);
-            const uint32_t b = float_to_fp8e4m3(q);
-            if ((e & 3) == 0) o[e >> 2] = b;
-            else o[e >> 2] |= b << (8 * (e & 3));
+        for (int e4 = 0; e4 < 8; ++e4) {
+            float q[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                q[t] = fminf(fmaxf(use_mul ? v[4 * e4 + t] * rinv : __fdiv_rn(v[4 * e4 + t], s), -448.f), 448.f);
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true);
+            o[e4] = (uint32_t)w;
         }
         u32x4* dst = (u32x4*)(y + m * K + g * 32);
         dst[0] = (u32x4){o[0], o[1], o[2], o[3]};
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256) void act_quant_mx_kernel(const void* x, uint8_
         uint32_t o[G / 8];
 #pragma unroll
         for (int e = 0; e < G; ++e) {
-            const float q = __fdiv_rn(v[e], s), a = fabsf(q);
+            const float q = (MODE == 1 && use_mul) ? v[e] * rinv : __fdiv_rn(v[e], s), a = fabsf(q);
             uint32_t c = (a > 0.25f) + (a > 0.75f) + (a > 1.25f) + (a > 1.75f) + (a > 2.5f) + (a > 3.5f) + (a > 5.0f) + (a > 7.0f);
             if (!(q >= 0.f)) c += 8u;
             // byte = lo | (hi << 4) in uint8 arithmetic, like the reference's pack (quant_utils.py:805-806): a code above 15 —
