@@ -25,6 +25,10 @@ CASES = {
 bench.WORKLOADS.update({"a16w2_8192_m1": (8192, 8192, 2, 128, 1, "fp16", 16, "hbm"), "a16w2_4096_m1": (4096, 4096, 2, 128, 1, "fp16", 32, "hbm"), "a16w2_11008_m1": (11008, 4096, 2, 128, 1, "fp16", 24, "hbm"), "a16w4_11008n_m1": (11008, 4096, 4, 128, 1, "fp16", 12, "hbm")})
 bench.WORKLOADS.update({"a16w4_4096_m2": (4096, 4096, 4, 128, 2, "fp16", 32, "hbm"), "a16w4_4096_m4": (4096, 4096, 4, 128, 4, "fp16", 32, "hbm"), "a16w4_8192_m4": (8192, 8192, 4, 128, 4, "fp16", 8, "hbm")})
 only = [a for a in sys.argv[1:] if not a.startswith("-")]
+bench.WORKLOADS.update({"a16w4_8192_m16": (8192, 8192, 4, 128, 16, "fp16", 8, "hbm"), "a16w4_4096_m32": (4096, 4096, 4, 128, 32, "fp16", 32, "hbm")})
+for a in only:   # any bench workload can be named; it gets the default list unless --tunings is given
+    if a not in CASES and a in bench.WORKLOADS:
+        CASES[a] = [(0, 0, 0, 0)]
 for a in sys.argv[1:]:   # --tunings='[[22,0,0,1024],[24,0,8,1024]]' replaces the list of every selected case
     if a.startswith("--tunings="):
         for k in CASES:
