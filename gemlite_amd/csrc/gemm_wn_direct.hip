@@ -65,8 +65,11 @@ __device__ __forceinline__ uint16_t dir_meta(const typename DirVec<V>::M& m, int
 }
 
 // SPG = MFMA k-steps (32 k each) between two applications of scale / zero: 4 (group >= 128), 2 (64), 1 (32)
-template <typename Tag, int NBITS, int V, int MT, int SPG>
-__global__ __launch_bounds__(256, 1) void gemm_wn_direct_kernel(const WnParams p) {
+// NW = waves per block (round 3): 4 = one wave per SIMD with two pieces of K in flight (round 1); 8 = two per SIMD, each with half
+// the K range — at 4096^2 every wave then has its WHOLE K range in flight from the start and the unpack / MFMA issue of one wave
+// overlaps the other's waits (the 4-wave kernel spends ~2 us of its 8.4 us at M = 16 issuing ~1000 VALU per wave one after the other)
+template <typename Tag, int NBITS, int V, int MT, int SPG, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 1) void gemm_wn_direct_kernel(const WnParams p) {
     using TR = F16Traits<Tag>;
     using DW = DirWin<Tag, NBITS>;
     using WT = typename DirVec<V>::W;
@@ -78,12 +81,12 @@ __global__ __launch_bounds__(256, 1) void gemm_wn_direct_kernel(const WnParams p
     constexpr int U = KS / NF;            // row-steps (4 packed rows, one per lane quarter) per wave and piece
     constexpr int NGRP = KS / SPG;        // metadata rows per wave and piece
     constexpr int BM = 16 * MT, TN = 16 * V;
-    constexpr int ROWS_WP = 4 * U, ROWS_PIECE = 4 * ROWS_WP;
+    constexpr int ROWS_WP = 4 * U, ROWS_PIECE = NW * ROWS_WP, NT = NW * 64;
     static_assert(E >= 8 && U >= 1 && NGRP >= 1 && SPG % NF == 0, "unsupported geometry");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red = (float*)smem;  // [4][BM][TN]
-    unsigned* flag = (unsigned*)(smem + (size_t)4 * BM * TN * 4);
+    float* red = (float*)smem;  // [NW][BM][TN]
+    unsigned* flag = (unsigned*)(smem + (size_t)NW * BM * TN * 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -93,6 +96,15 @@ __global__ __launch_bounds__(256, 1) void gemm_wn_direct_kernel(const WnParams p
     const int row_s0 = slice * p.rows_per_slice;
     const int npieces = p.rows_per_slice / ROWS_PIECE;
 
+#ifdef GL_DIRECT_TIMELINE  // development build only (scripts/timeline_direct.py): wave 0 of every block stamps the 100 MHz clock
+    const int lin_blk = tile + gridDim.x * (slice + gridDim.y * mtile);
+    const bool probe = (p.flags & 4) && p.counters && wave == 0 && lane == 0 && lin_blk < 512;
+    unsigned long long* stamps = (unsigned long long*)(p.counters + MAX_SPLITK_COUNTERS) + lin_blk * 8;
+    auto stamp = [&](int i) { if (probe) stamps[i] = __builtin_amdgcn_s_memrealtime(); };
+#else
+    auto stamp = [](int) {};
+#endif
+    stamp(0);
     const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
     const uint16_t* sp = need_s ? (const uint16_t*)p.scales : (const uint16_t*)p.w;  // dummy source keeps the
     const uint16_t* zp = need_z ? (const uint16_t*)p.zeros : (const uint16_t*)p.w;   // loop free of branches
@@ -231,9 +243,14 @@ __global__ __launch_bounds__(256, 1) void gemm_wn_direct_kernel(const WnParams p
 #pragma unroll
             for (int t = 0; t < MT; ++t) A.x[u][q][t] = B.x[u][q][t] = (u32x4){0u, 0u, 0u, 0u};  // rows >= M stay zero
     pipeline2_prime(npieces, A, B, load_piece);
-    pipeline2_run(npieces, A, B, load_piece, compute);
+    stamp(1);
+    pipeline2_run(npieces, A, B, load_piece, [&](const Piece& pc, int i) {
+        compute(pc, i);
+        if (i == 0) stamp(2);
+    });
+    stamp(3);
 
-    // ---- combine the 4 waves (disjoint K) through LDS ------------------------------------------------------
+    // ---- combine the NW waves (disjoint K) through LDS ------------------------------------------------------
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -243,35 +260,40 @@ __global__ __launch_bounds__(256, 1) void gemm_wn_direct_kernel(const WnParams p
             for (int j = 0; j < V; ++j) red[(wave * BM + row) * TN + c * V + j] = tot[t][j][rg];
         }
     __syncthreads();
-    constexpr int NOUT = BM * TN, OPT = NOUT / 256;
+    stamp(4);
+    constexpr int NOUT = BM * TN, OPT = NOUT / NT;
+    static_assert(NOUT % NT == 0 && OPT >= 1, "every thread owns OPT outputs of the tile");
     float part[OPT];
 #pragma unroll
     for (int it = 0; it < OPT; ++it) {
-        const int o = tid + it * 256;
+        const int o = tid + it * NT;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[w * NOUT + o];
+        for (int w = 0; w < NW; ++w) v += red[w * NOUT + o];
         part[it] = v;
     }
     const int tile_lin = mtile * gridDim.x + tile;
     if (p.splitk == 1) {
 #pragma unroll
         for (int it = 0; it < OPT; ++it) {
-            const int o = tid + it * 256, m = m0 + o / TN;
+            const int o = tid + it * NT, m = m0 + o / TN;
             if (m < p.M) store_out_t<Tag>(p.epi, part[it], m, (int64_t)tile * TN + (o % TN));
         }
+        stamp(5);
         return;
     }
     float* slab = p.slabs + ((int64_t)tile_lin * p.splitk) * NOUT;
 #pragma unroll
     for (int it = 0; it < OPT; ++it) {  // only rows that exist travel through the slabs
-        const int o = tid + it * 256;
+        const int o = tid + it * NT;
         if (m0 + o / TN < p.M) slab_store(slab + (int64_t)slice * NOUT + o, part[it]);
     }
+    stamp(5);
     if (!splitk_arrive_is_last(p.counters + tile_lin, p.splitk, flag)) return;
+    stamp(6);
 #pragma unroll
     for (int it = 0; it < OPT; ++it) {
-        const int o = tid + it * 256, m = m0 + o / TN;
+        const int o = tid + it * NT, m = m0 + o / TN;
         if (m < p.M) {
             float v = 0.f;
             for (int s = 0; s < p.splitk; ++s) v += slab_load(slab + (int64_t)s * NOUT + o);
@@ -279,45 +301,51 @@ __global__ __launch_bounds__(256, 1) void gemm_wn_direct_kernel(const WnParams p
         }
     }
     if (tid == 0) splitk_reset(p.counters + tile_lin);
+    stamp(7);
 }
 
 // ---------------------------------------------------------------------------------------------
 template <typename Tag, int NBITS, int V, int MT>
-static const void* dpick_spg(int spg) {
+static const void* dpick_spg(int spg, int nw) {
     // group size 64 (two metadata rows per 128 k) fits the 512-VGPR budget for one row tile only (M <= 16);
     // group size 32 and 17..32 rows at group size 64 stay with the LDS-staged streaming kernel
-    if (spg == 4) return (const void*)gemm_wn_direct_kernel<Tag, NBITS, V, MT, 4>;
+    if (spg == 4) {
+        if constexpr (V >= 2 && MT == 1) {  // 8 waves: 16 x 16 V outputs over 512 threads; two row tiles spill at 256 registers per wave
+            if (nw == 8) return (const void*)gemm_wn_direct_kernel<Tag, NBITS, V, MT, 4, 8>;
+        }
+        return nw == 4 ? (const void*)gemm_wn_direct_kernel<Tag, NBITS, V, MT, 4> : nullptr;
+    }
     if constexpr (MT == 1) {
-        if (spg == 2) return (const void*)gemm_wn_direct_kernel<Tag, NBITS, V, 1, 2>;
+        if (spg == 2 && nw == 4) return (const void*)gemm_wn_direct_kernel<Tag, NBITS, V, 1, 2>;
     }
     return nullptr;
 }
 template <typename Tag, int NBITS, int V>
-static const void* dpick_mt(int mt, int spg) {
-    if (mt == 1) return dpick_spg<Tag, NBITS, V, 1>(spg);
-    if constexpr (V >= 2) { if (mt == 2) return dpick_spg<Tag, NBITS, V, 2>(spg); }
+static const void* dpick_mt(int mt, int spg, int nw) {
+    if (mt == 1) return dpick_spg<Tag, NBITS, V, 1>(spg, nw);
+    if constexpr (V >= 2) { if (mt == 2) return dpick_spg<Tag, NBITS, V, 2>(spg, nw); }
     return nullptr;
 }
 template <typename Tag, int NBITS>
-static const void* dpick_v(int v, int mt, int spg) {
+static const void* dpick_v(int v, int mt, int spg, int nw) {
     switch (v) {
-        case 1: return dpick_mt<Tag, NBITS, 1>(mt, spg);
-        case 2: return dpick_mt<Tag, NBITS, 2>(mt, spg);
-        case 4: return dpick_mt<Tag, NBITS, 4>(mt, spg);
+        case 1: return dpick_mt<Tag, NBITS, 1>(mt, spg, nw);
+        case 2: return dpick_mt<Tag, NBITS, 2>(mt, spg, nw);
+        case 4: return dpick_mt<Tag, NBITS, 4>(mt, spg, nw);
         default: return nullptr;
     }
 }
 template <typename Tag>
-static const void* dpick_bits(int nbits, int v, int mt, int spg) {
+static const void* dpick_bits(int nbits, int v, int mt, int spg, int nw) {
     switch (nbits) {
-        case 2: return dpick_v<Tag, 2>(v, mt, spg);
-        case 4: return dpick_v<Tag, 4>(v, mt, spg);
+        case 2: return dpick_v<Tag, 2>(v, mt, spg, nw);
+        case 4: return dpick_v<Tag, 4>(v, mt, spg, nw);
         default: return nullptr;
     }
 }
 
 // tuning[0]: 0 auto | 1, 2, 4 force the words-per-lane V (16 V columns per block)
-// tuning[1]: 0 auto | n force split-K n
+// tuning[1]: 0 auto | n force split-K n;  tuning[2]: 0 auto | 4 / 8 waves per block (8: one row tile, >= 32-column tiles, K slice of whole 8-wave pieces)
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
     const int nbits = a.W_nbits;
     if (nbits != 2 && nbits != 4) return false;
@@ -343,7 +371,8 @@ bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     const int bm = 16 * mt;
     const int mtiles = (int)((a.M + bm - 1) / bm);
     const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
-    auto fn_of = [&](int v) { return f16 ? dpick_bits<half_tag>(nbits, v, mt, spg) : dpick_bits<bf16_tag>(nbits, v, mt, spg); };
+    auto fn_nw = [&](int v, int nw) { return f16 ? dpick_bits<half_tag>(nbits, v, mt, spg, nw) : dpick_bits<bf16_tag>(nbits, v, mt, spg, nw); };
+    auto fn_of = [&](int v) { return fn_nw(v, 4); };
     auto fits = [&](int v) { return a.N % (16 * v) == 0 && a.K % (2048 / v) == 0 && fn_of(v) != nullptr; };
     int v = 0, force_sk = 0;
     if (a.tuning[0] == 1 || a.tuning[0] == 2 || a.tuning[0] == 4) {
@@ -363,6 +392,14 @@ bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         // (4096 x 4096, M = 16: 7.9 us vs 8.9 us) although they pay the cross-block combine.
         if (v == 1 && a.M >= 8 && a.tuning[1] == 0 && fits(2) && (a.K / 1024) % 2 == 0 && (a.N / 32) * mtiles * 2 >= 256) {
             v = 2;
+            force_sk = 2;
+        }
+        // round 3 (profiles/r03/probe_fewrows_llm_shapes.log): the same step from 32- to 64-column tiles where 64-column tiles x 2
+        // slices still fill the chip — with 8 waves per block: 8192^2 M = 8 / 16 11.9 / 13.7 -> 10.7 / 12.3 us, 8192 x 28672 27.1 / 35.2
+        // -> 23.3 / 24.5; N = 6144 (192 blocks) loses (7.8 / 8.9 -> 8.0 / 9.8) and keeps the unsplit 32-column tiles
+        else if (v == 2 && mt == 1 && a.M >= 8 && a.tuning[1] == 0 && a.tuning[2] == 0 && fits(4) && a.K % 2048 == 0 && (a.N / 64) * 2 >= 256 &&
+                 fn_nw(4, 8) != nullptr) {
+            v = 4;
             force_sk = 2;
         }
     }
@@ -386,11 +423,20 @@ bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     if (splitk > 1 && ntl > (uint64_t)MAX_SPLITK_COUNTERS) return false;
     p.splitk = splitk;
     p.rows_per_slice = (int)(a.K / e) / splitk;
-    lp.fn = fn_of(v);
-    lp.name = v == 1 ? "gemm_wn_direct_kernel<tile16>" : (v == 2 ? "gemm_wn_direct_kernel<tile32>" : "gemm_wn_direct_kernel<tile64>");
+    // waves per block: tuning[2] = 4 / 8 forces; 8 needs a K slice of whole 8-wave pieces (4096 / V k) and V >= 2
+    int nw = 4;
+    const bool nw8_ok = fn_nw(v, 8) != nullptr && (a.K / splitk) % (4096 / v) == 0;
+    if (a.tuning[2] == 8) { if (!nw8_ok) return false; nw = 8; }
+    // default: with two K slices (4096^2 M = 8 / 16, 32-column tiles x 2: 7.1 / 8.3 -> 6.6 / 7.4 us; the 8192-wide shapes above);
+    // unsplit tiles are a wash (N = 14336: 9.8 / 11.8 -> 9.5 / 10.3, N = 28672: 22.8 / 25.6 -> 23.9 / 27.2) and keep 4 waves
+    else if (a.tuning[2] != 4 && nw8_ok && splitk == 2) nw = 8;
+    lp.fn = fn_nw(v, nw);
+    static const char* names[2][3] = {{"gemm_wn_direct_kernel<tile16>", "gemm_wn_direct_kernel<tile32>", "gemm_wn_direct_kernel<tile64>"},
+                                      {"gemm_wn_direct_kernel<tile16,8w>", "gemm_wn_direct_kernel<tile32,8w>", "gemm_wn_direct_kernel<tile64,8w>"}};
+    lp.name = names[nw == 8][v == 1 ? 0 : (v == 2 ? 1 : 2)];
     lp.grid = dim3(tiles, splitk, mtiles);
-    lp.block = dim3(256, 1, 1);
-    lp.lds_bytes = (size_t)4 * bm * 16 * v * 4 + 16;
+    lp.block = dim3(nw * 64, 1, 1);
+    lp.lds_bytes = (size_t)nw * bm * 16 * v * 4 + 16;
     lp.slab_bytes = splitk > 1 ? ntl * splitk * bm * 16 * v * 4 : 0;
     lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
     return true;

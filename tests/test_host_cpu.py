@@ -95,8 +95,11 @@ def test_struct_abi_and_validation():
     (dict(M=4), "gemv_mfma_kernel<tile16,rows4>"),
     (dict(M=4, tuning=(0, 0, 0, 512)), "gemm_wn_direct_kernel<tile16>"),   # 2 <= M <= 32: registers-only MFMA kernel, K not split
     (dict(M=5), "gemm_wn_direct_kernel<tile16>"),
-    (dict(M=8), "gemm_wn_direct_kernel<tile32>"),     # >= 8 rows: 32-column tiles x split-K 2 (less x traffic)
-    (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile32>"),
+    (dict(M=8), "gemm_wn_direct_kernel<tile32,8w>"),     # >= 8 rows: 32-column tiles x split-K 2 (less x traffic), round 3: 8 waves per block
+    (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile64,8w>"),   # ... 64-column tiles x 2 where they still fill the chip
+    (dict(M=8, N=6144, K=4096), "gemm_wn_direct_kernel<tile32>"),      # 192 blocks of 32 columns, unsplit: 4 waves
+    (dict(M=8, tuning=(0, 0, 4, 0)), "gemm_wn_direct_kernel<tile32>"),   # tuning[2] = 4 / 8: waves per block
+    (dict(M=7), "gemm_wn_direct_kernel<tile16>"),
     (dict(M=16, N=16384, K=16384), "gemm_wn_direct_kernel<tile64>"),
     (dict(M=24, N=16384, K=16384), "gemm_w4_mma_kernel<32x128>"),   # 17..32 rows over K >= 8192: LDS-staged x wins
     (dict(M=8, tuning=(0, 0, 1, 0)), "gemm_wn_stream_kernel"),  # tuning[2] = 1: LDS-staged streaming kernel
@@ -131,7 +134,7 @@ def test_struct_abi_and_validation():
     (dict(M=1, N=11008, K=4096), "gemv_wn_kernel<tile32>"),   # 4-bit, 32-column tiles over a short K: the dot-product family (8.9 vs 9.3)
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64,8w>"),   # 2-bit, long K: two waves per SIMD
-    (dict(M=16), "gemm_wn_direct_kernel<tile32>"),
+    (dict(M=16), "gemm_wn_direct_kernel<tile32,8w>"),
     (dict(M=1, mt=4), "gemm_w4_mma_kernel<32x128>"),   # manual GEMM family at M=1 -> the tiled MFMA kernel
     (dict(M=128), "gemm_w4_mma_kernel<64x128>"),
     (dict(M=256), "gemm_w4_mma_kernel<64x128>"),       # cfgA: 128 tiles x 2 K slices (18.6 us vs 30.4 for 256-row tiles x 8)

@@ -115,6 +115,8 @@ WN_FAMILIES = [
     ("direct16", 3, 13, (1, 0, 0, 0), "gemm_wn_direct_kernel"),
     ("direct32", 3, 16, (2, 0, 0, 0), "gemm_wn_direct_kernel"),
     ("direct64_sk2", 3, 32, (4, 2, 0, 0), "gemm_wn_direct_kernel"),
+    ("direct32_8w", 3, 16, (2, 1, 8, 0), "gemm_wn_direct_kernel<tile32,8w>"),
+    ("direct64_8w_sk2", 3, 13, (4, 2, 8, 0), "gemm_wn_direct_kernel<tile64,8w>"),
     ("stream", 3, 8, (0, 0, 1, 0), "gemm_wn_stream_kernel"),
     ("mma32", 4, 29, (0, 1, 1, 0), "gemm_w{b}_mma_kernel<32x128>"),
     ("mma64_sk3", 4, 64, (0, 3, 2, 0), "gemm_w{b}_mma_kernel<64x128>"),
@@ -159,7 +161,7 @@ def test_packed_weight_families_one_hot_times_position_coded_is_exact(nbits, fma
     if nbits in (4, 2):
         must |= {"gemv_mfma16", "gemv_mfma32", "mma64_xch2", "mma128_xch4", "mma_wide256"}
         if K == 2048:
-            must |= {"direct16", "direct32", "direct64_sk2", "stream"}
+            must |= {"direct16", "direct32", "direct64_sk2", "direct32_8w", "direct64_8w_sk2", "stream"}
     assert must <= set(ran), (sorted(must - set(ran)), ran)
 
 
