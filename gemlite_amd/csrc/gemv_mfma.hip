@@ -399,8 +399,11 @@ bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& 
     if (a.tuning[0] == 21 || a.tuning[0] == 22 || a.tuning[0] == 24) v = a.tuning[0] - 20;
     else if (a.tuning[0] != 0) return false;  // the dot-product family's tile codes (2 / 3 / 4)
     else {
+        // round 3 sweep (profiles/r03/probe_m1_llm_shapes_*.log): for 4-bit decode fewer, wider blocks win — 160 blocks, 128 over a
+        // short K (8960 x 1536: 64-column tiles 5.1 vs 8.1 us for 32-column ones; 6144 x 4096: 32-column 5.6 vs 8.1 for 16-column)
+        const int64_t want_blocks = (a.W_nbits == 4 && a.M == 1) ? (a.K <= 2048 ? 128 : 160) : 256;
         for (int cand : {4, 2, 1})
-            if (a.N % (16 * cand) == 0 && a.N / (16 * cand) >= 256) { v = cand; break; }
+            if (a.N % (16 * cand) == 0 && a.N / (16 * cand) >= want_blocks) { v = cand; break; }
         if (!v) return false;  // narrower matrices: the K-splitting kernels
     }
     if (a.N % (16 * v) != 0) return false;

@@ -809,9 +809,15 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
     if (force >= 2 && force <= 4) return try_plan(force, sk);
     // auto (measured, profiles/r01_*): the widest tile that still gives >= 256 blocks WITHOUT splitting K wins —
     // 256-byte row segments stream best, 64-byte ones worst, but any in-launch split-K combine costs ~3 us.
-    if (a.N % 64 == 0 && a.N / 64 >= 256 && try_plan(4, sk > 0 ? sk : 1)) return true;
-    if (a.N % 32 == 0 && a.N / 32 >= 256 && try_plan(3, sk > 0 ? sk : 1)) return true;
-    if (a.N % 16 == 0 && a.N / 16 >= 256 && try_plan(2, sk > 0 ? sk : 1)) return true;
+    // Round 3 (4-bit, 22 LLM layer shapes x every tile / slice combination, profiles/r03/probe_m1_llm_shapes_*.log): 160 blocks are
+    // enough — 5120^2 32-column tiles 7.6 vs 8.9 us for 16-column ones, 5120 x 13824 13.6 vs 18.3, N = 11008 .. 14336 over K = 4096
+    // 64-column tiles 8.5 .. 8.9 vs 9.0 .. 9.3 — and narrow matrices (N < 2048) want 16-column tiles UNSPLIT on the decode kernel
+    // (1024 x 4096: 4.5 vs 7.4 us, 1536 x 8960: 7.5 vs 9.4) rather than 32-column tiles with K slices.
+    const int64_t want_blocks = nbits == 4 ? 160 : 256;
+    if (nbits == 4 && sk == 0 && a.N < 2048 && a.K <= 12288 && try_plan(2, 1)) return true;
+    if (a.N % 64 == 0 && a.N / 64 >= want_blocks && try_plan(4, sk > 0 ? sk : 1)) return true;
+    if (a.N % 32 == 0 && a.N / 32 >= want_blocks && try_plan(3, sk > 0 ? sk : 1)) return true;
+    if (a.N % 16 == 0 && a.N / 16 >= want_blocks && try_plan(2, sk > 0 ? sk : 1)) return true;
     if (try_plan(3, sk)) return true;
     if (try_plan(4, sk)) return true;
     return try_plan(2, sk);

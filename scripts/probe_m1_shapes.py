@@ -1,0 +1,42 @@
+"""M = 1 (decode) of A16W4 g128 over LLM layer shapes: the planner's choice against (tile width, K slices) candidates of the
+dot-product GEMV family and the MFMA GEMV — graph-replayed us per launch, HBM-cold rotating layers.
+    python scripts/probe_m1_shapes.py [M]"""
+import json, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import gemlite_amd.core as core
+from gemlite_amd import _hip
+
+lib = _hip.load()
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+SHAPES = [(1536, 8960), (8960, 1536), (2048, 8192), (8192, 2048), (2560, 9728), (3072, 8192), (8192, 3072), (5120, 5120), (5120, 13824), (13824, 5120),
+          (6144, 4096), (4096, 4096), (4096, 14336), (14336, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (8192, 8192), (8192, 28672), (28672, 8192), (1024, 4096), (4096, 1024)]
+CANDS = [(0, 0, 0, 0)] + [(t, sk, 0, 512) for t in (2, 3, 4) for sk in (1, 2, 4)] + [(t, 0, 0, 1024) for t in (21, 22, 24)]
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+for (N, K) in SHAPES:
+    name = f"a16w4_{N}x{K}_m{M}"
+    nl = max(2, min(32, int(300e6 // (N * K // 2))))
+    bench.WORKLOADS[name] = (N, K, 4, 128, M, "fp16", nl, "hbm")
+    res = {}
+    for rep, t in enumerate([(0, 0, 0, 0)] + CANDS):   # the first run of a shape warms the allocator / clocks: the default is timed twice
+        core.TUNING_OVERRIDE = t if any(t) else None
+        try:
+            r = bench.Runner(name, dev, lib)
+            kn = r.kernel_name()
+            c_us, n, el = r.chained_us_per_launch(min_seconds=0.08)
+            if rep > 0:
+                res[str(t)] = (round(c_us, 2), kn)
+            del r
+        except Exception as e:
+            if rep > 0:
+                res[str(t)] = (None, str(e)[:50])
+        finally:
+            core.TUNING_OVERRIDE = None
+        torch.cuda.empty_cache()
+    ok = {k: v for k, v in res.items() if v[0] is not None}
+    best = min(ok, key=lambda k: ok[k][0])
+    print(json.dumps(dict(N=N, K=K, M=M, default=res["(0, 0, 0, 0)"], best=[best, ok[best][0], ok[best][1]], gain=round(res["(0, 0, 0, 0)"][0] / ok[best][0], 3),
+                          all={k: v[0] for k, v in res.items()})), flush=True)

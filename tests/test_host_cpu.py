@@ -120,7 +120,13 @@ def test_struct_abi_and_validation():
     # K = 11008 / 8960 (Llama-2-7B down_proj, Qwen2.5-1.5B): specialised kernels at every M, never the coverage kernel
     (dict(M=1, N=4096, K=11008), "gemv_w4_decode_kernel<tile16,16w>"),
     (dict(M=1, N=4096, K=11008, gs=64), "gemv_w4_decode_kernel<tile16,16w>"),
-    (dict(M=1, N=1536, K=8960), "gemv_wn_kernel<tile32>"),
+    (dict(M=1, N=1536, K=8960), "gemv_w4_decode_kernel<tile16,16w>"),   # round 3: narrow N -> 16-column tiles unsplit (7.5 vs 9.4 us)
+    (dict(M=1, N=1024, K=4096), "gemv_w4_decode_kernel<tile16,16w>"),
+    (dict(M=1, N=5120, K=5120), "gemv_wn_kernel<tile32>"),              # 160 blocks are enough (7.6 vs 8.9 us for 320 blocks of 16 columns)
+    (dict(M=1, N=14336, K=4096), "gemv_wn_kernel<tile64>"),
+    (dict(M=1, N=6144, K=4096), "gemv_mfma_kernel<tile32>"),            # MFMA GEMV on 6144 <= N <= 12288, K <= 8192
+    (dict(M=1, N=8960, K=1536), "gemv_mfma_kernel<tile64>"),
+    (dict(M=1, N=8192, K=28672), "gemv_mfma_kernel<tile32>"),
     (dict(M=4, N=4096, K=11008), "gemv_mfma_kernel<tile16,rows4>"),
     (dict(M=8, N=4096, K=11008), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=32, N=4096, K=11008, gs=64), "gemm_w4_mma_kernel<32x128>"),
@@ -131,7 +137,8 @@ def test_struct_abi_and_validation():
     (dict(M=256, N=4096, K=11008), "gemm_w4_mma_kernel<128x128>"),   # block-time model: 128 rows x 4 slices (40.5 vs 42.3 us for 64 x 2)
     (dict(M=1, nbits=2), "gemv_w2_mfma_kernel<tile16>"),   # 2-bit decode on the matrix core up to 32-column tiles (4.4 vs 4.9 us)
     (dict(M=1, nbits=2, tuning=(0, 0, 0, 512)), "gemv_wn_kernel<tile16>"),
-    (dict(M=1, N=11008, K=4096), "gemv_wn_kernel<tile32>"),   # 4-bit, 32-column tiles over a short K: the dot-product family (8.9 vs 9.3)
+    (dict(M=1, N=11008, K=4096), "gemv_mfma_kernel<tile64>"),   # round 3: 64-column tiles (172 blocks) on the MFMA GEMV: 7.9 vs 8.5 / 9.0 us
+    (dict(M=1, N=11008, K=4096, tuning=(0, 0, 0, 512)), "gemv_wn_kernel<tile64>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64,8w>"),   # 2-bit, long K: two waves per SIMD
     (dict(M=16), "gemm_wn_direct_kernel<tile32,8w>"),
