@@ -813,11 +813,20 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
     // enough — 5120^2 32-column tiles 7.6 vs 8.9 us for 16-column ones, 5120 x 13824 13.6 vs 18.3, N = 11008 .. 14336 over K = 4096
     // 64-column tiles 8.5 .. 8.9 vs 9.0 .. 9.3 — and narrow matrices (N < 2048) want 16-column tiles UNSPLIT on the decode kernel
     // (1024 x 4096: 4.5 vs 7.4 us, 1536 x 8960: 7.5 vs 9.4) rather than 32-column tiles with K slices.
+    // 16-column tiles keep the 256-block rule (2560 x 9728 / 3072 x 8192: 160 .. 192 unsplit blocks of 64-byte segments 10.0 / 8.5 us
+    // against 8.9 / 7.8 for 32-column tiles with K slices).  A long K over a narrow N (K >= 12288, fewer than 160 tiles of 64 columns)
+    // takes 64-column tiles with the fewest K slices that give 160 blocks: 8192 x 28672 23.1 vs 26.2 us, 4096 x 14336 10.6 vs 12.2,
+    // 5120 x 13824 12.9 vs 13.6.
     const int64_t want_blocks = nbits == 4 ? 160 : 256;
     if (nbits == 4 && sk == 0 && a.N < 2048 && a.K <= 12288 && try_plan(2, 1)) return true;
+    if (nbits == 4 && sk == 0 && a.K >= 12288 && a.N % 64 == 0 && a.N / 64 < 160 && a.N / 64 >= 40) {
+        int lsk = 2;
+        while ((a.N / 64) * lsk < 160) lsk *= 2;
+        if (try_plan(4, lsk)) return true;
+    }
     if (a.N % 64 == 0 && a.N / 64 >= want_blocks && try_plan(4, sk > 0 ? sk : 1)) return true;
     if (a.N % 32 == 0 && a.N / 32 >= want_blocks && try_plan(3, sk > 0 ? sk : 1)) return true;
-    if (a.N % 16 == 0 && a.N / 16 >= want_blocks && try_plan(2, sk > 0 ? sk : 1)) return true;
+    if (a.N % 16 == 0 && a.N / 16 >= 256 && try_plan(2, sk > 0 ? sk : 1)) return true;
     if (try_plan(3, sk)) return true;
     if (try_plan(4, sk)) return true;
     return try_plan(2, sk);

@@ -126,7 +126,8 @@ def test_struct_abi_and_validation():
     (dict(M=1, N=14336, K=4096), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=6144, K=4096), "gemv_mfma_kernel<tile32>"),            # MFMA GEMV on 6144 <= N <= 12288, K <= 8192
     (dict(M=1, N=8960, K=1536), "gemv_mfma_kernel<tile64>"),
-    (dict(M=1, N=8192, K=28672), "gemv_mfma_kernel<tile32>"),
+    (dict(M=1, N=8192, K=28672), "gemv_wn_kernel<tile64>"),             # long K over a narrow N: 64-column tiles x 2 K slices (23.1 vs 25.8 us)
+    (dict(M=1, N=4096, K=14336), "gemv_wn_kernel<tile64>"),
     (dict(M=4, N=4096, K=11008), "gemv_mfma_kernel<tile16,rows4>"),
     (dict(M=8, N=4096, K=11008), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=32, N=4096, K=11008, gs=64), "gemm_w4_mma_kernel<32x128>"),
@@ -385,7 +386,7 @@ def test_shipped_mi355x_table_is_well_formed_and_every_entry_selects_a_specialis
                 name = lib.gemlite_hip_kernel_name(C.byref(a)).decode()
                 assert name.startswith(("gemv_wn", "gemv_w4_decode", "gemv_mfma", "gemm_wn_direct", "gemm_wn_stream", "gemm_w4_mma", "gemm_w4_tiled")), (key, t, M, name)
             n += 1
-    assert n >= 10
+    assert n >= 5   # (round 3: five of the eleven cells fell to planner rules derived from the 22-shape sweep)
 
 
 def test_helper_processors_select_the_reference_modes():
