@@ -234,8 +234,20 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         //   4-bit, M = 1: 32-column tiles over a long K (8192^2: 9.9 vs 10.4).  Not the 16-column shapes (4096^2: 5.8 vs 4.8 for the
         //     dot-product decode kernel), not 64-column tiles (16384^2: 25.3 vs 23.7), not 32-column tiles over K = 4096 (9.3 vs 8.9);
         //   2-bit, M = 1: 16- and 32-column tiles (4096^2 4.4 vs 4.9, 8192^2 7.4 vs 8.6, 11008 x 4096 6.1 vs 8.2; 16384^2 18.0 vs 17.4: no);
-        //   4-bit, 2..4 rows: always (4096^2: 6.4 vs 7.3 for gemm_wn_direct, 8192^2 M = 4: 10.7 vs 11.2).
+        //   4-bit, 2..4 rows: N < 12288 (4096^2: 5.8 - 6.2 vs 6.4 - 7.5 for gemm_wn_direct, 6144 x 4096 5.9 vs 7.4, 5120 x 13824 17.1 vs 21.2,
+        //     1536 x 8960 10.7 vs 14.9) except a long K over a narrow N, which takes the registers-only kernel with 64-column tiles and
+        //     K slices (4096 x 14336 11.7 vs 16.5, 8192 x 28672 22.2 vs 28.5); N >= 12288: the registers-only kernel's 64-column tiles
+        //     unsplit (13824 x 5120 10.9 vs 11.6 .. 17.6, 28672 x 8192 21.9 vs 30.5) — profiles/r03/probe_m4_llm_shapes_*.log.
         // tuning[3] & 512 = never, & 1024 = wherever it applies (A/B runs).
+        if (x16 && a.W_nbits == 4 && a.M >= 2 && a.M <= 4 && mt == GEMLITE_MATMUL_AUTO && a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 &&
+            !(a.tuning[3] & 1024) && a.K >= 12288 && a.N <= 8192 && a.N % 64 == 0 && a.N / 64 >= 40) {
+            gemlite_hip_forward_args a2 = a;
+            a2.tuning[0] = 4;
+            a2.tuning[1] = a.N / 64 >= 128 ? 2 : 4;
+            WnParams pd = p;
+            LaunchPlan ld{};
+            if (plan_gemm_wn_direct(a2, pd, ld)) { r.kind = K_STREAM_WN; r.wn = pd; r.lp = ld; return; }
+        }
         if (x16 && !(a.tuning[3] & 512) && a.tuning[1] == 0 &&
             ((want_gemv && a.M == 1 && mt != GEMLITE_MATMUL_GEMV_SPLITK) || (a.M >= 2 && a.M <= 4 && mt == GEMLITE_MATMUL_AUTO))) {
             WnParams pm = p;
@@ -245,7 +257,7 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
                 // (round 3 sweep over 22 LLM shapes: 4-bit M = 1 also wins on every 6144 <= N <= 12288 with K <= 8192 — 6144 x 4096 5.6
                 //  vs 7.0 us, 8192 x 3072 5.6 vs 6.2, 8960 x 1536 5.1 vs 5.5, 11008 x 4096 7.9 vs 8.5 — and loses on narrow N, K > 8192
                 //  under 64-column tiles, and N >= 13824)
-                const bool wins = a.M >= 2 || (a.W_nbits == 4 ? (a.N >= 6144 && ((cols == 32 && a.K >= 8192 && a.K < 12288) || (a.N <= 12288 && a.K <= 8192))) : cols <= 32);
+                const bool wins = a.M >= 2 ? (a.W_nbits != 4 || a.N < 12288) : (a.W_nbits == 4 ? (a.N >= 6144 && ((cols == 32 && a.K >= 8192 && a.K < 12288) || (a.N <= 12288 && a.K <= 8192))) : cols <= 32));
                 if ((a.tuning[3] & 1024) || a.tuning[0] != 0 || wins) { r.kind = K_GEMV_WN; r.wn = pm; r.lp = lm; return; }
             }
         }

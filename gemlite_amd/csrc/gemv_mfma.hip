@@ -401,10 +401,13 @@ bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& 
     else {
         // round 3 sweep (profiles/r03/probe_m1_llm_shapes_*.log): for 4-bit decode fewer, wider blocks win — 160 blocks, 128 over a
         // short K (8960 x 1536: 64-column tiles 5.1 vs 8.1 us for 32-column ones; 6144 x 4096: 32-column 5.6 vs 8.1 for 16-column)
-        const int64_t want_blocks = (a.W_nbits == 4 && a.M == 1) ? (a.K <= 2048 ? 128 : 160) : 256;
+        const int64_t want_blocks = a.W_nbits == 4 ? (a.K <= 2048 ? 128 : 160) : 256;
         for (int cand : {4, 2, 1})
             if (a.N % (16 * cand) == 0 && a.N / (16 * cand) >= want_blocks) { v = cand; break; }
-        if (!v) return false;  // narrower matrices: the K-splitting kernels
+        // narrow matrices: 16-column tiles whatever the block count for 2 .. 4 rows (1536 x 8960, M = 4: 10.7 us against 14.9 for the
+        // 32-row MFMA tile the K = 8960 shapes used to fall to; 2560 x 9728: 12.0 vs 15.9) — at M = 1 the K-splitting kernels
+        if (!v && a.W_nbits == 4 && a.M >= 2 && a.N % 16 == 0) v = 1;
+        if (!v) return false;
     }
     if (a.N % (16 * v) != 0) return false;
     int nw = a.tuning[2] == 4 || a.tuning[2] == 8 || a.tuning[2] == 16 ? a.tuning[2] : 8;

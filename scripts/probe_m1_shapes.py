@@ -16,6 +16,8 @@ SHAPES = [(1536, 8960), (8960, 1536), (2048, 8192), (8192, 2048), (2560, 9728), 
           (6144, 4096), (4096, 4096), (4096, 14336), (14336, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (8192, 8192), (8192, 28672), (28672, 8192), (1024, 4096), (4096, 1024)]
 CANDS = [(0, 0, 0, 0)] + [(t, sk, 0, 512) for t in (2, 3, 4) for sk in (1, 2, 4)] + [(t, 0, 0, 1024) for t in (21, 22, 24)]
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+if M > 1:   # 2 .. 4 rows: the registers-only MFMA kernel (V = 1 / 2 / 4 words per lane x K slices) against the MFMA GEMV with 4 rows
+    CANDS = [(0, 0, 0, 0)] + [(v, sk, 0, 512) for v in (1, 2, 4) for sk in (1, 2, 4)] + [(t, 0, 0, 1024) for t in (21, 22, 24)]
 for (N, K) in SHAPES:
     name = f"a16w4_{N}x{K}_m{M}"
     nl = max(2, min(32, int(300e6 // (N * K // 2))))
