@@ -643,6 +643,16 @@ def test_launch_templates_are_immutable_and_keyed_by_everything_they_hold():
         core.GemLiteLinear.reset_config()
 
 
+def test_built_library_is_up_to_date_with_its_sources():
+    """`make -q`: the in-tree libgemlite_hip.so (what travels to the GPU box) is newer than every source — a source edit that
+    does not compile leaves the previous library behind, and every other test would pass on it."""
+    import subprocess
+    import gemlite_amd
+    csrc = os.path.join(os.path.dirname(gemlite_amd.__file__), "csrc")
+    rc = subprocess.run(["make", "-q", "-C", csrc], capture_output=True).returncode
+    assert rc == 0, "gemlite_amd/csrc is newer than libgemlite_hip.so: run `python -c 'import __graft_entry__ as g; g.build()'`"
+
+
 def test_isa_guard_no_scratch_or_spills_in_the_built_kernels():
     """scripts/isa_guard.py over the resource remarks of the build (gemlite_amd/csrc/build/*.remarks): only the known fallback
     kernels may touch scratch memory."""
