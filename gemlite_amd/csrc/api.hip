@@ -257,7 +257,7 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
                 // (round 3 sweep over 22 LLM shapes: 4-bit M = 1 also wins on every 6144 <= N <= 12288 with K <= 8192 — 6144 x 4096 5.6
                 //  vs 7.0 us, 8192 x 3072 5.6 vs 6.2, 8960 x 1536 5.1 vs 5.5, 11008 x 4096 7.9 vs 8.5 — and loses on narrow N, K > 8192
                 //  under 64-column tiles, and N >= 13824)
-                const bool wins = a.M >= 2 ? (a.W_nbits != 4 || a.N < 12288) : (a.W_nbits == 4 ? (a.N >= 6144 && ((cols == 32 && a.K >= 8192 && a.K < 12288) || (a.N <= 12288 && a.K <= 8192))) : cols <= 32);
+                const bool wins = a.M >= 2 ? (a.W_nbits != 4 || a.N < 12288) : (a.W_nbits == 4 ? (a.N >= 6144 && ((cols == 32 && a.K >= 8192 && a.K < 12288) || (a.N <= 12288 && a.K <= 8192))) : (cols <= 32 || a.K <= 8192));   // 2-bit: 64-column tiles too unless K is long (16384^2: 18.0 vs 17.4)
                 if ((a.tuning[3] & 1024) || a.tuning[0] != 0 || wins) { r.kind = K_GEMV_WN; r.wn = pm; r.lp = lm; return; }
             }
         }

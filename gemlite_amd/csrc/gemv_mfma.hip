@@ -401,12 +401,13 @@ bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& 
     else {
         // round 3 sweep (profiles/r03/probe_m1_llm_shapes_*.log): for 4-bit decode fewer, wider blocks win — 160 blocks, 128 over a
         // short K (8960 x 1536: 64-column tiles 5.1 vs 8.1 us for 32-column ones; 6144 x 4096: 32-column 5.6 vs 8.1 for 16-column)
-        const int64_t want_blocks = a.W_nbits == 4 ? (a.K <= 2048 ? 128 : 160) : 256;
+        const int64_t want_blocks = a.K <= 2048 ? 128 : 160;
         for (int cand : {4, 2, 1})
             if (a.N % (16 * cand) == 0 && a.N / (16 * cand) >= want_blocks) { v = cand; break; }
         // narrow matrices: 16-column tiles whatever the block count for 2 .. 4 rows (1536 x 8960, M = 4: 10.7 us against 14.9 for the
         // 32-row MFMA tile the K = 8960 shapes used to fall to; 2560 x 9728: 12.0 vs 15.9) — at M = 1 the K-splitting kernels
-        if (!v && a.W_nbits == 4 && a.M >= 2 && a.N % 16 == 0) v = 1;
+        // (2-bit, M = 1: the same — 1024 x 4096 3.7 vs 8.1 us, 3072 x 8192 6.2 vs 8.1, profiles/r03/probe_w2_m1_llm_shapes_*.log)
+        if (!v && ((a.W_nbits == 4 && a.M >= 2) || a.W_nbits == 2) && a.N % 16 == 0) v = 1;
         if (!v) return false;
     }
     if (a.N % (16 * v) != 0) return false;

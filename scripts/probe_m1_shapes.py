@@ -16,12 +16,13 @@ SHAPES = [(1536, 8960), (8960, 1536), (2048, 8192), (8192, 2048), (2560, 9728), 
           (6144, 4096), (4096, 4096), (4096, 14336), (14336, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (8192, 8192), (8192, 28672), (28672, 8192), (1024, 4096), (4096, 1024)]
 CANDS = [(0, 0, 0, 0)] + [(t, sk, 0, 512) for t in (2, 3, 4) for sk in (1, 2, 4)] + [(t, 0, 0, 1024) for t in (21, 22, 24)]
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+NBITS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 if M > 1:   # 2 .. 4 rows: the registers-only MFMA kernel (V = 1 / 2 / 4 words per lane x K slices) against the MFMA GEMV with 4 rows
     CANDS = [(0, 0, 0, 0)] + [(v, sk, 0, 512) for v in (1, 2, 4) for sk in (1, 2, 4)] + [(t, 0, 0, 1024) for t in (21, 22, 24)]
 for (N, K) in SHAPES:
-    name = f"a16w4_{N}x{K}_m{M}"
-    nl = max(2, min(32, int(300e6 // (N * K // 2))))
-    bench.WORKLOADS[name] = (N, K, 4, 128, M, "fp16", nl, "hbm")
+    name = f"a16w{NBITS}_{N}x{K}_m{M}"
+    nl = max(2, min(32, int(300e6 // (N * K * NBITS // 8))))
+    bench.WORKLOADS[name] = (N, K, NBITS, 128, M, "fp16", nl, "hbm")
     res = {}
     for rep, t in enumerate([(0, 0, 0, 0)] + CANDS):   # the first run of a shape warms the allocator / clocks: the default is timed twice
         core.TUNING_OVERRIDE = t if any(t) else None
