@@ -499,11 +499,11 @@ def test_direct_mfma_kernel_tiles_and_splits(nbits, N, K, tdt):
 def test_direct_mfma_kernel_all_modes(zeros_kind, fma, scales_kind, tdt):
     lin = _make_layer(2048, 4096, 4, 128 if scales_kind == "group" else 4096, tdt, seed=5, zeros_kind=zeros_kind, fma=fma,
                       scales_kind=scales_kind)
-    for M in (3, 24):
+    for M in (3, 6, 24):   # (3 rows: the MFMA GEMV since round 3 — the same modes on that kernel)
         x = torch.from_numpy(O.gen_x(M, 4096, seed=M).astype(np.float32)).to(tdt).to(DEV)
         y = lin(x)
         torch.cuda.synchronize()
-        assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel"), _kernel_name(lin, x)
+        assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel" if M > 4 else "gemv_mfma_kernel"), _kernel_name(lin, x)
         _compare(f"direct-modes/{zeros_kind}-{fma}-{scales_kind}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x),
                  lin.output_dtype.value)
 
@@ -640,7 +640,7 @@ def test_direct_mfma_kernel_group_size_64(nbits, tdt):
     for M in (2, 9, 16):
         x = torch.from_numpy(O.gen_x(M, 4096, seed=M + 5).astype(np.float32)).to(tdt).to(DEV)
         y_or = _oracle_from_layer(lin, x)
-        assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel"), _kernel_name(lin, x)
+        assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel" if M > 4 else ("gemv_mfma_kernel", "gemm_wn_direct_kernel")), _kernel_name(lin, x)
         for tuning in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (4, 0, 0, 0), (4, 2, 0, 0), (0, 0, 1, 0)):
             y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
             torch.cuda.synchronize()
