@@ -390,14 +390,15 @@ bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         // every block re-reads its K range of all M rows of x from L2: with 16-column tiles that is 4x the weight
         // bytes at M = 16.  From 8 rows on, 32-column tiles with K split in two were measured faster
         // (4096 x 4096, M = 16: 7.9 us vs 8.9 us) although they pay the cross-block combine.
-        if (v == 1 && a.M >= 8 && a.tuning[1] == 0 && fits(2) && (a.K / 1024) % 2 == 0 && (a.N / 32) * mtiles * 2 >= 256) {
+        // (round 3: from 5 rows — M = 6 at 4096^2 7.7 -> 6.5 us, 4096 x 14336 16.6 -> 11.8, profiles/r03/probe_m6_llm_shapes.log)
+        if (v == 1 && a.M >= 5 && a.tuning[1] == 0 && fits(2) && (a.K / 1024) % 2 == 0 && (a.N / 32) * mtiles * 2 >= 256) {
             v = 2;
             force_sk = 2;
         }
         // round 3 (profiles/r03/probe_fewrows_llm_shapes.log): the same step from 32- to 64-column tiles where 64-column tiles x 2
         // slices still fill the chip — with 8 waves per block: 8192^2 M = 8 / 16 11.9 / 13.7 -> 10.7 / 12.3 us, 8192 x 28672 27.1 / 35.2
         // -> 23.3 / 24.5; N = 6144 (192 blocks) loses (7.8 / 8.9 -> 8.0 / 9.8) and keeps the unsplit 32-column tiles
-        else if (v == 2 && mt == 1 && a.M >= 8 && a.tuning[1] == 0 && a.tuning[2] == 0 && fits(4) && a.K % 2048 == 0 && (a.N / 64) * 2 >= 256 &&
+        else if (v == 2 && mt == 1 && a.M >= 5 && a.tuning[1] == 0 && a.tuning[2] == 0 && fits(4) && a.K % 2048 == 0 && (a.N / 64) * 2 >= 256 &&
                  fn_nw(4, 8) != nullptr) {
             v = 4;
             force_sk = 2;

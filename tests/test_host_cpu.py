@@ -94,12 +94,13 @@ def test_struct_abi_and_validation():
     (dict(M=2), "gemv_mfma_kernel<tile16,rows4>"),    # 2..4 rows: the decode MFMA kernel (x staged once per wave in LDS)
     (dict(M=4), "gemv_mfma_kernel<tile16,rows4>"),
     (dict(M=4, tuning=(0, 0, 0, 512)), "gemm_wn_direct_kernel<tile16>"),   # 2 <= M <= 32: registers-only MFMA kernel, K not split
-    (dict(M=5), "gemm_wn_direct_kernel<tile16>"),
+    (dict(M=5), "gemm_wn_direct_kernel<tile32,8w>"),   # round 3: from 5 rows 32-column tiles x 2 K slices x 8 waves
     (dict(M=8), "gemm_wn_direct_kernel<tile32,8w>"),     # >= 8 rows: 32-column tiles x split-K 2 (less x traffic), round 3: 8 waves per block
     (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile64,8w>"),   # ... 64-column tiles x 2 where they still fill the chip
     (dict(M=8, N=6144, K=4096), "gemm_wn_direct_kernel<tile32>"),      # 192 blocks of 32 columns, unsplit: 4 waves
     (dict(M=8, tuning=(0, 0, 4, 0)), "gemm_wn_direct_kernel<tile32>"),   # tuning[2] = 4 / 8: waves per block
-    (dict(M=7), "gemm_wn_direct_kernel<tile16>"),
+    (dict(M=7), "gemm_wn_direct_kernel<tile32,8w>"),   # ... from 5 rows (M = 6: 7.7 -> 6.5 us)
+    (dict(M=5, N=8192, K=8192), "gemm_wn_direct_kernel<tile64,8w>"),
     (dict(M=16, N=16384, K=16384), "gemm_wn_direct_kernel<tile64>"),
     (dict(M=24, N=16384, K=16384), "gemm_w4_mma_kernel<32x128>"),   # 17..32 rows over K >= 8192: LDS-staged x wins
     (dict(M=8, tuning=(0, 0, 1, 0)), "gemm_wn_stream_kernel"),  # tuning[2] = 1: LDS-staged streaming kernel
