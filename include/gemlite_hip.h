@@ -162,7 +162,8 @@ typedef struct gemlite_hip_forward_args {
      *                              [0] 21/22/24 = 16-/32-/64-column tiles   [2] 4/8/16 waves per block
      *                              [3] & 512 = never, & 1024 = wherever it applies
      *   few rows (2..32, MFMA)     [0] 1/2/4 = 16-/32-/64-column tiles, 3 = the 8-wave tiled kernel instead
-     *                              [1] K slices   [2] 1 = LDS-staged streaming kernel
+     *                              [1] K slices   [2] 1 = LDS-staged streaming kernel, 4 / 8 = waves per block of the registers-only
+     *                              kernel (8: one row tile, >= 32-column tiles; default with two K slices)
      *   tiled (M > 32, MFMA)       [0] 1 = streaming kernel, 2 = the 4-wave tiled kernel of round 1 (4-bit only; the planner's
      *                              fallback for K = 64 * odd)
      *                              [1] K slices (any count <= K steps; slices may be uneven)
