@@ -2,6 +2,7 @@
 outputs, the C-ABI library (loads, exports every symbol of include/gemlite_hip.h, struct ABI), kernel
 selection, and loud failure without a GPU.  No compute is launched here."""
 import ctypes as C
+import json
 import os
 import sys
 import re
@@ -213,6 +214,24 @@ def test_kernel_selection(kw, kernel):
             assert got != kernel[:-3] and "tiled_kernel<" not in got.replace("gemm_w4_tiled_kernel<128x128>", ""), got
         return
     assert lib.gemlite_hip_kernel_name(C.byref(a)).decode() == kernel
+
+
+def test_planner_choices_on_llm_shapes():
+    """The kernel the C ABI picks on 23 LLM layer shapes x M in {1, 2, 4, 6, 8, 16, 32, 64, 256} (4-bit) / {1, 16, 256} (2-bit) is
+    frozen in tests/golden/planner_llm_shapes.json: the planner rules of round 3 come from GPU sweeps over exactly these shapes
+    (profiles/r03/probe_*_llm_shapes_*.log), and a rule edited for one shape should not silently move the others.  To regenerate
+    after an intended change: rows = [[nb, M, N, K, kernel_name(_args(M=M, N=N, K=K, nbits=nb, gs=128, in_dt=1, mt=-1))] ...]."""
+    lib = _hip.load()
+    fx = json.load(open(os.path.join(GOLDEN, "planner_llm_shapes.json")))["rows"]
+    assert len(fx) >= 270
+    moved = []
+    for nb, M, N, K, want in fx:
+        a = _args(M=M, N=N, K=K, nbits=nb, gs=128, in_dt=1, mt=-1)
+        got = lib.gemlite_hip_kernel_name(C.byref(a)).decode()
+        if got != want:
+            moved.append((nb, M, N, K, want, got))
+        assert "generic" not in got, (nb, M, N, K, got)   # none of these shapes may reach the coverage kernel
+    assert not moved, moved[:10]
 
 
 def test_workspace_sizing_cfgA():
