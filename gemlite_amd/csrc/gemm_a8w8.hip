@@ -340,10 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_mma_kernel(const GenericPara
     const __amdgpu_buffer_rsrc_t brW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + p.K), 0x00020000);
     // B fragment of slice g: 16 bytes at weight row n, k = k_s0 + step * 256 + kh * 128 + g * 32 + h * 16
-    // (development, tuning[3] & 32: lanes read one contiguous KiB instead of 64 rows x 16 bytes — wrong results, shows what
-    //  the uncoalesced weight fragments cost)
-    const uint32_t wvoff = (p.flags & 32) ? (uint32_t)((int64_t)(nt * BN + cg * 32) * p.stride_wn + k_s0 + kh * KW + lane * 16)
-                                          : (uint32_t)((int64_t)n * p.stride_wn + k_s0 + kh * KW + h * 16);
+    const uint32_t wvoff = (uint32_t)((int64_t)n * p.stride_wn + k_s0 + kh * KW + h * 16);
     struct BStep { u32x4 w[NS]; };
     auto req_b = [&](BStep& b, int step, int g) {
         // a tracked buffer load: the compiler retires it with its own counted vmcnt (see gemm_wn_mma.hip)

@@ -424,9 +424,10 @@ __global__ __launch_bounds__(256, (MI <= 4 ? 2 : 1)) void gemm_w4_pipe_kernel(co
     for (int ks = 0; ks < 4; ++ks) woff[ks] = (uint32_t)((kb + 2 * ks) * sw + n) * 4u;
     const uint32_t moff = (uint32_t)n * 2u;
     struct BStep { uint32_t w[4]; uint16_t s, z; };
-    // development probes (tuning[3] & 8 / & 16): push the weight / activation offsets out of range so that the loads
-    // return zeros at once — separates "waiting for HBM / L2" from everything else in a timing run (results are wrong)
-    const uint32_t bkill = (p.flags & 8) ? 0x80000000u : 0u, akill = (p.flags & 16) ? 0x40000000u : 0u;
+    // (round 1 had two timing probes here, tuning[3] & 8 / & 16, that pushed the weight / activation offsets out of range — wrong
+    //  results on request; removed in round 3: & 8 is the documented XCD-map switch of the 8-wave kernel, and this kernel is that
+    //  kernel's fallback for K = 64 x odd)
+    constexpr uint32_t bkill = 0u, akill = 0u;
     // piece 0..3: packed words, 4: scale, 5: zero (one load instruction each, so they can be placed one per MFMA gap)
     auto load_b1 = [&](BStep& b, int step, int piece) {
         if (piece < 4) {
