@@ -508,6 +508,13 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
         }
         const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes, dev);
         if (e != GEMLITE_OK) return e;
+        if (r.lp.arg_kind == 1) {  // scalar (SGPR-preloaded) arguments: gemv_decode.hip
+            Decode3Args& d = r.lp.d3;
+            d.counters = r.wn.counters;
+            void* dargs[] = {(void*)&d.w, (void*)&d.x, (void*)&d.s, (void*)&d.z, (void*)&d.out, (void*)&d.sw4, (void*)&d.mstride2,
+                             (void*)&d.nch_total, (void*)&d.modes, (void*)&d.counters};
+            return launch(r.lp.fn, r.lp.grid, r.lp.block, dargs, 0, st);
+        }
         void* kargs[] = {(void*)&r.wn};
         return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
     }

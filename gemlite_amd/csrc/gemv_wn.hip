@@ -33,6 +33,8 @@
 
 namespace gl {
 
+const void* gemv_w4_decode3_fn(int tag, bool nt);  // gemv_decode.hip
+
 // Unpack geometry.  One AND turns packed bits into two 16-bit floats q * 2^(NBITS*i) (i = position of the
 // element inside a WINDOW of consecutive bit fields that still fits the mantissa); the matching x pair is stored
 // pre-scaled by 2^-(NBITS*i) (an exact power of two), so only one shift per window (not per element) is needed.
@@ -788,6 +790,28 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
             lp.lds_bytes = (size_t)nw * 4 * 16 * 4;
             lp.slab_bytes = 0;
             lp.ws_bytes = 0;
+            // round 4: the same arithmetic behind preloaded scalar arguments, weights requested first (gemv_decode.hip); the common
+            // case only — no channel scales in the epilogue, contiguous output row, group size a power of two.  tuning[3] & 4096
+            // keeps the round-3 kernel (A/B runs).
+            if (nw == 16 && !(a.tuning[3] & 4096) && a.channel_scale_mode == 0 && a.stride_on == 1 && p.gs_shift >= 0 && p.gs_shift < 32 &&
+                (int64_t)rows * 16 < (1ll << 31)) {
+                const bool need_s2 = p.w_mode >= 2, need_z2 = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
+                lp.arg_kind = 1;
+                lp.fn = gemv_w4_decode3_fn(f16 ? 0 : 1, nt);
+                lp.name = "gemv_w4_decode3_kernel<tile16,16w>";
+                lp.lds_bytes = 0;  // static LDS
+                lp.d3.w = (const char*)p.w;
+                lp.d3.x = (const char*)p.x;
+                lp.d3.s = need_s2 ? (const char*)p.scales : (const char*)p.w;
+                lp.d3.z = (need_z2 || p.zero_is_scalar) ? (const char*)p.zeros : (const char*)p.w;
+                lp.d3.out = (uint16_t*)p.epi.out;
+                lp.d3.sw4 = (uint32_t)p.stride_wk * 4u;
+                lp.d3.mstride2 = (need_s2 || need_z2) ? (uint32_t)p.stride_meta_g * 2u : 0u;
+                lp.d3.nch_total = rows / 32;
+                lp.d3.modes = (uint32_t)p.w_mode | (p.zero_is_scalar ? 16u : 0u) | (((tiles & 15) == 0) ? 32u : 0u) | ((a.tuning[3] & 4) ? 64u : 0u) |
+                              ((uint32_t)p.gs_shift << 8);
+                lp.d3.counters = nullptr;
+            }
             return true;
         }
         lp.name = (xd && nw == 16) ? "gemv_wn_kernel<tile16,xdirect,16w>"

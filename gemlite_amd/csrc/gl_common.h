@@ -434,6 +434,16 @@ enum { MX_F16 = 1, MX_BF16 = 2, MX_FP8 = 3, MX_FP4 = 4 };
 // has been seen).  Kernels whose blocks WAIT for each other (reduce-scatter combine) are only planned within this limit.
 int resident_block_limit();
 
+// scalar kernel arguments of gemv_w4_decode3_kernel (gemv_decode.hip): 14 dwords the command processor preloads into SGPRs
+struct Decode3Args {
+    const char *w, *x, *s, *z;
+    uint16_t* out;
+    uint32_t sw4, mstride2;
+    int nch_total;
+    uint32_t modes;
+    unsigned* counters;
+};
+
 struct LaunchPlan {
     const void* fn;
     const char* name;
@@ -441,6 +451,8 @@ struct LaunchPlan {
     size_t lds_bytes;
     uint64_t ws_bytes;    // total workspace needed (COUNTER_BYTES + slab_bytes when K is split, else 0)
     uint64_t slab_bytes;
+    int arg_kind;         // 0: the kernel takes its parameter struct by value | 1: the scalar arguments of `d3`
+    Decode3Args d3;
 };
 
 }  // namespace gl

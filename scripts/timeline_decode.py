@@ -14,7 +14,7 @@ lib = _hip.load()
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 name = sys.argv[1] if len(sys.argv) > 1 else "a16w4_4096_m1"
-for tun in ((0, 0, 0, 4 | 512 | 64), (0, 0, 0, 4 | 512), (0, 0, 16, 4 | 512), (0, 0, 0, 4)):
+for tun in ((0, 0, 0, 4 | 4096), (0, 0, 0, 4), (0, 0, 0, 4 | 4096), (0, 0, 0, 4)):  # round-3 decode kernel vs decode3
     core.TUNING_OVERRIDE = tun
     r = bench.Runner(name, dev, lib)
     c_us, _, _ = r.chained_us_per_launch(min_seconds=0.1)
