@@ -3,8 +3,9 @@
 
 Default workload (BASELINE.json configs[1]): A16W4 group_size=128, 4096x4096, M=1 decode GEMV.
 A "step" is one pass of the hot path over a stack of LAYERS (=32) DISTINCT packed layers with the same
-input row — one decode step through 32 linear layers.  32 x 8.93 MB = 286 MB of weights exceeds the 256 MiB
-Infinity Cache, so every layer's stream comes from HBM (cache-cold rotation, SURVEY.md §7 "Hard parts").
+input row — one decode step through 64 linear layers.  64 x 8.93 MB = 572 MB of weights is more than twice the 256 MiB
+Infinity Cache (SURVEY.md §8(d) asks for >= 512 MiB; rounds 1-3 rotated 286 MB — `rotation_ab` in the line times both), so every
+layer's stream comes from HBM (cache-cold rotation, SURVEY.md §7 "Hard parts").
 The step is captured once as a hipGraph (the launch-bound regime the reference itself addresses with CUDA
 graphs, config.py:17) and replayed; `value` is whole-job algorithmic GB/s over all ranks.
 
@@ -17,8 +18,10 @@ secondary figure only (`event_us`; an EMPTY kernel reads ~4 us through them: `ev
   roofline        — M=1 (the `value` workload): algorithmic bytes per launch / time per launch of the TIMED REGION.
   roofline_m256   — cfgA (4096^2) and cfgB (8192^2, BASELINE configs[2]) at M=256 in bf16: TFLOP/s against the dense bf16 MFMA peak;
                     `mfma_util` = matrix-pipe busy share from the committed SQ counter passes (profiles/mfma_util.json), or null.
-  roofline_cfg4   — BASELINE configs[3]: A8W8 int8 4096^2 at M = 1 / 16 / 256 (x pre-quantised outside the timed matmul).
-  roofline_cfg5   — BASELINE configs[4]: A16W2 g128 and FP8 x FP8 16384^2 at M = 1 / 256.
+  roofline_cfg4   — BASELINE configs[3]: A8W8 int8 4096^2 at M = 1 / 16 / 256: the matmul alone (x pre-quantised outside the timed
+                    region) AND `*_layer_e2e`: layer(x) with the dynamic activation quantisation inside the timed region (round 4).
+  roofline_cfg5   — BASELINE configs[4]: A16W2 g128 and FP8 x FP8 16384^2 at M = 1 / 256 (+ `*_layer_e2e` for FP8).
+  roofline_m1_bf16, rotation_ab — the bf16 twin of the headline; the headline step over 32 (286 MB) vs 64 (572 MB) distinct layers.
   roofline_prefill_m2048 — 8192^2 at M=2048 (bf16), the large-M end of the MFMA kernel family.
   roofline_trend_m1 — the same GEMV family at 8192^2 and 16384^2 (fraction of HBM peak grows with size).
   sustained       — >= 6 s of back-to-back replays of the headline step (an outside sampler sees the GPU busy).
@@ -49,25 +52,25 @@ MXFP4_MFMA_PEAK_TFLOPS = 10000.0  # block-scaled fp4 / fp6, dense
 
 WORKLOADS = {
     # name: (N, K, nbits, group, M, dtype, layers, bound)
-    "a16w4_4096_m1": (4096, 4096, 4, 128, 1, "fp16", 32, "hbm"),
-    "a16w4_4096_m1_bf16": (4096, 4096, 4, 128, 1, "bf16", 32, "hbm"),
+    "a16w4_4096_m1": (4096, 4096, 4, 128, 1, "fp16", 64, "hbm"),
+    "a16w4_4096_m1_bf16": (4096, 4096, 4, 128, 1, "bf16", 64, "hbm"),
     "a16w4_4096_m8": (4096, 4096, 4, 128, 8, "fp16", 32, "hbm"),
     "a16w4_4096_m16": (4096, 4096, 4, 128, 16, "fp16", 32, "hbm"),
-    "a16w4_4096_m256": (4096, 4096, 4, 128, 256, "bf16", 32, "mfma"),
+    "a16w4_4096_m256": (4096, 4096, 4, 128, 256, "bf16", 64, "mfma"),
     "a16w4_4096_m256_fp16": (4096, 4096, 4, 128, 256, "fp16", 32, "mfma"),
-    "a16w4_8192_m256": (8192, 8192, 4, 128, 256, "bf16", 8, "mfma"),
+    "a16w4_8192_m256": (8192, 8192, 4, 128, 256, "bf16", 16, "mfma"),
     "a16w4_8192_m2048": (8192, 8192, 4, 128, 2048, "bf16", 8, "mfma"),   # prefill-sized M: the tiles fill the chip without K slices
     "a16w4_4096_m2048": (4096, 4096, 4, 128, 2048, "bf16", 32, "mfma"),
     "a16w4_8192_m8192": (8192, 8192, 4, 128, 8192, "bf16", 8, "mfma"),
-    "a16w4_8192_m1": (8192, 8192, 4, 128, 1, "fp16", 8, "hbm"),
-    "a16w2_16384_m1": (16384, 16384, 2, 128, 1, "fp16", 4, "hbm"),
-    "a16w2_16384_m256": (16384, 16384, 2, 128, 256, "bf16", 4, "mfma"),
-    "a16w4_16384_m1": (16384, 16384, 4, 128, 1, "fp16", 2, "hbm"),
+    "a16w4_8192_m1": (8192, 8192, 4, 128, 1, "fp16", 16, "hbm"),
+    "a16w2_16384_m1": (16384, 16384, 2, 128, 1, "fp16", 8, "hbm"),
+    "a16w2_16384_m256": (16384, 16384, 2, 128, 256, "bf16", 8, "mfma"),
+    "a16w4_16384_m1": (16384, 16384, 4, 128, 1, "fp16", 4, "hbm"),
     "a16w4_11008_m1": (4096, 11008, 4, 128, 1, "fp16", 12, "hbm"),
     # BASELINE config 4: A8W8 int8 dynamic (x pre-quantised per token outside the timed matmul; group = K: channel-wise)
-    "a8w8_4096_m1": (4096, 4096, 8, 4096, 1, "int8", 16, "hbm"),
-    "a8w8_4096_m16": (4096, 4096, 8, 4096, 16, "int8", 16, "hbm"),
-    "a8w8_4096_m256": (4096, 4096, 8, 4096, 256, "int8", 16, "mfma"),
+    "a8w8_4096_m1": (4096, 4096, 8, 4096, 1, "int8", 32, "hbm"),
+    "a8w8_4096_m16": (4096, 4096, 8, 4096, 16, "int8", 32, "hbm"),
+    "a8w8_4096_m256": (4096, 4096, 8, 4096, 256, "int8", 32, "mfma"),
     # BASELINE config 5, second half: FP8 x FP8 (e4m3, per-token x per-channel scales), 16384 x 16384
     "fp8_16384_m1": (16384, 16384, 8, 16384, 1, "fp8w8", 2, "hbm"),
     "fp8_16384_m256": (16384, 16384, 8, 16384, 256, "fp8w8", 2, "mfma"),
@@ -115,7 +118,7 @@ def work_per_launch(name):
     return nbytes, 2 * M * N * K
 
 
-def build_layers(name, device, layers=None):
+def build_layers(name, device, layers=None, raw_x=False):
     from gemlite_amd import GemLiteLinear
     from gemlite_amd.dtypes import TORCH_TO_DTYPE
 
@@ -146,6 +149,8 @@ def build_layers(name, device, layers=None):
         proc = (A8W8_int8_dynamic if dt == "int8" else A8W8_fp8_dynamic)(device=device, dtype=torch.float16)
         mods = [proc.from_weights((torch.randn(N, K, generator=g, device=device) / 30).half()) for _ in range(layers)]
         x = (torch.randn(M, K, generator=g, device=device) / 10).half()
+        if raw_x:
+            return mods, x
         return mods, scale_activations_per_token(x, torch.int8 if dt == "int8" else torch.float8_e4m3fn)  # (x_q [M, K], scales_x fp32 [M, 1])
     if dt == "fp8":
         from gemlite_amd.helper import A8Wn_HQQ_INT_dynamic
@@ -177,12 +182,15 @@ def build_layers(name, device, layers=None):
 
 
 class Runner:
-    """One workload: eager step, captured hipGraph of the step, per-launch event timing."""
+    """One workload: eager step, captured hipGraph of the step, per-launch event timing.
+    e2e (dynamic-quantisation workloads): time `layer(x)` on the UNQUANTISED 16-bit x — the product path, quantiser included (one fused
+    launch at M = 1, quantiser + matmul above) — instead of the matmul alone on a pre-quantised x."""
 
-    def __init__(self, name, device, lib, layers=None, matmul_type="", use_graph=True):
+    def __init__(self, name, device, lib, layers=None, matmul_type="", use_graph=True, e2e=False):
         self.name, self.device, self.lib, self.matmul_type = name, device, lib, matmul_type
+        self.e2e = e2e
         self.N, self.K, self.nbits, self.group, self.M, self.dt, _, self.bound = WORKLOADS[name]
-        self.mods, self.x = build_layers(name, device, layers)
+        self.mods, self.x = build_layers(name, device, layers, raw_x=e2e)
         self.layers = len(self.mods)
         self.bytes, self.flops = work_per_launch(name)
         self.stream = torch.cuda.Stream(device)
@@ -210,6 +218,8 @@ class Runner:
                 self.chain_graph = self.graph
 
     def call(self, lin):
+        if self.e2e:  # the layer as the user calls it: dynamic activation quantisation included
+            return lin(self.x)
         if self.dt in PREQUANT:  # the matmul alone: x was quantised once in build_layers
             from gemlite_amd.core import _hip_matmul
             return _hip_matmul(self.x[0], lin.W_q, lin.scales, lin.zeros, self.x[1], lin.get_meta_args(), -1)
@@ -294,14 +304,17 @@ class Runner:
         from gemlite_amd.core import _static_args
         lin = self.mods[0]
         a = _static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
-        x = self.x[0] if self.dt in PREQUANT else self.x
+        x = self.x if self.e2e else (self.x[0] if self.dt in PREQUANT else self.x)
         a.matmul_type = -1
         a.x = a.out = 0x1000
         a.M = x.shape[0]
         from gemlite_amd.dtypes import TORCH_TO_DTYPE
         a.input_dtype = lin.input_dtype.value if self.dt in MX else TORCH_TO_DTYPE[x.dtype].value
         a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = x.stride(0), x.stride(1), a.N, 1
-        if self.dt in PREQUANT:
+        if self.e2e and x.shape[0] > 1:  # quantiser + matmul: name the matmul the quantised x reaches
+            a.input_dtype = lin.input_dtype.value
+            a.scales_x = 0x1000
+        elif self.dt in PREQUANT and not self.e2e:
             a.scales_x = 0x1000
             if self.dt in MX:
                 a.stride_sx_m = self.x[1].stride(0)
@@ -366,6 +379,27 @@ def event_clock_floor_us(lib, stream, samples=64):
     return float(d.mean()) if d.size else float("nan")
 
 
+def empty_launch_period_us(lib, stream, n=64, min_seconds=0.05):
+    """Time per launch of an EMPTY 256 x 256 kernel, back to back inside a replayed hipGraph (the clock of every block of the line):
+    the dependent-launch boundary alone."""
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        for _ in range(n):
+            lib.gemlite_hip_launch_noop(256, 256, torch.cuda.current_stream().cuda_stream)
+    g.replay()
+    torch.cuda.synchronize()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        g.replay()
+        reps += 1
+        if reps % 10 == 0:
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 >= min_seconds:
+                break
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (reps * n) * 1e6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,6 +457,12 @@ def main():
             roof["event_clock_floor_us"] = round(event_clock_floor_us(lib, main_run.stream), 3)
         except Exception as e:
             print(f"[bench] per-kernel event timing unavailable: {e}", file=sys.stderr)
+    try:  # the dependent-launch period of an EMPTY kernel inside a replayed graph, same process: what no kernel can go below
+        e0 = empty_launch_period_us(lib, main_run.stream)
+        roof["empty_launch_us"] = round(e0, 3)
+        roof["kernel_us_minus_empty_launch"] = round(gap_us - e0, 3)
+    except Exception as e:
+        print(f"[bench] empty-launch period unavailable: {e}", file=sys.stderr)
     if bound == "hbm":
         roof["frac_vs_measured_copy_6290"] = round(roof["achieved"] / 6290.0, 4)
     else:
@@ -454,9 +494,12 @@ def main():
             line["sustained"] = {"seconds": round(el, 3), "launches": nl, "value": round(main_run.bytes / 1e9 / (us * 1e-6), 3),
                                  "unit": "GB/s", "us_per_launch": round(us, 3)}
 
-            def block(wname, nl=None, samples=0):
-                r = Runner(wname, device, lib, layers=nl, use_graph=not args.no_graph)
+            def block(wname, nl=None, samples=0, e2e=False):
+                r = Runner(wname, device, lib, layers=nl, use_graph=not args.no_graph, e2e=e2e)
                 out = r.roofline(0 if args.quick else samples, min_seconds=0.03 if args.quick else 0.25)
+                if e2e:
+                    out["what"] = ("layer(x) on fp16 x, dynamic per-token quantisation included: " +
+                                   ("ONE fused launch" if r.M == 1 else "quantiser launch + matmul launch; kernel_us is the time of the pair"))
                 out["traffic"] = _traffic(wname)
                 if out["bound"] == "mfma":
                     out["mfma_util"] = _committed("mfma_util.json", wname)
@@ -464,12 +507,21 @@ def main():
                 torch.cuda.empty_cache()
                 return out
             # the M=256 half of the headline metric, same process, bf16
-            line["roofline_m256"] = {"cfgA_4096": block("a16w4_4096_m256", 32, samples=64), "cfgB_8192": block("a16w4_8192_m256", 8, samples=32)}
-            # BASELINE configs[3]: A8W8 int8 channel-wise 4096^2, M in {1, 16, 256}
+            line["roofline_m256"] = {"cfgA_4096": block("a16w4_4096_m256", samples=64), "cfgB_8192": block("a16w4_8192_m256", samples=32)}
+            # SURVEY §8(d) config 2 is "fp16 + bf16": the bf16 twin of the headline
+            line["roofline_m1_bf16"] = block("a16w4_4096_m1_bf16")
+            # the rotation size does not carry the headline: the same step over 32 layers (286 MB, rounds 1-3) and 64 (572 MB)
+            r32 = block("a16w4_4096_m1", 32)
+            line["rotation_ab"] = {"layers32_286MB_us": r32["kernel_us"], "layers64_572MB_us": roof["kernel_us"]}
+            # BASELINE configs[3]: A8W8 int8 channel-wise 4096^2, M in {1, 16, 256}: the matmul alone on a pre-quantised x, and
+            # (`*_layer_e2e`, round 4) layer(x) as the product runs it, dynamic activation quantisation included
             line["roofline_cfg4"] = {f"a8w8_int8_4096_m{m}": block(f"a8w8_4096_m{m}") for m in (1, 16, 256)}
+            line["roofline_cfg4"].update({f"a8w8_int8_4096_m{m}_layer_e2e": block(f"a8w8_4096_m{m}", e2e=True) for m in (1, 16, 256)})
             # BASELINE configs[4]: A16W2 g128 and FP8 x FP8, 16384^2, M in {1, 256}
             line["roofline_cfg5"] = {"a16w2_16384_m1": block("a16w2_16384_m1"), "a16w2_16384_m256": block("a16w2_16384_m256"),
-                                     "fp8_16384_m1": block("fp8_16384_m1"), "fp8_16384_m256": block("fp8_16384_m256")}
+                                     "fp8_16384_m1": block("fp8_16384_m1"), "fp8_16384_m256": block("fp8_16384_m256"),
+                                     "fp8_16384_m1_layer_e2e": block("fp8_16384_m1", e2e=True),
+                                     "fp8_16384_m256_layer_e2e": block("fp8_16384_m256", e2e=True)}
             # the large-M end of the same kernel family (north star: "tiled GEMM for large-M prefill"), same clock
             line["roofline_prefill_m2048"] = block("a16w4_8192_m2048", 4)
             line["roofline_trend_m1"] = {"8192": block("a16w4_8192_m1"), "16384": block("a16w4_16384_m1")}

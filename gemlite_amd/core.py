@@ -28,6 +28,10 @@ from .dtypes import (DTYPE_TO_TORCH, FP8_INT8_DTYPES, TORCH_TO_DTYPE, DType, is_
 from .quant_utils import (scale_activations_mxfp4, scale_activations_mxfp8, scale_activations_nvfp4,
                           scale_activations_per_token)
 
+# the name the reference's own test file imports from gemlite.core (tests/test_gemlitelineartriton.py:6; the reference itself no
+# longer defines it — SURVEY App. B.7): per-token dynamic quantisation, (x_q, scales_x)
+scale_activations = scale_activations_per_token
+
 logger = logging.getLogger(__name__)
 
 # kernel families, in the reference's order: the index is the wire value of `matmul_type`

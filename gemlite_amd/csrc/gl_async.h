@@ -27,6 +27,18 @@ __device__ __forceinline__ void req_u32(uint32_t& dst, srd_t rs, uint32_t voff, 
 __device__ __forceinline__ void req_u16(uint32_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
     asm volatile("s_nop 4\n\tbuffer_load_ushort %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
+// the same without the nop: soffset computed by SALU instructions (s_mul / s_add / s_mov) is interlocked; only a VALU-written SGPR
+// (v_readfirstlane) needs the 5 wait states
+__device__ __forceinline__ void req_u32n(uint32_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void req_u8(uint32_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+typedef uint32_t u128_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void req_u128(u128_t& dst, srd_t rs, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
 // one LDS-DMA piece: 64 lanes x 16 bytes from buffer offset (voff per lane + soff) to LDS [lds_addr, +1024), lane-linear
 // (m0 is a RESERVED register of the AMDGPU backend: hipcc never keeps a value in it across statements, it writes m0 right
 //  before the few instructions that read it — none of which these kernels contain; `grep m0` on the generated code of the

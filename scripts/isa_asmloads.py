@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""ISA guard, part 3 (round 4): registers loaded by inline-asm buffer loads must not be touched before the counted wait that covers them.
+
+The MFMA tile kernel (gemm_wn_mma_kernel.inc) issues its weight / metadata loads from inline asm and retires them by hand with counted
+`s_waitcnt vmcnt(N)`; hipcc does not know these registers are in flight and may copy, spill or reuse one between the load and the
+wait (cdna_hip_programming.md §5.7 item 1).  This script replays the wave's memory queue over the generated code of every
+gemm_wn_mma_kernel instantiation — function start to the end of the K loop, then the K loop a second time (the ring wraps around the
+back edge) — and reports any instruction that reads or writes the destination of a load that is still outstanding at that point:
+loads return in order, so at `s_waitcnt vmcnt(k)` everything but the newest k requests has landed.
+    python scripts/isa_asmloads.py            exit 0: clean | 1: a destination is touched early | 2: nothing could be checked
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import isa_loops as L
+
+FAMILIES = ("gemm_wn_mma_kernel",)
+VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(text):
+    out = set()
+    for m in VREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def first_operand_regs(text):
+    ops = text.split(None, 1)[1] if " " in text else ""
+    return regs_of(ops.split(",")[0])
+
+
+def replay(lines, seq):
+    """seq: instruction indices in execution order.  Returns [(address, text, registers)] of early touches."""
+    queue, bad = [], []  # queue: oldest first; each entry = set of destination registers (empty: store / LDS-DMA)
+    for i in seq:
+        a, t = lines[i]
+        op = t.split()[0]
+        m = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t)
+        if m:
+            k = int(m.group(1))
+            if len(queue) > k:
+                queue = queue[len(queue) - k:] if k else []
+            continue
+        vmem = op.startswith(("buffer_", "global_", "flat_", "scratch_"))
+        touched = regs_of(t)
+        if vmem and "load" in op and " lds" not in t:
+            dest = first_operand_regs(t)
+            srcs = touched - dest
+        else:
+            dest, srcs = set(), touched
+        inflight = set().union(*queue) if queue else set()
+        clash = (srcs | dest) & inflight if vmem and "load" in op else touched & inflight
+        if clash:
+            bad.append((a, t, sorted(clash)))
+        if vmem and "atomic" not in op or (vmem and "atomic" in op):
+            queue.append(dest)
+    return bad
+
+
+def check():
+    seen, reports = 0, []
+    for co in L.code_objects(L.LIB):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            asm = subprocess.run([L.OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True).stdout
+        fn, lines = None, []
+
+        def flush():
+            nonlocal seen
+            if not fn or not any(h in fn for h in FAMILIES) or not lines:
+                return
+            seen += 1
+            # the K loop = the natural loop with the most MFMAs; approximated by the last backward branch that spans >= 16 MFMAs
+            # and whose body holds no s_endpgm: indices [lo, hi]
+            index = {a: i for i, (a, _) in enumerate(lines)}
+            best = None
+            for i, (a, t) in enumerate(lines):
+                m = re.match(r"(?:s_cbranch_\w+|s_branch)\s+(\d+)", t)
+                if not m:
+                    continue
+                offw = int(m.group(1))
+                if offw >= 32768:
+                    offw -= 65536
+                tgt = index.get(a + 4 + offw * 4)
+                if tgt is None or tgt > i:
+                    continue
+                body = lines[tgt:i + 1]
+                if any(x[1].startswith("s_endpgm") for x in body):
+                    continue
+                hot = sum("v_mfma" in x[1] for x in body)
+                if hot >= 16 and (best is None or hot > best[2]):
+                    best = (tgt, i, hot)
+            if best is None:
+                return
+            lo, hi, _ = best
+            seq = list(range(0, hi + 1)) + list(range(lo, hi + 1))
+            for (a, t, r) in replay(lines, seq)[:4]:
+                reports.append((fn, hex(a), t, r))
+        for line in asm.split("\n"):
+            m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)
+            if m:
+                flush()
+                fn, lines = m.group(2), []
+                continue
+            m = re.match(r"^\s+(\S.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+            if m and fn:
+                lines.append((int(m.group(2), 16), m.group(1).strip()))
+        flush()
+    return seen, reports
+
+
+if __name__ == "__main__":
+    if not L.OBJDUMP or not os.path.exists(L.LIB):
+        print("isa_asmloads: cannot check (no llvm-objdump or no library)")
+        sys.exit(2)
+    seen, reports = check()
+    if seen == 0:
+        print("isa_asmloads: no gemm_wn_mma_kernel found — nothing was checked")
+        sys.exit(2)
+    names = sorted(set(r[0] for r in reports))
+    dem = dict(zip(names, subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.strip().split("\n"))) if names else {}
+    print(f"isa_asmloads: {seen} MFMA tile kernels replayed; destination of an outstanding load touched early in {len(names)} kernels")
+    for (fn, a, t, r) in reports[:40]:
+        print(f"  EARLY {dem.get(fn, fn)[:120]} @{a}: {t[:80]}  (v{r})")
+    sys.exit(1 if reports else 0)
