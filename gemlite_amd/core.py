@@ -49,8 +49,57 @@ GEMLITE_ACC_DTYPE = {
     DType.NVFP4: DType.FP32,
 }
 
-GEMLITE_HIP_CONFIG_CACHE: dict = {}  # tuning hints keyed like the reference's autotune cache
+_CACHE_EPOCH = [0]  # bumped by every mutation of the tuning table: the C++ fast path caches tuning[] per (layer, M) for one epoch
+
+
+class _EpochDict(dict):
+    """A dict that counts its mutations (and those of the family dicts stored in it) in _CACHE_EPOCH — the tuning table is a plain
+    module-level dict that load_config(), the autoloader, helper.autotune_layer() and user code all write to directly."""
+
+    def _wrap(self, v):
+        return _EpochDict(v) if type(v) is dict else v
+
+    def __setitem__(self, k, v):
+        _CACHE_EPOCH[0] += 1
+        super().__setitem__(k, self._wrap(v))
+
+    def __delitem__(self, k):
+        _CACHE_EPOCH[0] += 1
+        super().__delitem__(k)
+
+    def setdefault(self, k, default=None):
+        if k not in self:
+            self[k] = default
+        return self[k]
+
+    def update(self, *a, **kw):
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+    def clear(self):
+        _CACHE_EPOCH[0] += 1
+        super().clear()
+
+    def pop(self, *a):
+        _CACHE_EPOCH[0] += 1
+        return super().pop(*a)
+
+    def popitem(self):
+        _CACHE_EPOCH[0] += 1
+        return super().popitem()
+
+
+GEMLITE_HIP_CONFIG_CACHE: dict = _EpochDict()  # tuning hints keyed like the reference's autotune cache
 GEMLITE_TRITON_CONFIG_CACHE = GEMLITE_HIP_CONFIG_CACHE  # reference name
+
+# ---- the C++ eager host path (gemlite_amd/csrc_torch/fast_forward.cpp -> gemlite_amd/_fast.so): optional, the ctypes path below is
+#      complete without it.  GEMLITE_HIP_NO_FAST_PATH=1 disables it.
+try:
+    if os.environ.get("GEMLITE_HIP_NO_FAST_PATH"):
+        raise ImportError("disabled")
+    from . import _fast as _FAST  # noqa: E402
+except Exception:  # not built (build() makes it), or a torch it was not built against
+    _FAST = None
 _FILE_LOCK = threading.Lock()
 
 
@@ -545,8 +594,53 @@ class GemLiteLinearHIP(torch.nn.Module):
     def forward_manual(self, x: Tensor, matmul_type: str = "GEMM") -> Tensor:
         return self._call(x, GEMLITE_MATMUL_TYPES_MAPPING[matmul_type])
 
+    # The attributes a launch template is derived from: assigning any of them drops the layer's C++ handle (tensors whose storage is
+    # replaced in place — module.to(), param.data = ... — are caught inside the C++ call by their data pointers).
+    _FAST_FIELDS = frozenset(("W_q", "scales", "zeros", "bias") + _META_FIELDS)
+
+    def __setattr__(self, name, value):
+        if name in GemLiteLinearHIP._FAST_FIELDS:
+            self.__dict__["_fast"] = None
+            self.__dict__["_fast_tried"] = None
+        super().__setattr__(name, value)
+
+    def _install_fast(self):
+        """Per-layer C++ launch handle for `layer(x)` (weight-only layers with 16-bit activations): (capsule, W_q, scales, zeros, bias)."""
+        d = self.__dict__
+        d["_fast"] = None
+        d["_fast_tried"] = _CACHE_EPOCH[0]
+        if _FAST is None or self.W_q is None or not self.W_q.is_cuda or self.elements_per_sample is None:
+            return
+        meta = self.get_meta_args()
+        if meta[0] or meta[5] not in (DType.FP16.value, DType.BF16.value):
+            return
+        W_q, scales, zeros = self.get_tensor_args()
+        cap = _FAST.make(_build_template(W_q, scales, zeros, meta), W_q, scales, zeros, _CACHE_EPOCH[0], not GEMLITE_HIP_CONFIG_CACHE)
+        if cap is not None:
+            d["_fast"] = (cap, W_q, scales, zeros, self.bias)
+
     def forward_auto_no_warmup(self, x: Tensor) -> Tensor:
-        return self._call(x, -1)
+        d = self.__dict__
+        f = d.get("_fast")
+        if f is not None and TUNING_OVERRIDE is None and not torch.compiler.is_compiling():
+            y = _FAST.forward(f[0], f[1], f[2], f[3], x, f[4], -1, _CACHE_EPOCH[0])
+            if y is NotImplemented:  # a tuning table is loaded and this M has not been looked up at this epoch yet
+                a = _static_args(f[1], f[2], f[3], self.get_meta_args())
+                M = x.numel() // max(1, x.shape[-1])
+                a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
+                _FAST.set_tuning(f[0], M, lookup_tuning(-1, M, a))
+                y = _FAST.forward(f[0], f[1], f[2], f[3], x, f[4], -1, _CACHE_EPOCH[0])
+            if y is False:  # the handle is stale (tensors moved, tuning table changed): rebuilt behind the slow call below
+                d["_fast"] = None
+                d["_fast_tried"] = None
+            elif y is not None and y is not NotImplemented:
+                return y
+        y = self._call(x, -1)
+        # (after a SUCCESSFUL slow call: errors and the once-per-shape coverage-kernel warning come from that path)
+        if _FAST is not None and d.get("_fast") is None and d.get("_fast_tried") != _CACHE_EPOCH[0] and TUNING_OVERRIDE is None \
+                and x.is_cuda and not torch.compiler.is_compiling():
+            self._install_fast()
+        return y
 
     # ----------------------------------------------------------------------- tuning-hint JSON cache
     @staticmethod

@@ -23,6 +23,7 @@ bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
 bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp);
+bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
@@ -192,6 +193,16 @@ static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
     r.lp.block = dim3(256, 1, 1);
 }
 
+// When the unsplit 64 x 64 A8W8 tiles are the default (profiles/r04/probe_a8w8_sq*.log; everything else keeps the round-3 kernels):
+// more than 64 rows and at most one round of tiles over the CUs (4096^2 int8: M = 65 .. 256 17.0 .. 21.7 -> 11.2 .. 13.6 us, 8192^2 M = 128
+// 28.4 -> 24.2), or up to two rounds of a short K with two blocks per CU (4096^2 M = 384 / 512: 31.5 / 23.9 -> 19.3 / 21.5 us; at
+// K = 8192 two rounds lose: 8192^2 M = 256 39.4 vs 34.4)
+static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
+    if (a.M <= 64 || a.N % 64 != 0) return false;
+    const int64_t tiles = (a.N / 64) * ((a.M + 63) / 64);
+    return tiles <= 256 || (tiles <= 512 && a.K <= 4096);
+}
+
 static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
     r.status = validate(&a);
     if (r.status != GEMLITE_OK) return;
@@ -326,9 +337,17 @@ coverage:
         r.kind = K_KMAJOR;  // GenericParams, no workspace
         return;
     }
+    // A8W8 (int8 / fp8), round 4: 64 x 64 tiles with K unsplit where they fill the chip about once (config 4 at M = 256: 256 tiles) —
+    // tuning[0] = 5 forces them, tuning[0] = 6 keeps the round-3 choice
+    if (!packed && a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
+        a.matmul_type != GEMLITE_MATMUL_GEMV_REVSPLITK &&
+        (a.tuning[0] == 5 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 64) && a8w8_sq_pays(a))) && plan_gemm_a8w8_sq(a, r.gp, r.lp)) {
+        r.kind = K_A8_MMA;
+        return;
+    }
     // A8W8 (int8 / fp8) from 2 rows: the 8-wave MFMA kernel.  tuning[0]: 1 = streaming kernel (one wave per column),
     // 2 = the 4-wave MFMA kernel of round 1 (M >= 32)
-    if (!packed && a.tuning[0] == 0 && a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
+    if (!packed && (a.tuning[0] == 0 || a.tuning[0] == 6) && a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
         a.matmul_type != GEMLITE_MATMUL_GEMV_REVSPLITK && plan_gemm_a8w8_mma(a, r.gp, r.lp)) {
         r.kind = K_A8_MMA;
         return;

@@ -608,6 +608,195 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_lds_kernel(const GenericPara
     a8_epilogue<DT, MI>(p, acc, smem, tid, lane, cg, kh, col, h, bid, slice, m0, nt);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: 64 x 64 tiles, K NOT split ("gemm_a8w8_sq_kernel").  At config 4 (int8, 4096^2, M = 256) the matrix pipes need 1.7 us
+// and every 128-column tiling above lands on 20-24 us (profiles/r03/probe_a8w8_m256_tiles.log: MFMA busy 8 %): 64 tiles of
+// 128 x 128 need four K slices to fill 256 CUs, and a launch is then prologue + a 4-slice combine through memory around a
+// 2-us loop.  Nothing is dequantised here, so a small tile costs no arithmetic — only operand traffic: a 64 x 64 tile
+// reads (64 + 64) bytes per k for 8192 int8 operations, i.e. its loop is bound by the CU's 64 B/clk vector-memory path (512 KB per
+// block at K = 4096 = ~3.9 us), 4 row tiles x 64 column tiles = 256 blocks fill the chip WITHOUT splitting K, and the
+// epilogue is a plain store.  8 waves: wave (rb, cb, kh) owns the 32 x 32 block (rb, cb) of the tile and half of every
+// 256-byte K step; both operands travel as 1-KiB LDS-DMA pieces (4 rows x 256 contiguous bytes, full cache lines) into
+// NST stages of [64 x rows | 64 weight rows] x 256 B, 16-byte slots XOR-swizzled with (row & 15) through the source address; one
+// counted wait + one barrier per step, the DMAs of the stage just freed go out right behind the barrier.  The four blocks that
+// share a weight column tile sit on ONE XCD (block b runs on XCD b % 8; speed only) so that three of them read it from L2.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT, int NST>
+__global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(const GenericParams p) {
+    using namespace async;
+    using AC = A8Acc<DT>;
+    typedef typename AC::T acc_t;
+    constexpr bool INT = DT == GEMLITE_DT_INT8;
+    constexpr int BM = 64, BN = 64, KSTEP = 256, PITCH = KSTEP, KW = KSTEP / 2, NS = KW / 32;
+    constexpr int STAGE = (BM + BN) * PITCH;               // x rows, then weight rows
+    constexpr int PX = BM * PITCH / 1024 / 8, PW = BN * PITCH / 1024 / 8, PT = PX + PW;  // DMA pieces per wave and stage
+    static_assert(PX == 2 && PW == 2 && NS == 4 && NST >= 2, "64 x 64 x 256 B");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST][STAGE], later the epilogue tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = (wave >> 1) & 1, cb = wave & 1, kh = wave >> 2;
+    const int col = lane & 31, h = lane >> 5;
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = p.N / BN;
+    int mt, nt;
+    {
+        const int lin = blockIdx.x;
+        if ((ntiles & 7) == 0) {  // the row tiles of one weight column tile on one XCD, back to back in its dispatch order
+            const int xcd = lin & 7, idx = lin >> 3;
+            mt = idx % mtiles;
+            nt = (idx / mtiles) * 8 + xcd;
+        } else {
+            mt = lin % mtiles;
+            nt = lin / mtiles;
+        }
+    }
+    const int m0 = mt * BM;
+    const int nsteps = p.K / KSTEP;
+
+    const srd_t rsX = make_srd(p.x, (uint32_t)((int64_t)(p.M - 1) * p.stride_xm + p.K));
+    const srd_t rsW = make_srd(p.w, (uint32_t)((int64_t)(p.N - 1) * p.stride_wn + p.K));
+    // piece j of wave w covers LDS bytes [(w * 2 + j) * 1024, +1024) of its region: row = byte / 256, physical 16-byte slot
+    // (byte % 256) / 16 holds the logical slot phys ^ (row & 15)
+    uint32_t xvoff[PX], wvoff[PW];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int byte = (wave * PX + j) * 1024 + lane * 16;
+        const int r = byte / PITCH, phys = (byte % PITCH) / 16;
+        const int logical = phys ^ (r & 15);
+        xvoff[j] = m0 + r < p.M ? (uint32_t)((int64_t)(m0 + r) * p.stride_xm + logical * 16) : 0x80000000u;  // rows >= M: zeros
+    }
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int byte = (wave * PW + j) * 1024 + lane * 16;
+        const int r = byte / PITCH, phys = (byte % PITCH) / 16;
+        const int logical = phys ^ (r & 15);
+        wvoff[j] = (uint32_t)((int64_t)(nt * BN + r) * p.stride_wn + logical * 16);
+    }
+    const uint32_t ldsx = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PX) * 1024u);
+    const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(BM * PITCH) + (uint32_t)(wave * PW) * 1024u);
+    auto request = [&](int stage, int step) __attribute__((always_inline)) {
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], so);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) req_lds16(rsW, ldsw + (uint32_t)(stage * STAGE + j * 1024), wvoff[j], so);
+    };
+    // fragments of slice g (32 k): A row rb * 32 + col, B weight row cb * 32 + col, both at byte kh * 128 + g * 32 + h * 16
+    int fa[NS], fb[NS];
+#pragma unroll
+    for (int g = 0; g < NS; ++g) {
+        const int slot = (kh * KW + g * 32 + h * 16) >> 4;
+        const int ra = rb * 32 + col, rw = cb * 32 + col;
+        fa[g] = ra * PITCH + ((slot ^ (ra & 15)) << 4);
+        fb[g] = (BM + rw) * PITCH + ((slot ^ (rw & 15)) << 4);
+    }
+    acc_t acc = AC::zero();
+
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) request(st, st < nsteps ? st : nsteps - 1);
+    auto do_step = [&](auto Jc, int step) __attribute__((always_inline)) {
+        constexpr int stage = decltype(Jc)::value, stage_fill = (stage + NST - 1) % NST;
+        wait_vm<(NST - 2) * PT>();  // this step's pieces have landed (the later stages' stay in flight)
+        __builtin_amdgcn_s_barrier();  // ... everybody's have, and everybody is done reading the stage refilled next
+        asm volatile("" ::: "memory");
+        request(stage_fill, step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1);  // past the end: repeat the last step (never consumed)
+        u32x4 a[NS], b[NS];
+#pragma unroll
+        for (int g = 0; g < NS; ++g) {
+            a[g] = *(const u32x4*)(smem + stage * STAGE + fa[g]);
+            b[g] = *(const u32x4*)(smem + stage * STAGE + fb[g]);
+        }
+        if constexpr (INT) {
+#pragma unroll
+            for (int g = 0; g < NS; ++g) acc = AC::mma(a[g], b[g], acc);
+        } else {
+#pragma unroll
+            for (int g = 0; g < NS; g += 2) acc = AC::mma64(a[g], a[g + 1], b[g], b[g + 1], acc);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the stage are complete before it reaches the next barrier
+    };
+    auto chain = [&](auto self, auto Jc, int s0) -> void {
+        constexpr int J = decltype(Jc)::value;
+        do_step(std::integral_constant<int, J>{}, s0 + J);
+        if constexpr (J + 1 < NST) {
+            if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
+        }
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += NST) chain(chain, std::integral_constant<int, 0>{}, s0);
+    wait_vm<0>();
+    __syncthreads();
+
+    // ---- epilogue: add the two K halves (raw accumulator words: int32 stays exact), transpose through LDS, 16-byte output rows
+    typedef typename std::conditional<INT, int, float>::type word_t;
+    typedef word_t word4 __attribute__((ext_vector_type(4)));
+    constexpr int C_PITCH = BN + 4;
+    {
+        acc_t* xch = (acc_t*)smem;  // [rb][cb][lane]
+        if (kh == 1) xch[(rb * 2 + cb) * 64 + lane] = acc;
+        __syncthreads();
+        if (kh == 0) acc += xch[(rb * 2 + cb) * 64 + lane];
+        __syncthreads();
+    }
+    word_t* ct = (word_t*)smem;  // [64][C_PITCH]
+    if (kh == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            ct[r * C_PITCH + cb * 32 + col] = acc[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + 512 * i, r = u >> 4, c4 = (u & 15) * 4;
+        const int m = m0 + r;
+        if (m < p.M) {
+            const word4 v = *(const word4*)(ct + r * C_PITCH + c4);
+            store_out4_any(p.epi, (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, m, (int64_t)nt * BN + c4);
+        }
+    }
+}
+
+bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
+    if (a.elements_per_sample != 1 || a.W_group_mode != 0 || a.M < 2) return false;
+    if (a.w_dtype != a.input_dtype) return false;
+    if (!(a.input_dtype == GEMLITE_DT_INT8 || a.input_dtype == GEMLITE_DT_FP8E4 || a.input_dtype == GEMLITE_DT_FP8E5)) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 64 != 0 || a.K % 256 != 0) return false;
+    if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
+    if ((int64_t)a.M * a.stride_xm >= (1ll << 31) || (int64_t)a.N * a.stride_wn >= (1ll << 31)) return false;
+    if (!(a.output_dtype == GEMLITE_DT_FP32 || a.output_dtype == GEMLITE_DT_FP16 || a.output_dtype == GEMLITE_DT_BF16)) return false;
+    if ((a.channel_scale_mode == 1 || a.channel_scale_mode == 3) &&
+        !(a.meta_dtype == GEMLITE_DT_FP32 || a.meta_dtype == GEMLITE_DT_FP16 || a.meta_dtype == GEMLITE_DT_BF16)) return false;
+    if ((a.channel_scale_mode == 1 || a.channel_scale_mode == 3) && ((uintptr_t)a.scales % 16) != 0) return false;
+    const int oal = a.output_dtype == GEMLITE_DT_FP32 ? 16 : 8;  // 4 outputs per store
+    if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
+    const int64_t tiles = (int64_t)(a.N / 64) * ((a.M + 63) / 64);
+    // tuning[0] = 5 forces this kernel.  Automatic: see the caller (api.hip) — 65 .. 256 rows whose 64 x 64 tiles fill the chip once
+    typedef void (*fn_t)(const GenericParams);
+    // tuning[2] = 2 / 3: two (64 KB of LDS: two blocks per CU) / three stages (development A/B); default four
+    // (one round of tiles: 4 stages in flight per block; two rounds: 2 stages = 64 KB of LDS, two co-resident blocks per CU cover each
+    //  other's prologue and epilogue — 4096^2 int8 M = 384: 24.4 us with 4 stages, 19.3 with 2; M = 256: 13.6 vs 17.9)
+    const int nst = (a.tuning[0] == 5 && (a.tuning[2] == 2 || a.tuning[2] == 3 || a.tuning[2] == 4)) ? a.tuning[2] : (tiles <= 256 ? 4 : 2);
+    fn_t fn = nullptr;
+    auto pick = [&](auto dt) -> fn_t {
+        constexpr int DT = decltype(dt)::value;
+        return nst == 2 ? gemm_a8w8_sq_kernel<DT, 2> : (nst == 3 ? gemm_a8w8_sq_kernel<DT, 3> : gemm_a8w8_sq_kernel<DT, 4>);
+    };
+    fn = a.input_dtype == GEMLITE_DT_INT8 ? pick(std::integral_constant<int, GEMLITE_DT_INT8>{})
+         : (a.input_dtype == GEMLITE_DT_FP8E4 ? pick(std::integral_constant<int, GEMLITE_DT_FP8E4>{}) : pick(std::integral_constant<int, GEMLITE_DT_FP8E5>{}));
+    g.splitk = 1;
+    g.flags = a.tuning[3];
+    lp.fn = (const void*)fn;
+    lp.name = "gemm_a8w8_sq_kernel<64x64>";
+    lp.grid = dim3((unsigned)tiles, 1, 1);
+    lp.block = dim3(512, 1, 1);
+    lp.lds_bytes = (size_t)nst * (64 + 64) * 256;
+    if (lp.lds_bytes < 64 * 68 * 4) lp.lds_bytes = 64 * 68 * 4;
+    lp.ws_bytes = 0;
+    lp.slab_bytes = 0;
+    return true;
+}
+
 typedef void (*a8_kernel_fn)(const GenericParams);
 template <int DT>
 static const void* a8_pick(int mi) {

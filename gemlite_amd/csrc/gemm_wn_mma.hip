@@ -86,7 +86,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     const int nbits = a.W_nbits;
     if (nbits != 4 && nbits != 2 && nbits != 1 && nbits != 8) return false;
     const int e = 32 / nbits;
-    if (a.N % mma::BN != 0) return false;
+    if (a.N % 64 != 0) return false;  // (128 for everything but the narrow tiles: checked behind them)
     // Activation type: the 16-bit float of the kernel's Tag, or 8 bits (fp8 e4m3 / int8: A8Wn dynamic, BitNet int8) with a
     // 16-bit output.  Tag = the type of the metadata read in the K loop = the output type (any of fp16 / bf16 / fp32 output
     // and fp32 channel scales go through the untyped epilogue store).
@@ -132,6 +132,65 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         return rounds * (P[i] + steps * S[i] + (sk > 1 ? Q[i] + sk * R[i] : 0.0)) + 0.0955 * slab_mb + 0.0484 * x_mb;
     };
     int mi = 0, splitk = 0;
+    // narrow tiles (32 MI x 64, KH = 4; round 4): tuning[2] = 32 + variant forces them (variants: gemm_wn_mma_kernel.inc, mma_pick_narrow);
+    // tuning[3] & 16384 keeps the round-3 choice (A/B runs)
+    // Automatic, from a sweep of 20 LLM layer shapes x M = 128 / 192 / 256 x {64 x 64, 64 x 64 x 2 slices, 128 x 64, 128 x 64 x 2} against
+    // the round-3 choice (profiles/r04/probe_mma_narrow_llm_shapes.log).  t64 = 64 x 64 tiles of the problem; every column tile re-reads
+    // its rows of x from L2, x_bytes = (N / 64) * M * K * 2 in total:
+    //   * 192 <= t64 <= 256 and x_bytes <= 160 MB: K UNSPLIT — all ten such cells win, 0.78 .. 0.89 of the round-3 time (4096^2 M = 256:
+    //     19.8 -> 16.8 us; 8192 x 2048 M = 128: 14.7 -> 11.9); beyond 160 MB the L2 -> LDS path is the limit and K slices win again
+    //     (4096 x 11008 M = 256: 344 MB, 33.3 -> 36.5), below 192 tiles too many CUs idle (5120^2 M = 128: 160 tiles, 18.4 -> 19.3);
+    //   * 96 <= t64 <= 128: TWO K slices (<= 256 blocks: one round) — all eight such cells win, 0.85 .. 0.97 (4096^2 M = 128: 15.4 -> 13.7,
+    //     4096 x 11008 M = 128: 28.4 -> 24.2); with 144 tiles two slices make two rounds (3072 x 8192 M = 192: 22.2 -> 32.9);
+    //   * the 128-row narrow tiles never beat the round-3 choice by more than 1 % in the sweep: forced variants only.
+    int narrow_v = -1, narrow_sk = 0;
+    if (a.tuning[2] >= 32 && a.tuning[2] <= 35) {
+        narrow_v = a.tuning[2] - 32;
+        narrow_sk = a.tuning[1] > 0 ? a.tuning[1] : 1;
+    } else if (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384) && x16 && (nbits == 4 || nbits == 2) &&
+               a.M > 64 && a.N % 64 == 0 && a.K % 256 == 0) {
+        const int64_t t64 = (int64_t)(a.N / 64) * ((a.M + 63) / 64);
+        const int64_t x_bytes = (int64_t)(a.N / 64) * ((a.M + 63) / 64 * 64) * a.K * 2;
+        if (t64 >= 192 && t64 <= 256 && x_bytes <= (160ll << 20)) {
+            narrow_v = 0;
+            narrow_sk = 1;
+        } else if (t64 >= 96 && t64 <= 128 && a.K / 256 >= 8) {
+            narrow_v = 0;
+            narrow_sk = 2;
+        }
+    }
+    if (narrow_v >= 0) {
+        static const int V_MI[4] = {2, 2, 4, 4}, V_KS[4] = {256, 512, 256, 256}, V_NST[4] = {3, 2, 2, 2};
+        const int v = narrow_v, vmi = V_MI[v], ks = V_KS[v], bm = 32 * vmi;
+        if (!x16 || (nbits != 4 && nbits != 2) || a.N % 64 != 0 || a.K % ks != 0) return false;
+        const int rows = (int)(a.K / e), units = (int)(a.K / ks);
+        const int splitk = narrow_sk;
+        if (splitk > units) return false;
+        if ((int64_t)rows * a.stride_wk * 4 >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31)) return false;
+        if (((int64_t)(a.K / (p.group_size > 0 ? p.group_size : a.K)) * p.stride_meta_g + a.N) * 2 >= (1ll << 31)) return false;
+        const int64_t tiles = (int64_t)(a.N / 64) * ((a.M + bm - 1) / bm);
+        if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
+        const bool f16 = tag_dt == GEMLITE_DT_FP16;
+        const void* fn = f16 ? mma_lookup_f16(6, nbits, v, 0, 0) : mma_lookup_bf16(6, nbits, v, 0, 0);
+        if (!fn) return false;
+        p.splitk = splitk;
+        p.rows_per_slice = rows;
+        p.combine = 0;
+        lp.fn = fn;
+        static const char* nn[2][2] = {{"gemm_w4_mma_kernel<64x64>", "gemm_w4_mma_kernel<128x64>"}, {"gemm_w2_mma_kernel<64x64>", "gemm_w2_mma_kernel<128x64>"}};
+        lp.name = nn[nbits == 4 ? 0 : 1][vmi == 2 ? 0 : 1];
+        lp.grid = dim3((unsigned)tiles, splitk, 1);
+        lp.block = dim3(512, 1, 1);
+        const size_t stages = (size_t)V_NST[v] * bm * ks * 2;
+        const size_t xch = (size_t)3 * 2 * vmi * 4 * 64 * 16;  // K-part exchange: [kh - 1][cg][mi][e4][lane] float4
+        const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * (64 + 4) * 4 + 16;
+        lp.lds_bytes = stages > xch ? stages : xch;
+        if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
+        lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * 64 * 4 : 0;
+        lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
+        return true;
+    }
+    if (a.N % mma::BN != 0) return false;
     // wide tiles (32 MI x 256): tuning[2] = 16 + MI (20 / 24) forces them
     const bool wide_ok = x16 && (nbits == 4 || nbits == 2) && a.N % 256 == 0 && a.K % 64 == 0;
     bool wide = (a.tuning[2] == 20 || a.tuning[2] == 24);

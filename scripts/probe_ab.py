@@ -9,7 +9,7 @@ from gemlite_amd.bench_utils import kernel_device_us
 
 DEV = torch.device("cuda:0")
 g = torch.Generator(device=DEV).manual_seed(0)
-CASES = {"cfgA": (4096, 4096, 4, 256, (0, 2, 2, 0), 32), "cfgB": (8192, 8192, 4, 256, (0, 2, 4, 0), 8),
+CASES = {"cfgAn": (4096, 4096, 4, 256, (0, 0, 32, 0), 64), "cfgA": (4096, 4096, 4, 256, (0, 2, 2, 0), 32), "cfgB": (8192, 8192, 4, 256, (0, 2, 4, 0), 8),
          "pre": (8192, 8192, 4, 2048, (0, 0, 0, 0), 8), "w2": (16384, 16384, 2, 256, (0, 0, 0, 0), 2),
          "m64": (4096, 4096, 4, 64, (0, 0, 0, 0), 32), "m1024": (4096, 4096, 4, 1024, (0, 0, 0, 0), 32)}
 for name in (sys.argv[1:] or ["cfgA", "cfgB", "pre"]):

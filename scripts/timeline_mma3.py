@@ -15,6 +15,7 @@ torch.cuda.set_device(0)
 T = 128
 CASES = {"cfgA": ("a16w4_4096_m256", [(0, 0, 0, 0), (0, 2, 2, T), (0, 4, 4, 0), (0, 4, 8, 0)]),
          "cfgB": ("a16w4_8192_m256", [(0, 0, 0, 0), (0, 2, 4, T), (0, 4, 8, 0), (0, 4, 8, T)])}
+CASES["cfgA_r4"] = ("a16w4_4096_m256", [(0, 0, 0, 0), (0, 0, 33, 0), (0, 0, 0, 16384)])   # round 4: narrow tiles (64 x 64, K unsplit) vs the round-3 choice
 for key in (sys.argv[1:] or ["cfgA", "cfgB"]):
     name, tunings = CASES[key]
     for tun in tunings:

@@ -514,13 +514,15 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
     W = (torch.randn(2048, 4096) / 30).half()
     lin = gemlite_amd.helper.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights(W)
     x = (torch.randn(77, 4096) / 10).half().to(DEV)
-    assert _kernel_name(lin, torch.empty(77, 4096, dtype=torch.int8)) == "gemm_a8w8_lds_kernel<128x128>", _kernel_name(lin, x)
+    # (round 4: 65 .. 256 rows whose 64 x 64 tiles fit one round of CUs run the unsplit kernel; the 128-row tile stays behind tuning[0] = 6)
+    assert _kernel_name(lin, torch.empty(77, 4096, dtype=torch.int8)) == "gemm_a8w8_sq_kernel<64x64>", _kernel_name(lin, x)
+    assert _kernel_name(lin, torch.empty(77, 4096, dtype=torch.int8), -1, (6, 0, 0, 0)) == "gemm_a8w8_lds_kernel<128x128>"
     y = lin(x)
     outs = {}
     # streaming kernel | 4-wave MFMA kernel of round 1 | 8-wave kernels: every tile height, K split 1 / 3 (uneven) / 8, weights
     # through LDS (128 / 256 rows, default) and straight from memory (tuning[3] & 64)
     for t in ((1, 0, 0, 0), (2, 0, 0, 0), (0, 1, 1, 0), (0, 3, 2, 0), (0, 8, 4, 0), (0, 1, 8, 0), (0, 5, 8, 0), (0, 3, 4, 0),
-              (0, 8, 4, 64), (0, 1, 8, 64), (0, 5, 8, 64)):
+              (0, 8, 4, 64), (0, 1, 8, 64), (0, 5, 8, 64), (6, 0, 0, 0), (5, 0, 2, 0), (5, 0, 3, 0), (5, 0, 4, 0)):
         gemlite_amd.core.TUNING_OVERRIDE = t
         try:
             outs[t] = lin(x)
@@ -552,10 +554,11 @@ def test_a8w8_lds_kernel_short_and_uneven_k(K):
     lin = gemlite_amd.helper.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights(W)
     for M in (70, 130, 300):
         x = (torch.randn(M, K) / 10).half().to(DEV)
-        want = "gemm_a8w8_lds_kernel<128x128>"
-        assert _kernel_name(lin, torch.empty(M, K, dtype=torch.int8)) == want
+        assert _kernel_name(lin, torch.empty(M, K, dtype=torch.int8), -1, (6, 0, 0, 0)) == "gemm_a8w8_lds_kernel<128x128>"
+        if K % 256 == 0:  # the unsplit 64 x 64 tiles of round 4 (256-byte K steps): fewer steps than stages at K = 256 / 512 / 768
+            assert _kernel_name(lin, torch.empty(M, K, dtype=torch.int8)) == "gemm_a8w8_sq_kernel<64x64>"
         outs = {}
-        for t in (None, (0, 0, 8, 0), (0, 2, 4, 0), (1, 0, 0, 0)):
+        for t in (None, (6, 0, 0, 0), (0, 0, 8, 0), (0, 2, 4, 0), (1, 0, 0, 0)) + (((5, 0, 2, 0), (5, 0, 4, 0)) if K % 256 == 0 else ()):
             gemlite_amd.core.TUNING_OVERRIDE = t
             try:
                 outs[t] = lin(x)
@@ -730,6 +733,52 @@ def test_mma_kernel_wide_tiles(nbits, tdt):
                 torch.cuda.synchronize()
                 _compare(f"mma_wide/w{nbits}/{str(tdt)[6:]}/{N}x{K}/M{M}/mi{mi}/sk{sk}", y, y_or, lin.output_dtype.value,
                          abs_gate=1e-3, extra=dict(kernel=name))
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_mma_kernel_narrow_tiles(nbits, tdt):
+    """Round 4: the 64-column tiles of the 8-wave MFMA kernel (tuning[2] = 32 + variant; four K quarters per step inside the block,
+    K normally NOT split over blocks): 64 / 128 rows, 256- and 512-k steps, 2 / 3 LDS stages, ragged M, several M and N tiles, uneven
+    forced K slices, group sizes 128 and 64, few K steps (K = 512: 1 or 2 steps, fewer than the stages / the register ring) — all
+    against the oracle."""
+    from gemlite_amd.core import _hip_matmul
+    for (N, K, gs) in ((192, 1536, 64), (256, 2560, 128), (128, 512, 128)):
+        lin = _make_layer(N, K, nbits, gs, tdt, seed=75 + nbits)
+        for M in (29, 64, 100, 130, 300):
+            x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
+            y_or = _oracle_from_layer(lin, x)
+            for v in (0, 1, 2, 3):
+                for sk in (0, 1, 2, 3):
+                    tuning = (0, sk, 32 + v, 0)
+                    try:
+                        name = _kernel_name(lin, x, 4, tuning)
+                    except Exception:
+                        continue  # more slices than K steps
+                    if not name.startswith(f"gemm_w{nbits}_mma_kernel<{64 if v < 2 else 128}x64>"):
+                        assert sk > (K // (512 if v == 1 else 256)), (name, tuning)  # only an impossible split may fall elsewhere
+                        continue
+                    y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 4, tuning)
+                    torch.cuda.synchronize()
+                    _compare(f"mma_narrow/w{nbits}/{str(tdt)[6:]}/{N}x{K}/M{M}/v{v}/sk{sk}", y, y_or, lin.output_dtype.value,
+                             abs_gate=1e-3, extra=dict(kernel=name))
+
+
+def test_mma_kernel_narrow_tiles_all_modes_and_headline_choice():
+    """Every W_group_mode through the narrow tiles, and the planner's choice at the headline shape (cfgA, M = 256: 64 x 64 tiles, K
+    unsplit — 20.3 -> 17.4 us, profiles/r04/probe_mma_narrow_*.log)."""
+    from gemlite_amd.core import _hip_matmul
+    for mode, kw in (("fma", {}), ("sub_mul", dict(fma=False)), ("symmetric", dict(zeros_kind="none")), ("int_zero", dict(zeros_kind="int"))):
+        lin = _make_layer(256, 1024, 4, 128, torch.bfloat16, seed=83, **kw)
+        x = torch.from_numpy(O.gen_x(200, 1024, seed=5).astype(np.float32)).to(torch.bfloat16).to(DEV)
+        y_or = _oracle_from_layer(lin, x)
+        for v in (0, 2):
+            y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 4, (0, 0, 32 + v, 0))
+            torch.cuda.synchronize()
+            _compare(f"mma_narrow/modes/{mode}/v{v}", y, y_or, lin.output_dtype.value, abs_gate=1e-3)
+    lin = _make_layer(4096, 4096, 4, 128, torch.bfloat16, seed=84)
+    x = torch.from_numpy(O.gen_x(256, 4096, seed=6).astype(np.float32)).to(torch.bfloat16).to(DEV)
+    assert _kernel_name(lin, x) == "gemm_w4_mma_kernel<64x64>", _kernel_name(lin, x)
 
 
 @pytest.mark.parametrize("K", [64, 128, 256, 384])

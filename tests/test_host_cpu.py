@@ -146,8 +146,10 @@ def test_struct_abi_and_validation():
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64,8w>"),   # 2-bit, long K: two waves per SIMD
     (dict(M=16), "gemm_wn_direct_kernel<tile32,8w>"),
     (dict(M=1, mt=4), "gemm_w4_mma_kernel<32x128>"),   # manual GEMM family at M=1 -> the tiled MFMA kernel
-    (dict(M=128), "gemm_w4_mma_kernel<64x128>"),
-    (dict(M=256), "gemm_w4_mma_kernel<64x128>"),       # cfgA: 128 tiles x 2 K slices (18.6 us vs 30.4 for 256-row tiles x 8)
+    (dict(M=128), "gemm_w4_mma_kernel<64x64>"),        # round 4: 128 narrow tiles x 2 K slices (15.4 -> 13.7 us)
+    (dict(M=256), "gemm_w4_mma_kernel<64x64>"),        # cfgA: 256 narrow tiles, K UNSPLIT: no slab + ticket combine (19.8 -> 16.8 us)
+    (dict(M=256, tuning=(0, 0, 0, 16384)), "gemm_w4_mma_kernel<64x128>"),   # tuning[3] & 16384: the round-3 choice, 128 tiles x 2 K slices
+    (dict(M=256, N=4096, K=11008), "gemm_w4_mma_kernel<128x128>"),   # 344 MB of x re-reads through L2: the narrow tiles lose (33.3 vs 36.5 us)
     (dict(M=256, N=8192, K=8192, in_dt=2), "gemm_w4_mma_kernel<128x128>"),   # cfgB
     (dict(M=256, tuning=(0, 0, 8, 0)), "gemm_w4_mma_kernel<256x128>"),   # tuning[2]: tile rows / 32
     (dict(M=256, tuning=(2, 0, 8, 0)), "gemm_w4_tiled_kernel<256x128>|ab"),   # built with `make AB=1` only
@@ -156,7 +158,7 @@ def test_struct_abi_and_validation():
     (dict(M=1024, N=8192, K=8192, in_dt=2), "gemm_w4_mma_kernel<256x128>"),   # 128 wide tiles do not
     (dict(M=256, N=8192, K=8192, in_dt=2, tuning=(0, 4, 20, 0)), "gemm_w4_mma_kernel<128x256>"),   # tuning[2] = 16 + rows / 32
     (dict(M=4096, N=16384, K=16384, nbits=2), "gemm_w2_mma_kernel<256x256>"),
-    (dict(M=256, nbits=2), "gemm_w2_mma_kernel<64x128>"),
+    (dict(M=256, nbits=2), "gemm_w2_mma_kernel<64x64>"),
     (dict(M=256, N=16384, K=16384, nbits=2), "gemm_w2_mma_kernel<256x128>"),   # BASELINE config 5
     (dict(M=4, mt=3), "gemm_wn_direct_kernel<tile16>"),  # manual GEMM_SPLITK
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
@@ -170,10 +172,12 @@ def test_struct_abi_and_validation():
     (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<64x16>"),
     (dict(M=64, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<64x16>"),
     (dict(M=64, N=8192, K=8192, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),   # <= 64 rows: weights straight from memory
-    (dict(M=65, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),
-    (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # fp8 x fp8, from 65 rows: both operands through LDS
+    (dict(M=65, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # round 4: unsplit 64 x 64 tiles while they fit
+    (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),  # one round of CUs (config 4: 21.7 -> 13.6 us) ...
+    (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_lds_kernel<128x128>"),   # (tuning[0] = 6: the round-3 tile, both operands through LDS)
+    (dict(M=256, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # ... two rounds of a long K: the 128-row tile
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 0, 64)), "gemm_a8w8_mma_kernel<128x128>"),   # A/B switch
-    (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),
+    (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # two rounds at K = 4096: 2 stages, two blocks per CU
     (dict(M=1024, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # 256-row tiles would leave half the chip idle
     (dict(M=4096, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<256x128>"),
     (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<256x128>"),  # config 5: 128 tiles x 2 slices of a long K
