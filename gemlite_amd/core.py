@@ -181,6 +181,7 @@ TUNING_OVERRIDE = None  # development hook: 4 ints forwarded as gemlite_hip_forw
 # from (addresses, shapes, strides, dtypes, numel, device, meta ints): an address reused by the allocator either
 # misses, or hits an entry that is correct by construction.
 _TEMPLATES: dict = {}
+_TEMPLATES_LOCK = threading.Lock()
 _SIZEOF_ARGS = _hip.C.sizeof(_hip.ForwardArgs)
 
 
@@ -230,9 +231,10 @@ def _static_args(W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args) -> _hip.
     t = _TEMPLATES.get(key)
     if t is None:
         t = _build_template(W_q, scales, zeros, meta_args)
-        while len(_TEMPLATES) >= 8192:  # oldest entry out (dicts keep insertion order), not the whole table
-            _TEMPLATES.pop(next(iter(_TEMPLATES)), None)
-        _TEMPLATES[key] = t
+        with _TEMPLATES_LOCK:  # (two threads evicting at once: "dictionary changed size during iteration")
+            while len(_TEMPLATES) >= 8192:  # oldest entry out (dicts keep insertion order), not the whole table
+                _TEMPLATES.pop(next(iter(_TEMPLATES)), None)
+            _TEMPLATES[key] = t
     return _hip.ForwardArgs.from_buffer_copy(t)
 
 
@@ -359,22 +361,19 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
     elif bool(meta_args[0]) and DType(in_code) in FP8_INT8_DTYPES:
         # dynamic per-token activation quantisation (core.py:155-175).  One row of 16-bit activations against unpacked
         # 8-bit weights (decode): the library quantises x inside the matmul kernel's prologue — one launch, not two.
-        fused = (FUSE_ACT_QUANT_M1 and x.numel() == x.shape[-1] and meta_args[4] == 1 and meta_args[10] == 0 and
-                 x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0)
+        # (the fused kernel's own preconditions — api.hip: K-contiguous weights, K % 16 == 0, K <= 65536, 16-byte aligned rows —
+        #  are checked HERE, so a layer that runs at M = 2 also runs at M = 1 without catching the library's refusal)
+        K_ = x.shape[-1]
+        fused = (FUSE_ACT_QUANT_M1 and x.numel() == K_ and meta_args[4] == 1 and meta_args[10] == 0 and
+                 x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0 and K_ % 16 == 0 and K_ <= 65536 and
+                 W_q.stride(0) == 1 and W_q.stride(1) % 16 == 0 and W_q.data_ptr() % 16 == 0 and
+                 (x.is_contiguous() and x.data_ptr() % 16 == 0))
         if not fused:
             x, scales_x = scale_activations_per_token(x, w_dtype=DTYPE_TO_TORCH[in_code])
     x2 = x if x.dim() == 2 else x.view(-1, x.shape[-1])
     # matmul_type < 0 (auto) is resolved inside the library: the HIP kernel families have their own M
     # thresholds (GEMV <= 4 rows, streaming MFMA above), unlike the Triton ones of get_matmul_type()
-    try:
-        out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type)
-    except (NotImplementedError, ValueError):
-        # the fused-quantisation kernel has stricter preconditions than the two-launch path (K % 16, 16-byte aligned views,
-        # K <= 65536: api.hip): a layer that runs at M = 2 must not fail at M = 1 — quantise separately and launch again
-        if not (bool(meta_args[0]) and scales_x is None and DType(in_code) in FP8_INT8_DTYPES and x2.dtype in (torch.float16, torch.bfloat16)):
-            raise
-        xq, scales_x = scale_activations_per_token(x2, w_dtype=DTYPE_TO_TORCH[in_code])
-        out = _hip_matmul(xq, W_q, scales, zeros, scales_x, meta_args, matmul_type)
+    out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type)
     if len(out_shape) != 2:
         out = out.view(out_shape)
     if bias is not None:

@@ -226,7 +226,9 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         p.w_mode = a.W_group_mode;
         p.meta_dt = a.meta_dtype; p.zeros_dt = a.zeros_dtype; p.zero_is_scalar = a.zero_is_scalar;
         p.stride_xm = a.stride_xm; p.stride_xk = a.stride_xk; p.stride_wk = a.stride_wk;
-        p.stride_meta_g = per_group_meta ? a.stride_meta_g : 0;
+        // one metadata row spanning all of K ([1, N] scales of a K-long group): the row stride is never used, and views of a
+        // [N, 1] tensor carry arbitrary values there (1 for `.t()`), which the planners' alignment checks would reject
+        p.stride_meta_g = (per_group_meta && eff_group < a.K) ? a.stride_meta_g : 0;
         p.flags = a.tuning[3];
         p.gs_shift = eff_group >= a.K ? 31
                      : ((eff_group > 0 && (eff_group & (eff_group - 1)) == 0) ? __builtin_ctz((unsigned)eff_group) : -1);
@@ -407,8 +409,16 @@ static int launch(const void* fn, dim3 grid, dim3 block, void** kargs, size_t ld
     return GEMLITE_OK;
 }
 
-static std::atomic<int> g_cu_count{256};
-int gl::resident_block_limit() { return g_cu_count.load(std::memory_order_relaxed); }
+// CU count PER DEVICE (one process-global minimum made the planners' choices depend on which other devices the process had
+// touched).  gemlite_hip_forward names the device it plans for (tl_plan_dev); the host-only queries (gemlite_hip_kernel_name,
+// gemlite_hip_query, gemlite_hip_workspace_bytes) plan for a full 256-CU part, whatever was launched before.
+static std::atomic<int> g_cu_by_dev[64];
+static thread_local int tl_plan_dev = -1;
+int gl::resident_block_limit() {
+    if (tl_plan_dev < 0) return 256;
+    const int n = g_cu_by_dev[tl_plan_dev & 63].load(std::memory_order_relaxed);
+    return n > 0 ? n : 256;
+}
 
 // The current device must be a gfx950 part: the code object holds no other ISA.  Checked once per device id.
 static int check_device(int* dev_out) {
@@ -421,9 +431,8 @@ static int check_device(int* dev_out) {
     if (st == 0) {
         hipDeviceProp_t prop;
         st = (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 2;
-        // the smallest CU count seen bounds what the planners may assume co-resident (partitioned / CU-masked devices report fewer)
-        if (st == 1 && prop.multiProcessorCount > 0 && prop.multiProcessorCount < g_cu_count.load(std::memory_order_relaxed))
-            g_cu_count.store(prop.multiProcessorCount, std::memory_order_relaxed);
+        // what the planners may assume co-resident on THIS device (partitioned devices report fewer CUs)
+        if (st == 1 && prop.multiProcessorCount > 0) g_cu_by_dev[slot].store(prop.multiProcessorCount, std::memory_order_relaxed);
         state[slot].store(st, std::memory_order_relaxed);
     }
     return st == 1 ? GEMLITE_OK : GEMLITE_ERR_NO_DEVICE;
@@ -513,7 +522,9 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
     int dev = 0;
     const int dv = check_device(&dev);  // (before planning: the planners ask for the device's CU count)
     Resolved r;
+    tl_plan_dev = dv == GEMLITE_OK ? dev : -1;
     resolve(*args, r);
+    tl_plan_dev = -1;
     if (r.status != GEMLITE_OK) return r.status;
     if (dv != GEMLITE_OK) return dv;
     hipStream_t st = (hipStream_t)stream;

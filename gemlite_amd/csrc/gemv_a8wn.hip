@@ -2,9 +2,9 @@
 // the reference's A8Wn_HQQ_INT_dynamic (fp8 e4m3 activations, helper.py:502-615) and A8W158_INT_dynamic (BitNet, int8
 // activations x ternary 2-bit codes, helper.py:1006-1062) through gemv_INT_*_kernel (gemv_kernels.py / gemv_revsplitK_kernels.py).
 //
-// Numerics are the reference's: the dequantised weight is cast to the ACTIVATION type before the product
-// (`b.to(a.dtype)`, gemm_kernels.py:384 and the same line of the GEMV kernels) — for fp8 that is a real rounding step per
-// weight, so the group-factored form of gemv_wn.hip (sum x q first, scale once per group) does not apply here: every
+// Numerics are the reference's, per kernel FAMILY: from 2 rows on (GEMM_SPLITK) the dequantised weight is cast to the ACTIVATION
+// type before the product (`b.to(a.dtype)`, gemm_kernels.py:384) — for fp8 that is a real rounding step per weight; at ONE row
+// (GEMV family, dot_prod_mode 0) it stays in the metadata type (round 4: found against the reference's own M = 1 output).  Either way, so the group-factored form of gemv_wn.hip (sum x q first, scale once per group) does not apply here: every
 // weight is dequantised, rounded to e4m3 with the hardware converter and multiplied as fp32; int8 activations use exact
 // integer codes on v_dot4_i32_i8.
 //
@@ -130,8 +130,20 @@ __global__ __launch_bounds__(1024) void gemv_a8wn_kernel(const WnParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float lo = (float)((ev >> (8 * j)) & 0xFFu), hi = (float)((od >> (8 * j)) & 0xFFu);
-                        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_fmaf(lo, A, B), __builtin_fmaf(hi, A, B), 0, false);
-                        const f32x2 wv = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);  // the weight as the e4m3 value the reference multiplies
+                        f32x2 wv;
+                        if constexpr (MB == 1) {
+                            // ONE row = the reference's GEMV family: its dot product is sum(a.to(acc) * b.to(acc)) (dot_prod_mode 0,
+                            // gemv_revsplitK_kernels.py:331-332, fp32 accumulation for fp8 inputs) — the dequantised weight stays in the
+                            // METADATA type, it is NOT rounded to e4m3 there.  (Rounds 2-3 rounded it like the GEMM family does: 2.9 % off
+                            // the reference's own M = 1 output on the MI355X, tests/golden/fullsize_ref_r4.npz a8w4_fp8dyn_m1.)
+                            wv[0] = TR::to_float(TR::from_float(__builtin_fmaf(lo, A, B)));
+                            wv[1] = TR::to_float(TR::from_float(__builtin_fmaf(hi, A, B)));
+                        } else {
+                            // 2 .. 4 rows = the reference's GEMM_SPLITK family: `b.to(a.dtype)` before tl.dot (gemm_splitK_kernels.py) —
+                            // the weight as the e4m3 value the reference multiplies
+                            const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_fmaf(lo, A, B), __builtin_fmaf(hi, A, B), 0, false);
+                            wv = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+                        }
 #pragma unroll
                         for (int m = 0; m < MB; ++m) {
                             accf[m][c] = __builtin_fmaf(xf[m][2 * j], wv[0], accf[m][c]);

@@ -2,7 +2,7 @@
 //
 // Replaces gemv_INT_revsplitK_kernel / gemv_INT_kernel / gemv_INT_splitK_kernel (gemlite/triton_kernels/gemv_revsplitK_kernels.py:226-462,
 // gemv_kernels.py:230-388, gemv_splitK_kernels.py:240-420) for the shapes gemv_w4_decode_kernel (gemv_wn.hip) took in round 3.  Same
-// arithmetic, same partial sums per lane (bit-identical outputs, tested); what changed is everything between "the wave exists" and
+// arithmetic (from the even / odd accumulator split on: without the fp16 pre-scale of x); what changed is everything between "the wave exists" and
 // "its first weight request is out", because at 8.9 MB a launch is latency-bound (1.5 us launch boundary + 0.9 us to
 // the first bytes + 1.3 us of streaming at the HBM rate + tail):
 //   * SCALAR kernel arguments, 14 dwords, compiled with -amdgpu-kernarg-preload-count: the command processor writes them into
@@ -103,7 +103,15 @@ __global__ __launch_bounds__(1024, 1) void gemv_w4_decode3_kernel(const char* wb
     for (int i = 0; i < WP; ++i) wmask[i] = (15u * 0x00010001u) << (4 * i);
 
     auto compute = [&](const Chunk& ck) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // fp16: the second field of a 16-bit window is read 4 bits up (16 q * 2^-24 as an fp16 subnormal).  Its products go to their
+        // own accumulator and the 2^-4 is applied ONCE to the fp32 sum, so nothing is ever rounded: rounds 2-3 (and the first decode3)
+        // scaled the matching x pairs by 2^-4 in fp16 instead, which lost mantissa bits for |x| < 2^-10 (1.8e-3 of mean |y|
+        // at |x| ~ 1e-4, tests/test_gpu_parity.py::test_small_magnitude_fp16_activations_on_the_decode_kernels)
+        float acc[WP][4];
+#pragma unroll
+        for (int wi = 0; wi < WP; ++wi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[wi][j] = 0.f;
         float xsum = 0.f;
         // quad lane j holds dwords (2 (j & 1), 2 (j & 1) + 1) of row j >> 1: row i's dwords d0..d3 = (x0x1)(x2x3)(x4x5)(x6x7)
         const uint32_t a0 = dpp_mov<0x00>(ck.xq[0]), a1 = dpp_mov<0x00>(ck.xq[1]), a2 = dpp_mov<0x55>(ck.xq[0]), a3 = dpp_mov<0x55>(ck.xq[1]);
@@ -118,14 +126,6 @@ __global__ __launch_bounds__(1024, 1) void gemv_w4_decode3_kernel(const char* wb
             xr[3] = __builtin_amdgcn_perm(d3, d1, 0x07060302u);
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) xsum = TR::dot2(xr[dd], TR::ONES2, xsum);
-            if constexpr (WP > 1) {  // fp16: odd pairs * 2^-4 (exact unless x is below 2^-10: see DESIGN §4), the matching fields are read 4 bits up
-#pragma unroll
-                for (int dd = 0; dd < 4; ++dd)
-                    if (dd % WP) {
-                        const h2_t v = __builtin_bit_cast(h2_t, xr[dd]) * (h2_t){(_Float16)(1.0f / (1 << (4 * (dd % WP)))), (_Float16)(1.0f / (1 << (4 * (dd % WP))))};
-                        xr[dd] = __builtin_bit_cast(uint32_t, v);
-                    }
-            }
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {
                 const int win = dd / WP, wi = dd % WP;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(1024, 1) void gemv_w4_decode3_kernel(const char* wb
                 for (int j = 0; j < 4; ++j) {
                     uint32_t h = (ck.w[i][j] >> (4 * WP * win)) & wmask[wi];
                     if constexpr (!SUBN) h |= TR::MAGIC2;
-                    acc[j] = TR::dot2(h, xr[dd], acc[j]);
+                    acc[wi][j] = TR::dot2(h, xr[dd], acc[wi][j]);
                 }
             }
         }
@@ -146,7 +146,8 @@ __global__ __launch_bounds__(1024, 1) void gemv_w4_decode3_kernel(const char* wb
             if (!need_z) z[j] = scalar_zero;
             const float a = s[j] * QSCALE;
             const float b = bz * z[j] * (b_times_s ? s[j] : 1.f);
-            float v = acc[j];
+            float v = acc[0][j];
+            if constexpr (WP > 1) v = __builtin_fmaf(acc[WP - 1][j], 1.0f / 16.0f, v);
             if constexpr (!SUBN) v -= TR::OFF * xsum;
             tot[j] += a * v + b * xsum;
         }

@@ -77,6 +77,30 @@ def case_helper(proc_name, N, K, M, seed, tdt=torch.float16, from_linear=False, 
     return build
 
 
+def case_a8wn(N, K, nbits, gs, M, seed, xseed):
+    """A8Wn_HQQ_INT_dynamic (helper.py:502-615): 4-bit grouped weights under DYNAMICALLY quantised fp8 e4m3 activations."""
+    def build(pkg):
+        W_q, scales, zeros = O.gen_data(N, K, nbits, gs, seed=seed)
+        proc = pkg.helper.A8Wn_HQQ_INT_dynamic(device=DEV, dtype=torch.float16, W_nbits=nbits, fp8=torch.float8_e4m3fn)
+        layer = proc.from_weights(torch.from_numpy(W_q).to(DEV), torch.from_numpy(scales.astype(np.float32)).half().to(DEV),
+                                  torch.from_numpy(zeros.astype(np.float32)).half().to(DEV))
+        x = torch.from_numpy(O.gen_x(M, K, seed=xseed).astype(np.float32)).half().to(DEV)
+        return layer, x
+    return build
+
+
+# Round 4 (VERDICT r3 #8): the kernels added since the first fixture had no reference-output pin — bf16 decode, the 2 .. 8-row
+# MFMA GEMV / few-row kernels, 64 rows, 2-bit bf16 decode, fp8-dynamic activations over packed weights.  Written to
+# fullsize_ref_r4.npz by `--which ref --only <these>`; the first fixture is left as recorded.
+CASES_R4 = (
+    [("cfgA_bf16_m1", case_int(4096, 4096, 4, 128, torch.bfloat16, 1, 0, 1), (1, 4096, 4096))]
+    + [(f"cfgA_{tn}_m{m}", case_int(4096, 4096, 4, 128, tdt, m, 0, m), (m, 4096, 4096))
+       for m in (2, 4, 8, 64) for tn, tdt in (("fp16", torch.float16), ("bf16", torch.bfloat16))]
+    + [("a16w2_16384_bf16_m1", case_int(16384, 16384, 2, 128, torch.bfloat16, 1, 5, 2), (1, 16384, 16384)),
+       ("a8w4_fp8dyn_m1", case_a8wn(4096, 4096, 4, 128, 1, 11, 3), (1, 4096, 4096)),
+       ("a8w4_fp8dyn_m16", case_a8wn(4096, 4096, 4, 128, 16, 11, 4), (16, 4096, 4096)),
+       ("a8w4_fp8dyn_m256", case_a8wn(4096, 4096, 4, 128, 256, 11, 5), (256, 4096, 4096))])
+
 CASES = [
     # name, builder, shape-for-flops
     ("cfgA_fp16_m1", case_int(4096, 4096, 4, 128, torch.float16, 1, 0, 1), (1, 4096, 4096)),
@@ -103,7 +127,7 @@ CASES = [
     ("mx_a4w4_m256", case_helper("A4W4_MXFP_dynamic", 2048, 4096, 256, 35, torch.bfloat16, True), (256, 2048, 4096)),
     ("mx_a16w4_m16", case_helper("A16W4_MXFP", 2048, 4096, 16, 36, torch.bfloat16, True), (16, 2048, 4096)),
     ("nvfp4_m16", case_helper("A4W4_NVFP_dynamic", 2048, 4096, 16, 37, torch.bfloat16, True), (16, 2048, 4096)),
-]
+] + list(CASES_R4)
 
 _FLUSH = None
 
@@ -159,7 +183,8 @@ def main():
     ap.add_argument("--tmp", default="/tmp/gemlite_ref_full")
     ap.add_argument("--budget-s", type=float, default=480.0)
     ap.add_argument("--fast-shapes", default="cfgA_fp16_m1,cfgA_bf16_m256,cfgB_bf16_m256")
-    ap.add_argument("--only", default="")
+    ap.add_argument("--only", default="", help="comma-separated case names, or `r4` = the round-4 additions")
+    ap.add_argument("--fixture", default="fullsize_ref.npz", help="file name of the golden fixture written by --which ref")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     os.makedirs(args.tmp, exist_ok=True)
@@ -168,8 +193,9 @@ def main():
     info = {"device": torch.cuda.get_device_properties(0).name, "torch": torch.__version__, "which": args.which,
             "triton": __import__("triton").__version__, "method": "256 MiB flush + event pair per call (benchmark_triton.py:44-60)"}
     golden, report = {}, []
-    only = set(filter(None, args.only.split(",")))
-    out_json = os.path.join(args.out, "reference_triton_mi355x.json" if args.which == "ref" else "hip_same_method.json")
+    only = set(c[0] for c in CASES_R4) if args.only == "r4" else set(filter(None, args.only.split(",")))
+    tag = "_r4" if args.only == "r4" else ""
+    out_json = os.path.join(args.out, f"reference_triton_mi355x{tag}.json" if args.which == "ref" else f"hip_same_method{tag}.json")
 
     def run_phase(mode, names, dump):
         if args.which == "ref":
@@ -212,8 +238,9 @@ def main():
 
     run_phase("default", [c[0] for c in CASES], dump=True)
     if args.which == "ref":
-        np.savez_compressed(os.path.join(args.out, "fullsize_ref.npz"), col0=np.array(COL0), colstep=np.array(COLSTEP), **golden)
-        run_phase("fast", [n for n in args.fast_shapes.split(",") if n], dump=False)
+        np.savez_compressed(os.path.join(args.out, args.fixture), col0=np.array(COL0), colstep=np.array(COLSTEP), **golden)
+        if not only:
+            run_phase("fast", [n for n in args.fast_shapes.split(",") if n], dump=False)
     info["elapsed_s"] = round(time.time() - t_start, 1)
     json.dump({"info": info, "report": report}, open(out_json, "w"), indent=1)
     print("done in", info["elapsed_s"], "s")

@@ -678,7 +678,10 @@ def test_remaining_helper_processors_against_the_oracle(M):
         y_or = O.forward_packed(xq, lin.W_q.data.cpu().numpy(), O.to_f64(lin.scales.data), O.to_f64(lin.zeros.data).reshape(-1)
                                 if lin.zeros.numel() == 1 else O.to_f64(lin.zeros.data), W_nbits=lin.W_nbits, group_size=lin.group_size,
                                 W_group_mode=lin.W_group_mode, channel_scale_mode=lin.channel_scale_mode, scales_x=sx,
-                                zero_is_scalar=lin.zeros.numel() == 1, weight_cast_code=code if code == O.FP8E4 else None)
+                                zero_is_scalar=lin.zeros.numel() == 1,
+                                # M = 1 is the reference's GEMV family: the dequantised weight stays in the metadata type there (fp16
+                                # here; gemv_revsplitK_kernels.py:331-332, pinned by tests/golden/fullsize_ref_r4.npz a8w4_fp8dyn_m1)
+                                weight_cast_code=(O.FP8E4 if M > 1 else O.FP16) if code == O.FP8E4 else None)
         kname = _kernel_name(lin, x)
         want = {(O.FP8E4, 1): "gemv_a8w4_kernel<tile16,16w>", (O.FP8E4, 8): "gemm_a8w4_mma_kernel<32x128>",
                 (O.INT8, 1): "gemv_a8w2_kernel<tile16,16w>", (O.INT8, 8): "gemm_a8w2_mma_kernel<32x128>"}[(code, M)]
@@ -1022,10 +1025,16 @@ def test_a8wn_fp8_activations_on_the_mfma_kernel(nbits, tdt):
             y_or = O.forward_packed(xq, lin.W_q.data.cpu().numpy(), O.to_f64(lin.scales.data), z, W_nbits=nbits,
                                     group_size=lin.group_size, W_group_mode=lin.W_group_mode,
                                     channel_scale_mode=lin.channel_scale_mode, scales_x=sx, weight_cast_code=O.FP8E4)
-            if M <= 4:  # decode sizes: the GEMV-class kernel (per-weight cast to e4m3, K not split across blocks)
+            if M <= 4:  # decode sizes: the GEMV-class kernel (K not split across blocks).  2 .. 4 rows: per-weight cast to e4m3 like
+                # the reference's GEMM_SPLITK family; ONE row = its GEMV family, whose dot product keeps the dequantised weight in the
+                # metadata type (gemv_revsplitK_kernels.py:331-332) — round 4, pinned by the reference's own M = 1 output on the
+                # MI355X (tests/golden/fullsize_ref_r4.npz, a8w4_fp8dyn_m1)
                 y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1)
                 torch.cuda.synchronize()
-                _compare(f"a8wn/w{nbits}/{str(tdt)[6:]}/g{gs}/post{int(post)}/M{M}/gemv", y, y_or, out_code, abs_gate=None)
+                y_or1 = y_or if M > 1 else O.forward_packed(
+                    xq, lin.W_q.data.cpu().numpy(), O.to_f64(lin.scales.data), z, W_nbits=nbits, group_size=lin.group_size,
+                    W_group_mode=lin.W_group_mode, channel_scale_mode=lin.channel_scale_mode, scales_x=sx, weight_cast_code=out_code)
+                _compare(f"a8wn/w{nbits}/{str(tdt)[6:]}/g{gs}/post{int(post)}/M{M}/gemv", y, y_or1, out_code, abs_gate=None)
             for sk in (0, 3):
                 tuning = (0, sk, mi, 0)
                 y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1, tuning)
@@ -1122,3 +1131,80 @@ def test_random_shapes_dtypes_and_modes_against_the_oracle(case):
     # 8-bit codes and shift-only modes give |y| >> 1: the absolute gate of the 4-bit fixtures does not apply
     _compare(f"random/{i}", y, _oracle_from_layer(lin, x), lin.output_dtype.value, abs_gate=None,
              extra=dict(kernel=name, case=[nbits, N, K, gs, M, str(tdt), zk, fma]))
+
+
+def test_cpp_eager_host_path_matches_the_python_path_and_notices_every_change():
+    """gemlite_amd/_fast.so (round 4): `layer(x)` without Python between tensor and launch.  It must return the Python path's bits, and
+    fall back (never use stale pointers / stale tuning) when the layer's tensors are swapped or re-allocated in place, when the tuning
+    table changes, for non-contiguous or wrong-dtype x, and keep bias / batched shapes."""
+    from gemlite_amd import core
+    if core._FAST is None:
+        pytest.skip("gemlite_amd/_fast.so not built")
+    lin = _make_layer(512, 1024, 4, 128, torch.float16, seed=91)
+    x = torch.from_numpy(O.gen_x(3, 1024, seed=2)).to(DEV)
+
+    def slow(layer, xx):
+        return core._forward_impl(xx, layer.bias, layer.get_tensor_args(), layer.get_meta_args(), -1)
+    y0 = lin(x)                      # slow call, installs the handle
+    assert lin.__dict__.get("_fast") is not None
+    y1 = lin(x)                      # fast call
+    assert torch.equal(y0, y1) and torch.equal(y1, slow(lin, x))
+    # batched input + bias
+    lin.bias = torch.randn(512, dtype=torch.float16, device=DEV)
+    assert lin.__dict__.get("_fast") is None          # assigning a template field drops the handle
+    xb = torch.from_numpy(O.gen_x(6, 1024, seed=3)).to(DEV).view(2, 3, 1024)
+    ya = lin(xb)
+    yb = lin(xb)
+    assert lin.__dict__.get("_fast") is not None and yb.shape == (2, 3, 512) and torch.equal(ya, yb) and torch.equal(yb, slow(lin, xb))
+    # tensors re-allocated IN PLACE (what module.to() / param.data = ... do): same Python objects, new storage
+    lin.W_q.data = lin.W_q.data.clone()
+    lin.scales.data = (lin.scales.data.float() * 2).to(lin.scales.dtype)
+    y2 = lin(x)
+    assert torch.equal(y2, slow(lin, x)) and not torch.equal(y2[:, :8], (y1 + lin.bias)[:, :8])
+    y2b = lin(x)
+    assert torch.equal(y2, y2b)
+    # the tuning table changes: handles of the old epoch must not be used
+    a = core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
+    try:
+        core.GEMLITE_HIP_CONFIG_CACHE.setdefault("GEMM_SPLITK", {})[core.config_key(3, a.N, a.K, 128, 8, a.type_id)] = {"tuning": [0, 2, 0, 0]}
+        y3 = lin(x)
+        y3b = lin(x)     # fast again, with the looked-up tuning of this M
+        assert torch.equal(y3, y3b) and torch.equal(y3, slow(lin, x))
+    finally:
+        core.GemLiteLinear.reset_config()
+    # x the fast path does not take: non-contiguous, other dtype (-> the Python path's behaviour, including its errors)
+    xnc = torch.from_numpy(O.gen_x(3, 2048, seed=4)).to(DEV)[:, ::2]
+    assert torch.equal(lin(xnc), slow(lin, xnc.contiguous()))
+    with pytest.raises(Exception):
+        lin(torch.zeros(3, 1000, dtype=torch.float16, device=DEV))   # wrong K: the Python path's ValueError
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("amp", [1e-3, 3e-4, 1e-4])
+def test_small_magnitude_fp16_activations_on_the_decode_kernels(amp):
+    """the fp16 decode kernels of rounds 2-3 pre-scale half of the x pairs by 2^-4 (4-bit; 2^-6 for 2-bit fields) IN fp16 so
+    that one AND yields two products; for |x| below 2^-10 that scaled value is an fp16 subnormal and loses mantissa bits (the reference
+    multiplies the unscaled x — but accumulates its GEMV in fp16, where products of this size are subnormal as well).  The round-4 decode
+    kernel (gemv_decode.hip) keeps the two field positions in separate fp32 accumulators instead and applies the 2^-4 once to the sum:
+    nothing is rounded there, so its error against the float64 oracle is the fp16 rounding of the OUTPUT alone whatever the magnitude
+    of x.  The kernels that still pre-scale (round-3 decode kernel, matrix-core decode kernels at 1 and 3 rows, the 2-bit variant) are
+    bounded: measured 3e-4 / 8e-4 / 1.8e-3 of mean |y| at |x| ~ 1e-3 / 3e-4 / 1e-4 (profiles/r04/pytest_gpu_c16.log)."""
+    from gemlite_amd.core import _hip_matmul
+    bound_scaled = {1e-3: 1e-3, 3e-4: 2e-3, 1e-4: 5e-3}[amp]
+    for nbits, N, K, M, tuning, want, bound in (
+            (4, 1024, 4096, 1, (0, 0, 0, 0), "gemv_w4_decode3_kernel", 4e-4),          # exact products: output rounding only
+            (4, 4096, 4096, 1, (0, 0, 0, 4096), "gemv_w4_decode_kernel", bound_scaled),
+            (4, 8192, 4096, 1, (0, 0, 0, 0), "gemv_mfma_kernel", bound_scaled),
+            (4, 1024, 4096, 3, (0, 0, 0, 0), "gemv_mfma_kernel", bound_scaled),
+            (2, 1024, 4096, 1, (0, 0, 0, 0), "gemv_w2_mfma_kernel", 4 * bound_scaled)):
+        lin = _make_layer(N, K, nbits, 128, torch.float16, seed=95 + nbits)
+        g = np.random.default_rng(7)
+        x = torch.from_numpy((g.standard_normal((M, K)) * amp).astype(np.float16)).to(DEV)
+        name = _kernel_name(lin, x, -1, tuning)
+        assert name.startswith(want), name
+        y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
+        torch.cuda.synchronize()
+        y_or = _oracle_from_layer(lin, x)
+        rel = float(np.abs(y.float().cpu().numpy().astype(np.float64) - y_or).mean() / np.abs(y_or).mean())
+        print(f"small-x amp={amp} {name}: rel={rel:.3e}")
+        assert rel < bound, (amp, name, rel, bound)

@@ -698,3 +698,23 @@ def test_isa_loop_guards_on_the_built_library(script):
     if out.returncode == 2:
         pytest.skip(out.stdout.strip())
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_tuning_table_mutations_bump_the_epoch_of_the_cpp_fast_path():
+    """core.GEMLITE_HIP_CONFIG_CACHE counts its mutations (also those of the family dicts inside it): the C++ eager path caches tuning[]
+    per (layer, M) for one epoch only."""
+    from gemlite_amd import core
+    e0 = core._CACHE_EPOCH[0]
+    try:
+        fam = core.GEMLITE_HIP_CONFIG_CACHE.setdefault("GEMM", {})
+        e1 = core._CACHE_EPOCH[0]
+        fam["(1, 2, 3, 4, 5, 6)"] = {"tuning": [0, 0, 0, 0]}
+        e2 = core._CACHE_EPOCH[0]
+        core.GEMLITE_HIP_CONFIG_CACHE.update({"GEMV": {"k": {"tuning": [1, 0, 0, 0]}}})
+        core.GEMLITE_HIP_CONFIG_CACHE["GEMV"]["k2"] = {"tuning": [2, 0, 0, 0]}
+        e3 = core._CACHE_EPOCH[0]
+        assert e0 < e1 < e2 < e3
+        assert json.loads(json.dumps(core.GEMLITE_HIP_CONFIG_CACHE))["GEMV"]["k2"]["tuning"][0] == 2   # still a plain JSON object
+    finally:
+        core.GemLiteLinear.reset_config()
+    assert core._CACHE_EPOCH[0] > e3 and not core.GEMLITE_HIP_CONFIG_CACHE

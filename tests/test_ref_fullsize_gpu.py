@@ -69,3 +69,34 @@ def test_fixture_is_the_reference_run_recorded_in_profiles():
     rec = json.load(open(os.path.join(ROOT, "profiles", "r03", "reference_triton_mi355x.json")))
     done = {r["case"] for r in rec["report"] if "us" in r}
     assert set(BOUNDS) <= done
+
+
+# ---- round 4: the kernels added after the first fixture, pinned to the reference's outputs as well ------------------
+# tests/golden/fullsize_ref_r4.npz = `python oracle/run_ref_gpu.py --which ref --only r4 --fixture fullsize_ref_r4.npz` on an MI355X
+# (timings: profiles/r04/reference_triton_mi355x_r4.json).  Bounds: the reference's GEMV / GEMM_SPLITK families accumulate (fp16
+# inputs) or round partial sums (bf16 outputs through atomics) in 16 bits — measured distance of the fp32-accumulating HIP kernels
+# 2e-4 (fp16) / 1.7e-3 (bf16) at 2 .. 8 rows, 4.4e-3 at bf16 M = 1; 64 rows is the MFMA tile kernel on both sides (3e-7).
+GOLD_R4 = os.path.join(ROOT, "tests", "golden", "fullsize_ref_r4.npz")
+BOUNDS_R4 = {
+    "cfgA_bf16_m1": 9e-3, "a16w2_16384_bf16_m1": 9e-3,
+    **{f"cfgA_fp16_m{m}": 1e-3 for m in (2, 4, 8)}, **{f"cfgA_bf16_m{m}": 4e-3 for m in (2, 4, 8)},
+    "cfgA_fp16_m64": 1e-4, "cfgA_bf16_m64": 1e-4,
+    "a8w4_fp8dyn_m1": 9e-3, "a8w4_fp8dyn_m16": 9e-3, "a8w4_fp8dyn_m256": 9e-3,
+}
+
+
+@pytest.mark.parametrize("name", sorted(BOUNDS_R4))
+def test_hip_matches_reference_outputs_from_the_mi355x_round4_cases(name):
+    import gemlite_amd
+    from oracle.run_ref_gpu import COL0, COLSTEP
+    gold = np.load(GOLD_R4)
+    assert name in gold.files, f"{name} missing from the fixture"
+    layer, x = _cases()[name](gemlite_amd)
+    y = layer(x)
+    torch.cuda.synchronize()
+    dt = str(gold[name + "__dtype"])
+    ref = torch.from_numpy(gold[name]).view({"torch.float16": torch.float16, "torch.bfloat16": torch.bfloat16}[dt]).float().numpy().astype(np.float64)
+    got = y[:, COL0::COLSTEP].float().cpu().numpy().astype(np.float64)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    rel = np.abs(got - ref).mean() / np.abs(ref).mean()
+    assert rel < BOUNDS_R4[name], (name, rel, BOUNDS_R4[name])
