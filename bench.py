@@ -311,7 +311,13 @@ class Runner:
         from gemlite_amd.dtypes import TORCH_TO_DTYPE
         a.input_dtype = lin.input_dtype.value if self.dt in MX else TORCH_TO_DTYPE[x.dtype].value
         a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = x.stride(0), x.stride(1), a.N, 1
-        if self.e2e and x.shape[0] > 1:  # quantiser + matmul: name the matmul the quantised x reaches
+        if self.e2e and x.shape[0] > 1:
+            import gemlite_amd.core as core
+            # one launch where the library quantises the rows inside the matmul launch (csrc/gl_coopquant.h) ...
+            if core.FUSE_ACT_QUANT_ROWS and core.TUNING_OVERRIDE is None and not core.lookup_tuning(-1, a.M, a) and \
+                    self.lib.gemlite_hip_query(ctypes.byref(a)) == 0:
+                return self.lib.gemlite_hip_kernel_name(ctypes.byref(a)).decode()
+            # ... else quantiser + matmul: name the matmul the quantised x reaches
             a.input_dtype = lin.input_dtype.value
             a.scales_x = 0x1000
         elif self.dt in PREQUANT and not self.e2e:

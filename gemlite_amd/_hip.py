@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgemlite_hip.so")
 ABI_VERSION = 1
 
 # status codes (gemlite_status_t)
-OK, ERR_BAD_ARGUMENT, ERR_UNSUPPORTED, ERR_BAD_SHAPE, ERR_WORKSPACE, ERR_LAUNCH, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_BAD_ARGUMENT, ERR_UNSUPPORTED, ERR_BAD_SHAPE, ERR_WORKSPACE, ERR_LAUNCH, ERR_NO_DEVICE, ERR_NO_FUSED_QUANT = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class ForwardArgs(C.Structure):

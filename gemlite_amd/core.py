@@ -172,6 +172,12 @@ def get_matmul_type(batch_size: int, W_nbits: int, mx_dtype: bool = False) -> st
 _META_FIELDS = ("scaled_activations", "W_nbits", "group_size", "unpack_mask", "elements_per_sample", "input_dtype",
                 "output_dtype", "acc_dtype", "meta_dtype", "channel_scale_mode", "W_group_mode", "data_contiguous")
 FUSE_ACT_QUANT_M1 = True  # decode of dynamically quantised layers: activation quantisation fused into the matmul kernel
+# 2 <= M <= 64: ONE launch whose first blocks quantise the rows of x while the others stream their weights (csrc/gl_coopquant.h).
+# Built, bit-identical to quantiser + matmul, and OFF: an in-launch hand-off on this part is a chain of ~5 dependent device-scope
+# memory round trips (row load, write-through drain, flag, poll, first read of the quantised rows: 1-2 us each), a launch boundary
+# plus the 2.3-us quantiser is ~4 us — layer(x) measured 3.3-7 us SLOWER fused (profiles/r04/probe_fused_quant_v*.log).
+FUSE_ACT_QUANT_ROWS = False
+_NO_FUSED_QUANT = set()  # (N, K, weight code, x dtype, M, device) the library answered GEMLITE_ERR_NO_FUSED_QUANT for
 TUNING_OVERRIDE = None  # development hook: 4 ints forwarded as gemlite_hip_forward_args.tuning (0 = library default)
 
 # Per-layer launch templates.  A template is the IMMUTABLE byte image of a gemlite_hip_forward_args whose static
@@ -269,7 +275,7 @@ def lookup_tuning(matmul_type: int, M: int, a) -> Optional[tuple]:
 
 
 def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x: Optional[Tensor], meta_args,
-                matmul_type: int, tuning=None) -> Tensor:
+                matmul_type: int, tuning=None, fused_quant_optional: bool = False) -> Optional[Tensor]:
     """out[M, N] = epilogue(x[M, K] @ dequant(W_q)) — the seam the reference fills with
     GEMLITE_TRITON_MAPPING[...].forward (core.py:184-190).  ONE C call per launch: the library plans, carves the
     caller's per-stream workspace and launches; only if that workspace turns out too small is it regrown."""
@@ -317,6 +323,8 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
             ws = _hip.workspace(x.device, stream, need)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             rc = lib.gemlite_hip_forward(_hip.C.byref(a), stream)
+    if rc == _hip.ERR_NO_FUSED_QUANT and fused_quant_optional:
+        return None  # no kernel quantises these rows in-launch: the caller quantises x and calls again (two launches)
     if rc != 0:
         _hip.raise_for_status(rc, "gemlite_hip_forward")
     # a shape that only the coverage kernel takes is correct but orders of magnitude slower: say so, once per shape
@@ -368,6 +376,21 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
                  x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0 and K_ % 16 == 0 and K_ <= 65536 and
                  W_q.stride(0) == 1 and W_q.stride(1) % 16 == 0 and W_q.data_ptr() % 16 == 0 and
                  (x.is_contiguous() and x.data_ptr() % 16 == 0))
+        if not fused and FUSE_ACT_QUANT_ROWS and x.numel() > K_ and meta_args[4] == 1 and meta_args[10] == 0 and \
+                x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0 and TUNING_OVERRIDE is None and x.is_contiguous():
+            # 2 <= M: ONE launch where the library has a kernel whose blocks quantise the rows among themselves (same arithmetic,
+            # bit-identical to the two-launch path); where it has none it says so once per (shape, M) and the answer is remembered
+            x2f = x if x.dim() == 2 else x.view(-1, K_)
+            fkey = (W_q.shape[1], K_, in_code, x.dtype, x2f.shape[0], x.device.index)
+            if fkey not in _NO_FUSED_QUANT:
+                out = _hip_matmul(x2f, W_q, scales, zeros, None, meta_args, matmul_type, fused_quant_optional=True)
+                if out is not None:
+                    if len(out_shape) != 2:
+                        out = out.view(out_shape)
+                    if bias is not None:
+                        out += bias
+                    return out
+                _NO_FUSED_QUANT.add(fkey)
         if not fused:
             x, scales_x = scale_activations_per_token(x, w_dtype=DTYPE_TO_TORCH[in_code])
     x2 = x if x.dim() == 2 else x.view(-1, x.shape[-1])

@@ -12,6 +12,7 @@
 #include <atomic>
 
 #include "gl_common.h"
+#include "gl_coopquant.h"
 
 namespace gl {
 // planners (defined next to their kernels)
@@ -22,7 +23,7 @@ bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
-bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp);
+bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq = false);
 bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
@@ -59,7 +60,7 @@ static int dtype_size(int dt) {
     }
 }
 
-enum Kind { K_NONE = 0, K_GEMV_WN, K_STREAM_WN, K_TILED_WN, K_KMAJOR, K_A8_MMA, K_GENERIC };
+enum Kind { K_NONE = 0, K_GEMV_WN, K_STREAM_WN, K_TILED_WN, K_KMAJOR, K_A8_MMA, K_A8_FQ, K_GENERIC };
 
 struct Resolved {
     Kind kind = K_NONE;
@@ -83,10 +84,11 @@ static Epilogue make_epilogue(const gemlite_hip_forward_args& a) {
     return e;
 }
 
-// Dynamic activation quantisation fused into the matmul (M = 1): the caller passes the UNQUANTISED 16-bit x, no scales_x,
-// and the 8-bit unpacked weights of a dynamically quantised layer (channel_scale_mode 2 / 3).
+// Dynamic activation quantisation fused into the matmul: the caller passes the UNQUANTISED 16-bit x, no scales_x, and the 8-bit
+// unpacked weights of a dynamically quantised layer (channel_scale_mode 2 / 3).  M = 1: every block quantises the row itself
+// (kmajor_fused_quant_kernel); 2 <= M: the blocks of the A8W8 kernels deal the rows among themselves (gl_coopquant.h).
 static bool wants_fused_quant(const gemlite_hip_forward_args* a) {
-    return a->M == 1 && a->elements_per_sample == 1 && !a->scales_x &&
+    return a->M >= 1 && a->elements_per_sample == 1 && !a->scales_x &&
            (a->channel_scale_mode == 2 || a->channel_scale_mode == 3) && a->W_group_mode == 0 &&
            (a->input_dtype == GEMLITE_DT_FP16 || a->input_dtype == GEMLITE_DT_BF16) &&
            (a->w_dtype == GEMLITE_DT_INT8 || a->w_dtype == GEMLITE_DT_FP8E4 || a->w_dtype == GEMLITE_DT_FP8E5);
@@ -319,6 +321,33 @@ coverage:
     g.stride_meta_g = per_group_meta ? a.stride_meta_g : 0;
     g.stride_meta_n = per_group_meta ? a.stride_meta_n : ((a.W_group_mode == 1 && !a.zero_is_scalar) ? 1 : 0);
     r.gp = g;
+    // 2 <= M <= 64 of a dynamically quantised layer: the rows kernel with producer blocks in front that quantise x (gl_coopquant.h).
+    // Planned on the arguments the matmul will see — 8-bit x [M, K] (row stride K) and fp32 scales in the workspace; the pointers
+    // are filled in at launch.  GEMLITE_ERR_NO_FUSED_QUANT: ask again with quantised x and scales_x (two launches).
+    if (wants_fused_quant(&a) && a.M >= 2) {
+        r.status = GEMLITE_ERR_NO_FUSED_QUANT;
+        if (a.tuning[0] != 0 || a.tuning[1] != 0 || a.tuning[2] != 0 || a.matmul_type != GEMLITE_MATMUL_AUTO) return;
+        if (a.M > cq::MAX_ROWS || a.stride_xk != 1 || a.K % 16 != 0 || a.stride_xm % 8 != 0 || ((uintptr_t)a.x % 16) != 0) return;
+        gemlite_hip_forward_args b = a;
+        b.input_dtype = a.w_dtype;
+        b.x = (const void*)(uintptr_t)0x1000;  // (alignment checks only: the workspace copies are 256-byte aligned)
+        b.scales_x = (const void*)(uintptr_t)0x1000;
+        b.stride_xm = a.K;
+        b.stride_sx_m = 1;
+        LaunchPlan lp{};
+        GenericParams gq = g;
+        if (a.M > 64 || !plan_a8w8_rows(b, lp, true)) return;
+        gq.x = nullptr; gq.x_dt = a.w_dtype; gq.stride_xm = a.K; gq.stride_xk = 1;
+        gq.int_acc = a.w_dtype == GEMLITE_DT_INT8 ? 1 : 0;
+        gq.epi.scales_x = nullptr; gq.epi.stride_sx_m = 1;
+        gq.cq_x = a.x; gq.cq_stride_xm = a.stride_xm; gq.cq_xdt = a.input_dtype;
+        gq.flags = a.tuning[3];
+        r.status = GEMLITE_OK;
+        r.kind = K_A8_FQ;
+        r.gp = gq;
+        r.lp = lp;
+        return;
+    }
     // M = 1 of a dynamically quantised layer with the activation quantisation fused into the prologue
     if (wants_fused_quant(&a)) {
         if (a.stride_wk != 1 || a.stride_xk != 1 || a.K % 16 != 0 || a.stride_wn % 16 != 0 || a.K > 65536 ||
@@ -476,6 +505,7 @@ const char* gemlite_hip_status_string(int status) {
         case GEMLITE_ERR_WORKSPACE: return "workspace missing or too small";
         case GEMLITE_ERR_LAUNCH: return "HIP launch failed (see gemlite_hip_last_hip_error)";
         case GEMLITE_ERR_NO_DEVICE: return "current device is not gfx950";
+        case GEMLITE_ERR_NO_FUSED_QUANT: return "no kernel with in-launch activation quantisation for this shape: quantise x first and pass scales_x";
         default: return "unknown status";
     }
 }
@@ -554,6 +584,17 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
             r.gp.counters = (unsigned*)args->workspace;
             r.gp.slabs = (float*)((char*)args->workspace + COUNTER_BYTES);
         }
+        const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes, dev);
+        if (e != GEMLITE_OK) return e;
+        void* kargs[] = {(void*)&r.gp};
+        return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
+    }
+    if (r.kind == K_A8_FQ) {  // cooperative activation quantisation: the workspace holds the flags, the quantised rows and their scales
+        if (!args->workspace || args->workspace_bytes < r.lp.ws_bytes) return GEMLITE_ERR_WORKSPACE;
+        char* payload = (char*)args->workspace + COUNTER_BYTES;
+        r.gp.counters = (unsigned*)args->workspace;
+        r.gp.x = payload;
+        r.gp.epi.scales_x = (const float*)(payload + cq::xq_bytes(args->M, args->K));
         const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes, dev);
         if (e != GEMLITE_OK) return e;
         void* kargs[] = {(void*)&r.gp};

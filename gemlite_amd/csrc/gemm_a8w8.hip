@@ -15,6 +15,7 @@
 // that gives every CU a block (4096 x 4096, M = 256: 64x64 -> 256 blocks).
 #include "gl_common.h"
 #include "gl_async.h"
+#include "gl_coopquant.h"
 
 #include <type_traits>
 
@@ -938,14 +939,26 @@ bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
 // ---------------------------------------------------------------------------------------------------------------------
 // MT = row tiles of 16 (round 3: 17..64 rows used to fall to the 32-row tile of the 8-wave kernel — 17.4 us at 4096^2 int8, M = 32,
 // against 6.7 us for 16 rows here): the weight fragment of a chunk is loaded once and multiplied with MT x fragments.
-template <int DT, int MT>
+// FQ (round 4): the launch quantises the activations itself (gl_coopquant.h) — p.x / p.epi.scales_x are workspace copies that the
+// blocks fill cooperatively; this block's first weight fragments are requested before that and arrive while it waits for the flags.
+template <int DT, int MT, bool FQ>
 __global__ __launch_bounds__(512) void a8w8_rows_kernel(const GenericParams p) {
     typedef typename std::conditional<DT == GEMLITE_DT_INT8, i32x4, f32x4>::type acc_t;
     __shared__ __attribute__((aligned(16))) uint32_t red[MT][8][64][4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, kg = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    int tile = blockIdx.x;
+    if constexpr (FQ) {  // the first gridDim.x - N / 16 blocks quantise rows and leave
+        const int nprod = (int)gridDim.x - p.N / 16;
+        if (tile < nprod) {
+            cq::produce<DT>(p, nprod, (float*)&red[0][0][0][0]);
+            cq::depart(p);
+            return;
+        }
+        tile -= nprod;
+    }
+    const int64_t n0 = (int64_t)tile * 16;
     const int nchunks = (int)(p.K / 64);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + p.K), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((int64_t)(p.M - 1) * p.stride_xm + p.K), 0x00020000);
@@ -960,11 +973,18 @@ __global__ __launch_bounds__(512) void a8w8_rows_kernel(const GenericParams p) {
     constexpr int D = MT == 1 ? 8 : (MT == 2 ? 6 : 4);  // chunks in flight per wave ((1 + MT) x 16 bytes per lane each)
     u32x4 wb[D], xb[D][MT];
     const int mine = (nchunks - wave + 7) >> 3;  // chunks wave, wave + 8, ...
-    auto load = [&](int slot, int i) __attribute__((always_inline)) {
+    auto load_w = [&](int slot, int i) __attribute__((always_inline)) {
         const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((wave + 8 * i) * 64);
         wb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, so, 0);
+    };
+    auto load_x = [&](int slot, int i) __attribute__((always_inline)) {
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((wave + 8 * i) * 64);
 #pragma unroll
         for (int t = 0; t < MT; ++t) xb[slot][t] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], so, 0);
+    };
+    auto load = [&](int slot, int i) __attribute__((always_inline)) {
+        load_w(slot, i);
+        load_x(slot, i);
     };
     auto mma = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -985,9 +1005,22 @@ __global__ __launch_bounds__(512) void a8w8_rows_kernel(const GenericParams p) {
             }
         }
     };
+    if constexpr (FQ) {
 #pragma unroll
-    for (int j = 0; j < D; ++j)
-        if (j < mine) load(j, j);
+        for (int j = 0; j < D; ++j)
+            if (j < mine) load_w(j, j);
+        cq::wait_rows<DT>(p, (float*)&red[0][0][0][0]);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < mine) load_x(j, j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < mine) load(j, j);
+    }
+    // (the ring's requests sit behind `if (base + j + D < mine)`: hipcc retires each group of D chunks with one full vmcnt(0) at the
+    //  loop header — the group's D x (1 + MT) KB per wave are requested together and 8 waves per CU interleave, which keeps >= 100 KB
+    //  per CU in flight; an unconditional steady-state loop compiles to the same bulk-synchronous shape, tried in round 4)
     for (int base = 0; base < mine; base += D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -1018,12 +1051,13 @@ __global__ __launch_bounds__(512) void a8w8_rows_kernel(const GenericParams p) {
         }
         if (m < p.M) epilogue_store(p.epi, v, m, n0 + (l & 15));
     }
+    if constexpr (FQ) cq::depart(p);
 }
 
 // 2 <= M <= 64 (M = 1 too when forced with tuning[0] = 4), same-dtype 8-bit operands, both K-contiguous.  17..64 rows: 2 / 4 row
 // tiles per block while every block's re-read of x from L2 (M K bytes) stays below the 8-wave kernel's fixed cost — measured
 // crossover in profiles/r03/probe_a8w8_rows_mt.log
-bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
+bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq) {
     if (a.elements_per_sample != 1 || a.W_group_mode != 0 || a.M > 64 || a.M < 1) return false;
     if (a.w_dtype != a.input_dtype) return false;
     if (!(a.input_dtype == GEMLITE_DT_INT8 || a.input_dtype == GEMLITE_DT_FP8E4 || a.input_dtype == GEMLITE_DT_FP8E5)) return false;
@@ -1037,19 +1071,21 @@ bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
     if (mt > 1 && a.tuning[0] != 4 && (int64_t)a.M * a.K * (a.N / 16) > (88ll << 20)) return false;
     auto pick = [&](auto dt) -> const void* {
         constexpr int DT = decltype(dt)::value;
-        return mt == 1 ? (const void*)a8w8_rows_kernel<DT, 1> : (mt == 2 ? (const void*)a8w8_rows_kernel<DT, 2> : (const void*)a8w8_rows_kernel<DT, 4>);
+        if (fq) return mt == 1 ? (const void*)a8w8_rows_kernel<DT, 1, true> : (mt == 2 ? (const void*)a8w8_rows_kernel<DT, 2, true> : (const void*)a8w8_rows_kernel<DT, 4, true>);
+        return mt == 1 ? (const void*)a8w8_rows_kernel<DT, 1, false> : (mt == 2 ? (const void*)a8w8_rows_kernel<DT, 2, false> : (const void*)a8w8_rows_kernel<DT, 4, false>);
     };
     switch (a.input_dtype) {
         case GEMLITE_DT_INT8: lp.fn = pick(std::integral_constant<int, GEMLITE_DT_INT8>{}); break;
         case GEMLITE_DT_FP8E4: lp.fn = pick(std::integral_constant<int, GEMLITE_DT_FP8E4>{}); break;
         default: lp.fn = pick(std::integral_constant<int, GEMLITE_DT_FP8E5>{}); break;
     }
-    lp.name = mt == 1 ? "a8w8_rows_kernel<16x16>" : (mt == 2 ? "a8w8_rows_kernel<32x16>" : "a8w8_rows_kernel<64x16>");
-    lp.grid = dim3((unsigned)(a.N / 16), 1, 1);
+    lp.name = fq ? (mt == 1 ? "a8w8_rows_fq_kernel<16x16>" : (mt == 2 ? "a8w8_rows_fq_kernel<32x16>" : "a8w8_rows_fq_kernel<64x16>"))
+                 : (mt == 1 ? "a8w8_rows_kernel<16x16>" : (mt == 2 ? "a8w8_rows_kernel<32x16>" : "a8w8_rows_kernel<64x16>"));
+    lp.grid = dim3((unsigned)(a.N / 16 + (fq ? (a.M < 64 ? a.M : 64) : 0)), 1, 1);  // fq: one producer block per row in front
     lp.block = dim3(512, 1, 1);
     lp.lds_bytes = 0;
-    lp.ws_bytes = 0;
-    lp.slab_bytes = 0;
+    lp.slab_bytes = fq ? cq::payload_bytes(a.M, a.K) : 0;  // the quantised rows and their scales
+    lp.ws_bytes = fq ? COUNTER_BYTES + lp.slab_bytes : 0;
     return true;
 }
 

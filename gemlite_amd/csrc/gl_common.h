@@ -426,6 +426,12 @@ struct GenericParams {
     int64_t stride_sx_blk_m;
     int mx_x, mx_w, mx_scale_e4m3;
     float mx_post;
+    // cooperative activation quantisation inside the launch (gl_coopquant.h): the caller's 16-bit activations, their row stride
+    // (elements) and type.  `x` / `epi.scales_x` then point at the workspace copies (row stride K) that the blocks fill first;
+    // `counters` [0, M) are the row flags, [M] the departure count.
+    const void* cq_x;
+    int64_t cq_stride_xm;
+    int cq_xdt;
 };
 enum { MX_F16 = 1, MX_BF16 = 2, MX_FP8 = 3, MX_FP4 = 4 };
 

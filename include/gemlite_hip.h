@@ -88,7 +88,10 @@ typedef enum gemlite_status_t {
     GEMLITE_ERR_BAD_SHAPE = -3,    /* K not a multiple of elements_per_sample / group    */
     GEMLITE_ERR_WORKSPACE = -4,    /* workspace missing or smaller than required         */
     GEMLITE_ERR_LAUNCH = -5,       /* hipLaunchKernel failed; see gemlite_hip_last_hip_error */
-    GEMLITE_ERR_NO_DEVICE = -6     /* current device is not gfx950                       */
+    GEMLITE_ERR_NO_DEVICE = -6,    /* current device is not gfx950                       */
+    GEMLITE_ERR_NO_FUSED_QUANT = -7 /* scales_x == NULL with 16-bit x asked for the in-launch activation quantisation, which this
+                                    * shape / M has no kernel for: quantise x (gemlite_hip_scale_activations_per_token) and call
+                                    * again with scales_x.  Not an error of the layer. */
 } gemlite_status_t;
 
 /* W_group_mode / channel_scale_mode follow gemlite/triton_kernels/utils.py:73-87 and
@@ -118,9 +121,12 @@ typedef struct gemlite_hip_forward_args {
     const void* scales;   /* [K/group, N] meta_dtype, or [N] channel scales, or NULL       */
     const void* zeros;    /* [K/group, N] meta_dtype, 1-elem int32 (scalar), or NULL       */
     const void* scales_x; /* [M] fp32 per-token activation scales, or NULL.  NULL together with
-                           * channel_scale_mode 2/3, M == 1, 16-bit float x and unpacked int8 / fp8 weights asks for
-                           * the FUSED dynamic quantisation: x is quantised per token inside the matmul kernel
-                           * (same arithmetic as gemlite_hip_scale_activations_per_token, one launch instead of two) */
+                           * channel_scale_mode 2/3, 16-bit float x and unpacked int8 / fp8 weights asks for
+                           * the FUSED dynamic quantisation: x is quantised per token inside the matmul launch
+                           * (same arithmetic as gemlite_hip_scale_activations_per_token, one launch instead of two).
+                           * M == 1: always available.  M >= 2: the blocks of the launch deal the rows among themselves
+                           * (needs the workspace: flags + M*K bytes + M floats); GEMLITE_ERR_NO_FUSED_QUANT where no such
+                           * kernel applies (gemlite_hip_query() answers without launching). */
     void* out;            /* [M, N] output_dtype                                           */
     void* workspace;      /* >= gemlite_hip_workspace_bytes(); zero-filled ONCE by the owner */
     uint64_t workspace_bytes;

@@ -964,6 +964,118 @@ def test_fused_activation_quant_at_m1_is_bit_identical_to_the_two_launch_path(ki
     _compare(f"fused-quant/{kind}", lin(x), y_or, 1, abs_gate=5e-3)
 
 
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+def test_cooperative_activation_quant_from_two_rows_is_bit_identical_to_the_two_launch_path(kind, tdt):
+    """SURVEY.md §8 f1 / VERDICT r3 #5: for 2 .. 64 rows the A8W8 launch carries producer blocks that quantise the rows of x into the
+    workspace (csrc/gl_coopquant.h) while the tile blocks stream their weights and wait for the row flags — `layer(x)` is ONE launch.
+    Same arithmetic as scale_activations_per_token (quant_utils.py:231-253) + the same matmul kernel body: bit-identical outputs,
+    every M class (16 / 32 / 64-row fragments), launch after launch with different activations in the same workspace (a stale cache
+    line of the previous launch would show), flags left zero; above 64 rows the library says GEMLITE_ERR_NO_FUSED_QUANT and the host
+    path runs quantiser + matmul."""
+    from gemlite_amd import core
+    from gemlite_amd.core import _hip_matmul
+    torch.manual_seed(23)
+    core.FUSE_ACT_QUANT_ROWS = True  # (opt-in: measured slower than two launches, see core.py)
+    core._NO_FUSED_QUANT.clear()
+    try:
+        _cooperative_quant_cases(kind, tdt, core, _hip_matmul)
+    finally:
+        core.FUSE_ACT_QUANT_ROWS = False
+    ws = _hip.workspace(torch.device(DEV), _hip.current_stream_handle(torch.device(DEV)), 0)
+    torch.cuda.synchronize()
+    assert int(ws[:4 * 1100].view(torch.int32).abs().sum()) == 0  # row flags and departure count are zero again
+
+
+def _cooperative_quant_cases(kind, tdt, core, _hip_matmul):
+    for N, K in ((1024, 2048), (4096, 4096)):
+        W = (torch.randn(N, K) / 30).to(tdt)
+        proc = (gemlite_amd.helper.A8W8_int8_dynamic if kind == "int8" else gemlite_amd.helper.A8W8_fp8_dynamic)(device=DEV, dtype=tdt)
+        lin = proc.from_weights(W)
+        qdt = torch.int8 if kind == "int8" else torch.float8_e4m3fn
+        for M in (2, 5, 16, 17, 33, 64, 65, 256):
+            want = "a8w8_rows_fq_kernel" if M <= 64 else "unsupported"
+            for rep in range(3):
+                x = (torch.randn(M, K, device=DEV) * (0.05 + 0.2 * rep)).to(tdt)
+                x[min(rep, M - 1), 7] = 3.0 + rep  # an outlier row: its scale differs a lot from its neighbours'
+                a = core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
+                a.matmul_type, a.M, a.x, a.out = -1, M, x.data_ptr(), 0x1000
+                a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = K, 1, N, 1
+                a.input_dtype = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+                name = _hip.load().gemlite_hip_kernel_name(_hip.C.byref(a)).decode()
+                assert name.startswith(want), (M, name)
+                y_fused = lin(x)
+                xq, sx = scale_activations_per_token(x, w_dtype=qdt)
+                y_two = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1)
+                torch.cuda.synchronize()
+                assert torch.equal(y_fused, y_two), (kind, tdt, N, K, M, rep, float((y_fused.float() - y_two.float()).abs().max()))
+            # 3-d input, and the switch
+            x3 = (torch.randn(1, M, K, device=DEV) / 10).to(tdt)
+            y3 = lin(x3)
+            core.FUSE_ACT_QUANT_ROWS = False
+            try:
+                y3_two = lin(x3)
+            finally:
+                core.FUSE_ACT_QUANT_ROWS = True
+            assert y3.shape == (1, M, N) and torch.equal(y3, y3_two)
+
+
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+def test_cooperative_activation_quant_when_no_block_produces_its_rows(kind):
+    """The wait is bounded: a block that has polled long enough quantises the first missing row itself (identical bytes).  With the
+    test bit tuning[3] & 32768 NO block quantises its own share, so every row arrives that way — the launch must still finish with the
+    two-launch result.  (What happens when the owner of a row is not resident: CU masks, a co-running kernel, a grid above the chip.)"""
+    from gemlite_amd.core import _hip_matmul
+    torch.manual_seed(29)
+    N, K = 1024, 2048
+    W = (torch.randn(N, K) / 30).half()
+    lin = (gemlite_amd.helper.A8W8_int8_dynamic if kind == "int8" else gemlite_amd.helper.A8W8_fp8_dynamic)(device=DEV, dtype=torch.float16).from_weights(W)
+    qdt = torch.int8 if kind == "int8" else torch.float8_e4m3fn
+    for M in (3, 40, 64):
+        x = (torch.randn(M, K, device=DEV) / 8).half()
+        y_steal = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, (0, 0, 0, 32768))
+        xq, sx = scale_activations_per_token(x, w_dtype=qdt)
+        y_two = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1)
+        torch.cuda.synchronize()
+        assert torch.equal(y_steal, y_two), (kind, M)
+        y_again = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1)  # flags were left zero: the next in-launch quantisation is right as well
+        torch.cuda.synchronize()
+        assert torch.equal(y_again, y_two), (kind, M)
+
+
+@pytest.mark.parametrize("M", [16, 48])
+def test_cooperative_activation_quant_under_graph_replay(M):
+    """One captured `layer(x)` launch replayed with x rewritten in place between replays: every replay starts from zeroed flags
+    (the in-kernel reset) and reads the rows of ITS launch."""
+    torch.manual_seed(31)
+    N = K = 4096
+    W = (torch.randn(N, K) / 30).half()
+    lin = gemlite_amd.helper.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights(W)
+    x = (torch.randn(M, K, device=DEV) / 10).half()
+    gemlite_amd.core.FUSE_ACT_QUANT_ROWS = True
+    gemlite_amd.core._NO_FUSED_QUANT.clear()
+    lin(x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        lin(x)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            y = lin(x)
+    torch.cuda.current_stream().wait_stream(s)
+    gemlite_amd.core.FUSE_ACT_QUANT_ROWS = False
+    try:
+        for rep in range(12):
+            x.copy_((torch.randn(M, K, device=DEV) * (0.03 * (rep + 1))).half())
+            g.replay()
+            torch.cuda.synchronize()
+            y_two = lin(x)
+            torch.cuda.synchronize()
+            assert torch.equal(y, y_two), (M, rep)
+    finally:
+        gemlite_amd.core.FUSE_ACT_QUANT_ROWS = False
+
+
 def test_shipped_tuning_table_autoloads_by_device_and_its_entries_stay_correct():
     """gemlite_amd/configs/mi355x.json is found from the device (name or ISA), loaded once on the first launch like the
     reference's configs/<gpu>.json (core.py:634-654), and launches that hit an entry still match the oracle."""

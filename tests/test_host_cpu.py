@@ -700,6 +700,35 @@ def test_isa_loop_guards_on_the_built_library(script):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def test_in_launch_activation_quantisation_is_planned_from_two_rows_and_says_when_it_is_not():
+    """include/gemlite_hip.h: scales_x == NULL with 16-bit x and unpacked 8-bit weights (channel_scale_mode 2 / 3) asks for the
+    quantisation inside the matmul launch.  M = 1: the fused GEMV; 2 <= M: a launch whose first blocks quantise the rows
+    for it (2 <= M <= 64: producer blocks in front of the rows kernel; workspace = flags + M K bytes + M floats); where neither applies the answer is GEMLITE_ERR_NO_FUSED_QUANT (-7),
+    which core._forward_impl turns into quantiser + matmul — never an exception."""
+    lib = _hip.load()
+
+    def ask(M, N=4096, K=4096, w=4, **kw):
+        a = _args(M=M, N=N, K=K, nbits=8, gs=K, in_dt=1, w_mode=0, c_mode=3, e=1, w_dtype=w, meta_dt=0, **kw)
+        a.scales_x = None
+        return lib.gemlite_hip_query(C.byref(a)), lib.gemlite_hip_kernel_name(C.byref(a)).decode(), int(lib.gemlite_hip_workspace_bytes(C.byref(a)))
+
+    assert ask(1)[:2] == (0, "kmajor_fused_quant_kernel")
+    for w in (4, 3):  # int8, fp8 e4m3
+        assert ask(2, w=w)[:2] == (0, "a8w8_rows_fq_kernel<16x16>")
+        assert ask(17, w=w)[:2] == (0, "a8w8_rows_fq_kernel<32x16>")
+        assert ask(64, w=w)[:2] == (0, "a8w8_rows_fq_kernel<64x16>")
+        assert ask(65, w=w)[0] == _hip.ERR_NO_FUSED_QUANT   # the tile kernels: every block would be a producer, the chain in front of
+        assert ask(256, w=w)[0] == _hip.ERR_NO_FUSED_QUANT  # its own pipeline — measured slower than two launches (profiles/r04)
+    rc, _, ws = ask(64)
+    assert ws == 65536 * 4 + 64 * 4096 + 256  # ticket words | quantised rows | scales (padded to 256)
+    assert ask(32, N=16384, K=16384)[0] == _hip.ERR_NO_FUSED_QUANT       # past the rows kernel's x re-read budget: the 8-wave kernel
+    assert ask(16, tuning=(0, 2, 0, 0))[0] == _hip.ERR_NO_FUSED_QUANT    # a forced plan keeps the two-launch form
+    a = _args(M=16, nbits=4, gs=128, in_dt=1, w_mode=3, c_mode=2)        # packed weights (A8Wn): scales_x stays mandatory
+    a.scales_x = None
+    assert lib.gemlite_hip_query(C.byref(a)) == _hip.ERR_BAD_ARGUMENT
+    assert b"scales_x" in lib.gemlite_hip_status_string(_hip.ERR_NO_FUSED_QUANT)
+
+
 def test_tuning_table_mutations_bump_the_epoch_of_the_cpp_fast_path():
     """core.GEMLITE_HIP_CONFIG_CACHE counts its mutations (also those of the family dicts inside it): the C++ eager path caches tuning[]
     per (layer, M) for one epoch only."""
