@@ -28,11 +28,12 @@ bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, Laun
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
-bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, bool nv = false);
 bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 const void* mx_generic_kernel_fn();
 const void* act_quant_mx_kernel_fn(int mode);
+const void* nvfp4_expand_f16_kernel_fn();
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
 const void* kmajor_w8a16_kernel_fn(int mb);
@@ -60,7 +61,7 @@ static int dtype_size(int dt) {
     }
 }
 
-enum Kind { K_NONE = 0, K_GEMV_WN, K_STREAM_WN, K_TILED_WN, K_KMAJOR, K_A8_MMA, K_A8_FQ, K_GENERIC };
+enum Kind { K_NONE = 0, K_GEMV_WN, K_STREAM_WN, K_TILED_WN, K_KMAJOR, K_A8_MMA, K_A8_FQ, K_NV_MMA, K_GENERIC };
 
 struct Resolved {
     Kind kind = K_NONE;
@@ -68,6 +69,7 @@ struct Resolved {
     WnParams wn{};
     GenericParams gp{};
     int status = GEMLITE_OK;
+    uint64_t nv_x16_bytes = 0;  // K_NV_MMA: bytes of the fp16 expansion of x in the workspace (behind the split-K slabs)
 };
 
 static Epilogue make_epilogue(const gemlite_hip_forward_args& a) {
@@ -186,6 +188,34 @@ static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
         p.stride_xm = a.stride_xm; p.stride_xk = a.stride_xk; p.stride_wk = 1;
         p.flags = a.tuning[3];
         if (plan_gemm_wn_mma_mx(a, p, r.lp)) { r.kind = K_TILED_WN; r.wn = p; return; }
+    }
+    // NVFP4 (round 4): both operands are exact in fp16 — x is expanded into the workspace by a small kernel in front, the weights in
+    // the K loop of the fp16 MFMA tile kernel (Geo<NVW4>), the layer's constant output factor rides as a per-row scale.  Two launches
+    // inside this call.  tuning[0] = 1 keeps the coverage kernel.
+    if (a.input_dtype == GEMLITE_DT_NVFP4 && a.channel_scale_mode == 4 && (a.tuning[0] == 0 || a.tuning[0] == 2) &&
+        ((uintptr_t)a.x % 8) == 0 && a.stride_xm % 8 == 0 && a.K % 128 == 0 && (int64_t)a.M * a.K < (1ll << 30)) {
+        gemlite_hip_forward_args b = a;
+        b.input_dtype = GEMLITE_DT_MXFP16;
+        b.x = (const void*)(uintptr_t)0x1000;  // (alignment checks only: the workspace copy is 256-byte aligned)
+        b.stride_xm = a.K;
+        WnParams p{};
+        p.x = nullptr; p.w = (const uint32_t*)a.w_q; p.scales = a.scales; p.zeros = nullptr;
+        p.epi = g.epi;
+        p.epi.c_mode = 2;  // out = acc * post[m]
+        p.epi.scales_x = nullptr;
+        p.epi.stride_sx_m = 1;
+        p.epi.meta_dt = p.epi.out_dt;
+        p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
+        p.group_size = 16;
+        p.stride_xm = a.K; p.stride_xk = 1; p.stride_wk = 1;
+        p.flags = a.tuning[3];
+        if (plan_gemm_wn_mma_mx(b, p, r.lp, true)) {
+            r.kind = K_NV_MMA;
+            r.wn = p;
+            r.nv_x16_bytes = (uint64_t)(((int64_t)a.M * a.K * 2 + 255) & ~(int64_t)255);
+            r.lp.ws_bytes = COUNTER_BYTES + r.lp.slab_bytes + r.nv_x16_bytes + (uint64_t)((a.M * 4 + 255) & ~(int64_t)255);
+            return;
+        }
     }
     if (a.M > 65535) { r.status = GEMLITE_ERR_BAD_SHAPE; return; }
     r.kind = K_GENERIC;
@@ -587,6 +617,33 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
         const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes, dev);
         if (e != GEMLITE_OK) return e;
         void* kargs[] = {(void*)&r.gp};
+        return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
+    }
+    if (r.kind == K_NV_MMA) {  // NVFP4: [tickets | split-K slabs | fp16 expansion of x | per-row output factor]
+        if (!args->workspace || args->workspace_bytes < r.lp.ws_bytes) return GEMLITE_ERR_WORKSPACE;
+        char* base = (char*)args->workspace;
+        uint16_t* x16 = (uint16_t*)(base + COUNTER_BYTES + r.lp.slab_bytes);
+        float* post = (float*)((char*)x16 + r.nv_x16_bytes);
+        r.wn.counters = (unsigned*)base;
+        r.wn.slabs = (float*)(base + COUNTER_BYTES);
+        r.wn.x = x16;
+        r.wn.epi.scales_x = post;
+        const uint8_t* xq = (const uint8_t*)args->x;
+        const uint8_t* sx = (const uint8_t*)args->scales_x;
+        int M = (int)args->M, K = (int)args->K;
+        int64_t sxm = args->stride_xm, ssm = args->stride_sx_m;
+        float post_v = r.gp.mx_post;
+        void* eargs[] = {(void*)&xq, (void*)&sx, (void*)&x16, (void*)&post, (void*)&M, (void*)&K, (void*)&sxm, (void*)&ssm, (void*)&post_v};
+        const int64_t nblk = ((int64_t)M * (K / 16) + 255) / 256;
+        void* es = tl_evt_start; void* ee = tl_evt_stop;  // (profile events, if any, bracket BOTH launches)
+        tl_evt_stop = nullptr;
+        int rc = launch(nvfp4_expand_f16_kernel_fn(), dim3((unsigned)nblk, 1, 1), dim3(256, 1, 1), eargs, 0, st);
+        if (rc != GEMLITE_OK) return rc;
+        (void)es;
+        tl_evt_start = nullptr; tl_evt_stop = ee;
+        const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes, dev);
+        if (e != GEMLITE_OK) return e;
+        void* kargs[] = {(void*)&r.wn};
         return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
     }
     if (r.kind == K_A8_FQ) {  // cooperative activation quantisation: the workspace holds the flags, the quantised rows and their scales

@@ -192,6 +192,40 @@ __global__ __launch_bounds__(256) void mx_generic_kernel(const GenericParams p) 
 const void* mx_generic_kernel_fn() { return (const void*)mx_generic_kernel; }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// NVFP4 activations -> fp16 (round 4).  gfx950's scaled MFMA takes e8m0 block-32 scales only; an e2m1 code times its e4m3 block-16
+// scale has at most 5 significant bits and lies in [2^-10, 2688], i.e. it is EXACT in fp16 — so the NVFP4 x NVFP4 contraction
+// (gemm_MX_kernel with the e4m3 scales, gemlite/triton_kernels/gemm_kernels.py:422-547: dequantise both operands block-wise, multiply,
+// fp32 accumulate) runs on the fp16 MFMA tile kernel (gemm_wn_mma_kernel.inc, Geo<NVW4>) with both operands expanded exactly: the
+// weights in its K loop, x here — M x K x 2 bytes into the workspace (2 MB at M = 256, K = 4096).  Thread = one 16-k block: 8 code
+// bytes + 1 scale byte in, 32 bytes out.  `post[m]` receives the layer's constant output factor (meta_scale_norm^2,
+// gemm_kernels.py:461, 530-531), which the tile kernel applies as a per-row scale in its epilogue.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nvfp4_expand_f16_kernel(const uint8_t* __restrict__ xq, const uint8_t* __restrict__ sx, uint16_t* __restrict__ out,
+                                                              float* __restrict__ post, int M, int K, int64_t stride_xm, int64_t stride_sx_m, float post_v) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const int kb_per_row = K / 16;
+    const int64_t bi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (bi >= (int64_t)M * kb_per_row) return;
+    const int m = (int)(bi / kb_per_row), kb = (int)(bi % kb_per_row);
+    const u32x2 codes = *(const u32x2*)(xq + (int64_t)m * stride_xm + kb * 8);
+    const _Float16 hs = (_Float16)__builtin_amdgcn_cvt_f32_fp8((int)sx[(int64_t)m * stride_sx_m + kb], 0);
+    const h2_t s2 = {hs, hs};
+    uint32_t o[8];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        o[4 * d + 0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[d], 1.0f, 0) * s2);
+        o[4 * d + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[d], 1.0f, 1) * s2);
+        o[4 * d + 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[d], 1.0f, 2) * s2);
+        o[4 * d + 3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[d], 1.0f, 3) * s2);
+    }
+    u32x4* dst = (u32x4*)(out + (int64_t)m * K + kb * 16);
+    dst[0] = (u32x4){o[0], o[1], o[2], o[3]};
+    dst[1] = (u32x4){o[4], o[5], o[6], o[7]};
+    if (kb == 0) post[m] = post_v;
+}
+const void* nvfp4_expand_f16_kernel_fn() { return (const void*)nvfp4_expand_f16_kernel; }
+
+// ---------------------------------------------------------------------------------------------------------------------
 // decode kernel (M <= 4): one wave per output column, lanes along K with 16-byte pieces of the K-contiguous weight row (the
 // streaming form of kmajor_matmul_kernel).  A piece is 32 fp4 / 16 fp8 weights of ONE microscaling block: the hardware
 // converters (v_cvt_scalef32_pk_*) turn it into scaled 16-bit pairs (exact: e2m1 / e4m3 times 2^e fits bf16), the same

@@ -11,16 +11,24 @@ const void* mma_lookup_bf16(int kind, int nbits, int mi, int xdt, int xch);
 // K-contiguous weight geometry (Geo<MXW8 / MXW4>) — the weights are converted by v_cvt_scalef32_pk_* with their block scale, 4
 // VALU per fragment instead of 23.  `p` arrives with x / w / scales / epilogue / M / N / K / strides filled in by the caller.
 // tuning[1] = K slices, tuning[2] = tile rows / 32.
-bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
+// nv (round 4): NVFP4 weights (e4m3 scale per 16 k) under the fp16 EXPANSION of NVFP4 activations — `a` then describes that expansion
+// (input MXFP16, x [M, K] fp16 in the workspace); any of fp16 / bf16 / fp32 leaves through the untyped epilogue store.
+bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, bool nv) {
     const bool f16 = a.input_dtype == GEMLITE_DT_MXFP16;
     if (!f16 && a.input_dtype != GEMLITE_DT_MXBF16) return false;
-    if (a.output_dtype != (f16 ? GEMLITE_DT_FP16 : GEMLITE_DT_BF16)) return false;  // typed epilogue
-    const int nb = a.W_nbits == 8 ? mma::MXW8 : mma::MXW4;
-    if (a.group_size != 32 || a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % mma::BN != 0 || a.K % 128 != 0) return false;
+    if (nv && (!f16 || a.W_nbits != 4)) return false;
+    if (!nv && a.output_dtype != (f16 ? GEMLITE_DT_FP16 : GEMLITE_DT_BF16)) return false;  // typed epilogue
+    const int nb = nv ? mma::NVW4 : (a.W_nbits == 8 ? mma::MXW8 : mma::MXW4);
+    const int sbk = nv ? 16 : 32;  // k per scale byte
+    if (a.group_size != sbk || a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % mma::BN != 0 || a.K % 128 != 0) return false;
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0 || ((uintptr_t)a.w_q % 16) != 0 || a.stride_wn % 16 != 0) return false;
     if (((uintptr_t)a.out % 8) != 0 || (a.stride_om * 2) % 8 != 0) return false;
     if ((int64_t)a.N * a.stride_wn >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31)) return false;
-    if ((int64_t)(a.K / 32) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    if ((int64_t)(a.K / sbk) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    if (nv) {
+        const int oal = a.output_dtype == GEMLITE_DT_FP32 ? 16 : 8;  // 4 outputs per (untyped) store
+        if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
+    }
     auto kstep_of = [](int c) { return c >= 4 ? 128 : 256; };
     const int cap = a.M > 128 ? 8 : (a.M > 64 ? 4 : (a.M > 32 ? 2 : 1));
     // cheap conversion: the tallest tile that still gives >= 128 tiles (else >= 64, else the tallest M fills), then the
@@ -67,7 +75,8 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     static const char* names[2][4] = {
         {"gemm_a16w8_mxfp_kernel<32x128>", "gemm_a16w8_mxfp_kernel<64x128>", "gemm_a16w8_mxfp_kernel<128x128>", "gemm_a16w8_mxfp_kernel<256x128>"},
         {"gemm_a16w4_mxfp_kernel<32x128>", "gemm_a16w4_mxfp_kernel<64x128>", "gemm_a16w4_mxfp_kernel<128x128>", "gemm_a16w4_mxfp_kernel<256x128>"}};
-    lp.name = names[nb == mma::MXW8 ? 0 : 1][mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))];
+    static const char* nv_names[4] = {"gemm_nvfp4_f16_kernel<32x128>", "gemm_nvfp4_f16_kernel<64x128>", "gemm_nvfp4_f16_kernel<128x128>", "gemm_nvfp4_f16_kernel<256x128>"};
+    lp.name = nv ? nv_names[mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))] : names[nb == mma::MXW8 ? 0 : 1][mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))];
     lp.grid = dim3((unsigned)tiles, splitk, 1);
     lp.block = dim3(512, 1, 1);
     const bool w8 = nb == mma::MXW8;

@@ -161,7 +161,16 @@ def test_c_abi_routes_block_scaled_formats():
     a.tuning[0] = 2                                                       # A/B switch: MFMA kernel at decode sizes
     assert name(a) == "gemm_mx_a8w8_kernel<32x128>"
     assert name(args(17, 4, 48, 4, N=16384)) == "gemm_mx_a4w4_kernel<64x128>"
-    assert name(args(18, 4, 8, 4, group=16)) == "mx_generic_kernel"       # NVFP4: no gfx950 instruction
+    # NVFP4: no scaled-MFMA form takes e4m3 block-16 scales; both operands are exact in fp16, so the fp16 tile kernel runs it (round 4:
+    # x expanded by a kernel in front, the weights in the K loop; workspace = tickets + slabs + M K fp16 + M floats)
+    assert name(args(18, 4, 8, 4, group=16)) == "gemm_nvfp4_f16_kernel<32x128>"
+    assert name(args(18, 4, 256, 4, group=16)) == "gemm_nvfp4_f16_kernel<64x128>"
+    a = args(18, 4, 8, 4, group=16)
+    assert lib.gemlite_hip_workspace_bytes(C.byref(a)) >= 65536 * 4 + 8 * 4096 * 2 + 256
+    a.tuning[0] = 1
+    assert name(a) == "mx_generic_kernel"                                 # A/B switch: the coverage kernel of rounds 2-3
+    a = args(18, 4, 8, 4, group=16, N=4096 + 64)
+    assert name(a) == "mx_generic_kernel"                                 # N % 128 != 0
     assert lib.gemlite_hip_query(C.byref(args(18, 4, 8, 4, group=32))) == _hip.ERR_UNSUPPORTED
     assert lib.gemlite_hip_query(C.byref(args(17, 8, 8, 4))) == _hip.ERR_UNSUPPORTED  # fp4 activations x fp8 weights
     a = args(16, 8, 64, 4)

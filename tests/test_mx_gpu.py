@@ -145,7 +145,7 @@ PROCS = {
 EXPECT = {"A16W8_MXFP": "gemm_a16w8_mxfp_kernel", "A16W4_MXFP": "gemm_a16w4_mxfp_kernel",
           "A8W8_MXFP_dynamic": "gemm_mx_a8w8_kernel", "A8W8_MXFP_dynamic_post": "gemm_mx_a8w8_kernel",
           "A8W4_MXFP_dynamic": "gemm_mx_a8w4_kernel", "A8W4_MXFP_dynamic_post": "gemm_mx_a8w4_kernel",
-          "A4W4_MXFP_dynamic": "gemm_mx_a4w4_kernel", "A4W4_NVFP_dynamic": "mx_generic_kernel"}
+          "A4W4_MXFP_dynamic": "gemm_mx_a4w4_kernel", "A4W4_NVFP_dynamic": "gemm_nvfp4_f16_kernel"}
 
 
 @pytest.mark.parametrize("proc", list(PROCS))
@@ -176,7 +176,7 @@ def test_processor_forward_vs_oracle(proc, tdt):
 
 
 @pytest.mark.parametrize("proc", ["A8W8_MXFP_dynamic", "A8W4_MXFP_dynamic", "A4W4_MXFP_dynamic", "A8W8_MXFP_dynamic_post",
-                                  "A16W8_MXFP", "A16W4_MXFP"])
+                                  "A16W8_MXFP", "A16W4_MXFP", "A4W4_NVFP_dynamic"])
 def test_mfma_kernel_tiles_slices_and_coverage_agree(proc):
     """the scaled-MFMA kernel at every tile height x K slices, and the coverage kernel, against the oracle and each other"""
     tdt = torch.bfloat16
@@ -190,8 +190,8 @@ def test_mfma_kernel_tiles_slices_and_coverage_agree(proc):
     outs = {}
     try:
         tunings = [(0, 1, 1, 0), (0, 1, 2, 0), (0, 1, 4, 0), (0, 2, 1, 0), (0, 4, 2, 0), (0, 3, 4, 0), (0, 8, 1, 0), (1, 0, 0, 0)]
-        if proc.startswith("A16"):
-            tunings += [(0, 1, 8, 0), (0, 5, 8, 0)]  # 256-row tiles exist on the 16-bit-activation kernel only
+        if proc.startswith("A16") or "NVFP" in proc:
+            tunings += [(0, 1, 8, 0), (0, 5, 8, 0)]  # 256-row tiles exist on the 16-bit-activation kernel only (NVFP4 runs on it: both operands expanded to fp16)
         for tuning in tunings:
             C.TUNING_OVERRIDE = tuning
             name = _kernel_name(layer, x, tuning)
