@@ -33,6 +33,7 @@ bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPla
 bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 const void* mx_generic_kernel_fn();
 const void* act_quant_mx_kernel_fn(int mode);
+bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp, bool any_m = false);
 const void* nvfp4_expand_f16_kernel_fn();
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
@@ -172,8 +173,13 @@ static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
     g.mx_post = a.input_dtype == GEMLITE_DT_NVFP4 ? 0.0025f : 1.0f;  // meta_scale_norm = 0.05 ** 2 (gemm_kernels.py:461, 530-531)
     g.splitk = 1;
     r.gp = g;
-    // decode sizes: the streaming kernel (tuning[0] = 2 keeps the MFMA kernels for A/B runs)
-    if (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
+    // 1 .. 64 rows of fp8 / fp4 activations (round 4): 16-column blocks, one 16-row scaled MFMA per 128-k chunk straight from memory.
+    // Faster than the streaming kernel below from ONE row (4096^2 fp4 x fp4: 5.4 vs 6.3 us at M = 1, 5.6 vs 9.9 at M = 4) and than the
+    // 32-row tile up to 64 rows (M = 16: 5.8 vs 17.3 us) — profiles/r04/probe_mx_rows.log.  tuning[0] = 4 forces it past its
+    // x re-read budget, 5 = the streaming kernel, 2 = the tile kernels.
+    if ((a.tuning[0] == 4 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0)) && plan_mx_rows(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
+    // decode sizes of what is left (16-bit activations x MX weights, K % 128 != 0): the streaming kernel
+    if ((a.tuning[0] == 0 || a.tuning[0] == 5) && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
     // prefill sizes of the same-format pairs: 256 x 256 tiles, both operands through LDS (tuning[0] = 3 forces it at any M)
     if (plan_gemm_mx_tile(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
     if ((a.tuning[0] == 0 || a.tuning[0] == 2) && plan_gemm_mx_mma(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
@@ -189,6 +195,8 @@ static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
         p.flags = a.tuning[3];
         if (plan_gemm_wn_mma_mx(a, p, r.lp)) { r.kind = K_TILED_WN; r.wn = p; return; }
     }
+    // fp8 / fp4 activations that no tile kernel took (K % 512 != 0 with fp4 activations ...): the few-row kernel over 64-row tiles
+    if (a.tuning[0] == 0 && plan_mx_rows(a, r.gp, r.lp, true)) { r.kind = K_KMAJOR; return; }
     // NVFP4 (round 4): both operands are exact in fp16 — x is expanded into the workspace by a small kernel in front, the weights in
     // the K loop of the fp16 MFMA tile kernel (Geo<NVW4>), the layer's constant output factor rides as a per-row scale.  Two launches
     // inside this call.  tuning[0] = 1 keeps the coverage kernel.

@@ -367,6 +367,153 @@ bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPla
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Few rows (round 4; replaces gemm_splitK_MX_kernel, gemlite/triton_kernels/gemm_splitK_kernels.py:458-593, for 5 .. 64 rows — they
+// ran on the 32-row tile of the 8-wave kernel below: 17-18 us at 4096^2, the chip 7/8 empty): the shape of a8w8_rows_kernel
+// (gemm_a8w8.hip).  Block = 16 output columns (16 K-contiguous weight rows) x all of K, 8 waves dealing the 128-k chunks round-robin;
+// a chunk is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 rows of x whose operands come straight from 16-byte loads, nothing is
+// unpacked.  Operand layout of that instruction (measured: scripts/ubench/probe_mx16.hip, profiles/r04/probe_mx16_layout.log), lane
+// (r = lane & 15, q = lane >> 4) of row / column r:
+//   fp4: its 16 bytes are k = 32 q + e (low nibble first); its scale register (byte 0) scales them — MX block q of the chunk;
+//   fp8: byte b of its 32 is k = 64 (b >> 4) + 16 q + (b & 15) — 16 bytes of two different MX blocks — and block s of the chunk takes
+//        its scale from the lane with q == s: the lane LOADS bytes of blocks q >> 1 and 2 + (q >> 1) and CARRIES the scale of block q;
+//   D:   column lane & 15, rows 4 (lane >> 4) + reg.
+// Mixed formats (fp8 x rows against fp4 weight rows) pair by k, each side in its own layout.  c_mode 2 (per-token fp32 scale in the
+// epilogue): the activation block scale is the constant 127.  Rows >= M read zeros through the descriptor's range check.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int XF, int WF, int MT>
+__global__ __launch_bounds__(512) void mx_rows_kernel(const GenericParams p) {
+    constexpr int XV = XF == 0 ? 2 : 1, WV = WF == 0 ? 2 : 1;  // 16-byte pieces per fragment
+    __shared__ __attribute__((aligned(16))) float red[MT][8][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const int mbase = (int)blockIdx.y * (16 * MT);  // (more than 64 rows: row tiles along grid.y — the fall-back below the tile kernels)
+    const int nchunks = p.K / 128;
+    const int xk_bytes = XF == 0 ? p.K : p.K / 2, wk_bytes = WF == 0 ? p.K : p.K / 2;  // bytes of one row
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + wk_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((int64_t)(p.M - 1) * p.stride_xm + xk_bytes), 0x00020000);
+    const int blocks_k = p.K / 32;
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.scales, (short)0, (int)((int64_t)(blocks_k - 1) * p.stride_meta_g + (int64_t)(p.N - 1) * p.stride_meta_n + 1), 0x00020000);
+    const bool blk_x = p.sx_blocks != nullptr;
+    const int m_pad = (p.M + 31) / 32 * 32;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(blk_x ? p.sx_blocks : p.w), (short)0, blk_x ? (int)((int64_t)(m_pad - 1) * p.stride_sx_blk_m + blocks_k) : 4, 0x00020000);
+    // byte offsets inside a 128-k chunk: fp8 pieces at 16 q and 64 + 16 q, the fp4 piece at 16 q (= k 32 q)
+    const uint32_t wvoff = (uint32_t)((n0 + c) * p.stride_wn + q * 16);
+    const uint32_t svoff = (uint32_t)((n0 + c) * p.stride_meta_n + (int64_t)q * p.stride_meta_g);
+    uint32_t xvoff[MT], avoff[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = mbase + c + 16 * t;
+        xvoff[t] = m < p.M ? (uint32_t)((int64_t)m * p.stride_xm + q * 16) : 0x80000000u;  // rows >= M: zeros
+        avoff[t] = (uint32_t)((int64_t)m * p.stride_sx_blk_m + q);                            // (rows < m_pad exist)
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int D = MT == 1 ? 4 : (MT == 2 ? 3 : 2);  // chunks in flight per wave
+    struct Chunk { u32x4 w[WV]; uint32_t sw; u32x4 x[MT][XV]; uint32_t sx[MT]; };
+    Chunk ring[D];
+    const int mine = (nchunks - wave + 7) >> 3;  // chunks wave, wave + 8, ...
+    auto load = [&](int slot, int i) __attribute__((always_inline)) {
+        const int ch = wave + 8 * i;
+        Chunk& k = ring[slot];
+        const uint32_t wo = (uint32_t)__builtin_amdgcn_readfirstlane(ch * (WF == 0 ? 128 : 64));
+        const uint32_t xo = (uint32_t)__builtin_amdgcn_readfirstlane(ch * (XF == 0 ? 128 : 64));
+        k.w[0] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, wo, 0);
+        if constexpr (WV == 2) k.w[1] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, wo + 64u, 0);
+        k.sw = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsS, svoff, (uint32_t)__builtin_amdgcn_readfirstlane(ch * 4 * (int)p.stride_meta_g), 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            k.x[t][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], xo, 0);
+            if constexpr (XV == 2) k.x[t][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], xo + 64u, 0);
+            k.sx[t] = blk_x ? (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, avoff[t], (uint32_t)__builtin_amdgcn_readfirstlane(ch * 4), 0) : 127u;
+        }
+    };
+    auto mma = [&](int slot) __attribute__((always_inline)) {
+        const Chunk& k = ring[slot];
+        v8i bv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bv[i] = (int)k.w[0][i];
+            bv[4 + i] = WV == 2 ? (int)k.w[WV - 1][i] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            v8i av;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[i] = (int)k.x[t][0][i];
+                av[4 + i] = XV == 2 ? (int)k.x[t][XV - 1][i] : 0;
+            }
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc[t], XF, WF, 0, (int)k.sx[t], 0, (int)k.sw);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        if (j < mine) load(j, j);
+    for (int base = 0; base < mine; base += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (base + j < mine) {
+                mma(j);
+                if (base + j + D < mine) load(j, base + j + D);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *(f32x4*)&red[t][wave][lane][0] = acc[t];
+    __syncthreads();
+    for (int u = tid; u < MT * 256; u += 512) {
+        const int t = u >> 8, l = u & 63, r = (u >> 6) & 3;
+        const int m = mbase + 16 * t + 4 * (l >> 4) + r;  // C fragment of a 16 x 16 MFMA: column lane & 15, rows 4 (lane >> 4) + r
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[t][w][l][r];
+        if (m < p.M) epilogue_store(p.epi, v * p.mx_post, m, n0 + (l & 15));
+    }
+}
+
+// 1 <= M <= 64, same conditions as the scaled-MFMA kernel below plus K % 128 == 0 and the x re-read budget of a8w8_rows_kernel
+// (8192^2 fp8: M = 32 25.7 vs 24.2 us, M = 64 42.0 vs 25.1 for the tile kernel).  tuning[0] = 4 forces it past the budget.
+// any_m: the fall-back for shapes no tile kernel takes (fp4 activations with K % 512 != 0 — K = 11008 — ran on the coverage kernel:
+// 4.5 ms at 4096 x 11008, M = 1): 64-row tiles along grid.y, any M.
+bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp, bool any_m) {
+    if ((a.M > 64 && !any_m) || a.M < 1 || a.M > 65535 * 64 || g.mx_scale_e4m3 || g.group_size != 32) return false;
+    if (!(g.mx_x == MX_FP8 || g.mx_x == MX_FP4) || (g.mx_x == MX_FP4 && g.mx_w != MX_FP4)) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.K % 128 != 0 || a.N % 16 != 0) return false;
+    if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
+    if ((int64_t)a.M * a.stride_xm + a.K >= (1ll << 31) || (int64_t)a.N * a.stride_wn + a.K >= (1ll << 31)) return false;
+    if ((int64_t)(a.K / 32) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    const int64_t xrow = g.mx_x == MX_FP8 ? a.K : a.K / 2;
+    if (mt > 1 && a.tuning[0] != 4 && !any_m && (int64_t)a.M * xrow * (a.N / 16) > (88ll << 20)) return false;  // every block re-reads its rows of x from L2
+    typedef void (*fn_t)(const GenericParams);
+    fn_t fn = nullptr;
+    auto pick = [&](auto xf, auto wf) -> fn_t {
+        constexpr int XF = decltype(xf)::value, WF = decltype(wf)::value;
+        return mt == 1 ? mx_rows_kernel<XF, WF, 1> : (mt == 2 ? mx_rows_kernel<XF, WF, 2> : mx_rows_kernel<XF, WF, 4>);
+    };
+    typedef std::integral_constant<int, 0> F8;
+    typedef std::integral_constant<int, 4> F4;
+    const bool x8 = g.mx_x == MX_FP8, w8 = g.mx_w == MX_FP8;
+    fn = x8 ? (w8 ? pick(F8{}, F8{}) : pick(F8{}, F4{})) : pick(F4{}, F4{});
+    lp.fn = (const void*)fn;
+    static const char* names[3][3] = {{"mx_rows_a8w8_kernel<16x16>", "mx_rows_a8w8_kernel<32x16>", "mx_rows_a8w8_kernel<64x16>"},
+                                      {"mx_rows_a8w4_kernel<16x16>", "mx_rows_a8w4_kernel<32x16>", "mx_rows_a8w4_kernel<64x16>"},
+                                      {"mx_rows_a4w4_kernel<16x16>", "mx_rows_a4w4_kernel<32x16>", "mx_rows_a4w4_kernel<64x16>"}};
+    lp.name = names[x8 ? (w8 ? 0 : 1) : 2][mt == 1 ? 0 : (mt == 2 ? 1 : 2)];
+    lp.grid = dim3((unsigned)(a.N / 16), (unsigned)((a.M + 16 * mt - 1) / (16 * mt)), 1);
+    lp.block = dim3(512, 1, 1);
+    lp.lds_bytes = 0;
+    lp.ws_bytes = 0;
+    lp.slab_bytes = 0;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // scaled-MFMA kernel.  AF / BF: element format of x / w as the instruction's cbsz / blgp code (0 = fp8 e4m3, 4 = fp4 e2m1).
 // A K step moves 256 BYTES of every x row (256 k of fp8, 512 k of fp4); wave (cg, kh) owns all rows x 32 columns x the
 // kh-th half of the step = NS slices of 64 k.  Per slice and lane: A fragment = 16 (fp4) or 2 x 16 (fp8) bytes read from

@@ -154,13 +154,24 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(args(16, 8, 256, 4)) == "gemm_mx_a8w8_kernel<128x128>"  # the tallest tile that fills the chip with <= K / 1024 slices
     assert name(args(16, 8, 2048, 4, N=8192, K=8192)) == "gemm_mx_a8w8_tile_kernel<256x256>"  # >= 96 tiles of 256 x 256
     assert name(args(16, 8, 512, 4, N=8192, K=8192)) == "gemm_mx_a8w8_kernel<128x128>"        # 64 tiles: the 128-row kernel
-    assert name(args(16, 8, 1, 4)) == "mx_gemv_w8_kernel"             # decode: streaming kernel up to 4 rows
-    assert name(args(17, 4, 4, 4)) == "mx_gemv_w4_kernel"
-    assert name(args(16, 8, 5, 4)) == "gemm_mx_a8w8_kernel<32x128>"
+    assert name(args(16, 8, 1, 4)) == "mx_rows_a8w8_kernel<16x16>"    # round 4: fp8 / fp4 activations take the few-row MFMA kernel from 1 row
+    assert name(args(17, 4, 4, 4)) == "mx_rows_a4w4_kernel<16x16>"
+    a = args(16, 8, 1, 4)
+    a.tuning[0] = 5                                                       # A/B switch: the streaming kernel of rounds 2-3 (up to 4 rows)
+    assert name(a) == "mx_gemv_w8_kernel"
+    assert name(args(16, 8, 1, 4, K=4096 + 32)) == "mx_gemv_w8_kernel"   # K % 128 != 0
+    assert name(args(14, 8, 1, 0)) == "mx_gemv_w8_kernel"                # 16-bit activations x MX weights
+    assert name(args(17, 4, 300, 4, K=11008)) == "mx_rows_a4w4_kernel<64x16>"   # fp4 activations, K % 512 != 0: no tile kernel -> 64-row tiles of the few-row kernel
+    assert name(args(17, 4, 300, 4, K=4096)) == "gemm_mx_a4w4_kernel<128x128>"
+    assert name(args(16, 8, 5, 4)) == "mx_rows_a8w8_kernel<16x16>"       # round 4: 5 .. 64 rows, 16-column blocks
+    assert name(args(16, 4, 33, 2)) == "mx_rows_a8w4_kernel<64x16>"
+    assert name(args(17, 4, 20, 4)) == "mx_rows_a4w4_kernel<32x16>"
+    assert name(args(16, 8, 64, 4, N=16384, K=16384)) == "gemm_mx_a8w8_kernel<64x128>"  # past the x re-read budget: the tile kernel
     a = args(16, 8, 1, 4)
     a.tuning[0] = 2                                                       # A/B switch: MFMA kernel at decode sizes
     assert name(a) == "gemm_mx_a8w8_kernel<32x128>"
-    assert name(args(17, 4, 48, 4, N=16384)) == "gemm_mx_a4w4_kernel<64x128>"
+    assert name(args(17, 4, 48, 4, N=16384)) == "gemm_mx_a4w4_kernel<64x128>"   # 48 x 2 KB x 1024 blocks of x re-reads: over the budget
+    assert name(args(17, 4, 40, 4, N=16384)) == "mx_rows_a4w4_kernel<64x16>"
     # NVFP4: no scaled-MFMA form takes e4m3 block-16 scales; both operands are exact in fp16, so the fp16 tile kernel runs it (round 4:
     # x expanded by a kernel in front, the weights in the K loop; workspace = tickets + slabs + M K fp16 + M floats)
     assert name(args(18, 4, 8, 4, group=16)) == "gemm_nvfp4_f16_kernel<32x128>"

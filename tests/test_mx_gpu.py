@@ -161,11 +161,20 @@ def test_processor_forward_vs_oracle(proc, tdt):
         x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
         name = _kernel_name(layer, x)
         want = EXPECT[proc] if (M > 4 or "NVFP" in proc) else "mx_gemv_w"
+        if M <= 64 and "dynamic" in proc and "NVFP" not in proc:
+            want = "mx_rows_"  # round 4: 1 .. 64 rows of the fp8 / fp4 activation formats
         assert name.startswith(want), (proc, M, name)
         y = layer(x)
         assert y.dtype == tdt and tuple(y.shape) == (M, N)
         ref = _oracle(layer, x) + bias.float().cpu().numpy().astype(np.float64)
         _check(f"{proc} {tdt} M={M} {name}", y, ref, tdt)
+        if M <= 4 and "dynamic" in proc and "NVFP" not in proc:  # the streaming kernel of rounds 2-3 (A/B switch) gives the same answer
+            try:
+                C.TUNING_OVERRIDE = (5, 0, 0, 0)
+                assert _kernel_name(layer, x, (5, 0, 0, 0)).startswith("mx_gemv_w")
+                _check(f"{proc} {tdt} M={M} gemv", layer(x), ref, tdt)
+            finally:
+                C.TUNING_OVERRIDE = None
         if M <= 4 and "NVFP" not in proc:  # the MFMA kernel at decode sizes (A/B switch) gives the same answer
             try:
                 C.TUNING_OVERRIDE = (2, 0, 0, 0)
@@ -207,6 +216,52 @@ def test_mfma_kernel_tiles_slices_and_coverage_agree(proc):
     for ws in _hip._workspaces.values():
         torch.cuda.synchronize()
         assert int(ws[:4 * 61440].view(torch.int32).abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("proc", ["A8W8_MXFP_dynamic", "A8W8_MXFP_dynamic_post", "A8W4_MXFP_dynamic", "A8W4_MXFP_dynamic_post", "A4W4_MXFP_dynamic"])
+def test_few_row_scaled_mfma_kernel(proc):
+    """mx_rows_kernel (one v_mfma_scale_f32_16x16x128_f8f6f4 per 128-k chunk and 16 rows, operands straight from memory): every
+    format pair (fp8 x fp8, fp8 x fp4 — each side in its own operand layout — fp4 x fp4), block and per-token activation scales, the
+    three row-tile heights with ragged M, K an odd multiple of 128, forced at decode sizes; against the float64 oracle and against the
+    8-wave tile kernel it replaces at these sizes."""
+    tdt = torch.bfloat16
+    N, K = 256, 1152
+    lin = _linear(N, K, tdt, seed=9)
+    bias = lin.bias.data.float().cpu().numpy().astype(np.float64)
+    layer = PROCS[proc](tdt).from_linear(lin, del_orig=False)
+    g = torch.Generator().manual_seed(13)
+    for M in (1, 3, 5, 16, 17, 32, 33, 50, 64):
+        x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
+        x[0, :64] *= 30   # blocks with very different scales inside a row
+        ref = _oracle(layer, x) + bias
+        try:
+            C.TUNING_OVERRIDE = (4, 0, 0, 0)
+            name = _kernel_name(layer, x, (4, 0, 0, 0))
+            assert name.startswith("mx_rows_") and name.endswith({1: "<16x16>", 2: "<32x16>", 4: "<64x16>"}[1 if M <= 16 else (2 if M <= 32 else 4)]), name
+            y = layer(x)
+            _check(f"{proc} rows M={M} {name}", y, ref, tdt)
+            C.TUNING_OVERRIDE = (2, 0, 0, 0)
+            y_tile = layer(x)
+            _check(f"{proc} rows vs tile kernel M={M}", y, y_tile.float().cpu().numpy(), tdt)
+        finally:
+            C.TUNING_OVERRIDE = None
+        assert _kernel_name(layer, x).startswith("mx_rows_"), _kernel_name(layer, x)
+
+
+def test_fp4_activations_with_k_not_a_multiple_of_512_leave_the_coverage_kernel():
+    """The fp4 x fp4 tile kernels step 512 k; K = 11008 (Llama down_proj) is 21.5 such steps and ran on the coverage kernel in rounds 2-3
+    (4.5 ms at 4096 x 11008).  Round 4: any M on 64-row tiles of the few-row kernel (grid.y), 128-k chunks."""
+    tdt = torch.bfloat16
+    N, K = 256, 1280
+    lin = _linear(N, K, tdt, seed=21)
+    bias = lin.bias.data.float().cpu().numpy().astype(np.float64)
+    layer = PROCS["A4W4_MXFP_dynamic"](tdt).from_linear(lin, del_orig=False)
+    g = torch.Generator().manual_seed(17)
+    for M in (7, 64, 65, 100, 300):
+        x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
+        name = _kernel_name(layer, x)
+        assert name.startswith("mx_rows_a4w4_kernel"), name
+        _check(f"a4w4 K=1280 M={M} {name}", layer(x), _oracle(layer, x) + bias, tdt)
 
 
 @pytest.mark.parametrize("M", [1, 4, 16])
