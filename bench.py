@@ -91,13 +91,18 @@ WORKLOADS = {
     "mx_a4w4_4096_m1": (4096, 4096, 4, 32, 1, "mxa4", 32, "hbm"),
     "mx_a4w4_8192_m256": (8192, 8192, 4, 32, 256, "mxa4", 8, "mfma"),
     "mx_a4w4_8192_m2048": (8192, 8192, 4, 32, 2048, "mxa4", 8, "mfma"),
+    # round 4: decode-batch sizes of the block-scaled formats (few-row scaled-MFMA kernel) and NVFP4 (fp16 MFMA tile kernel)
+    "mx_a8w8_4096_m16": (4096, 4096, 8, 32, 16, "mxa8", 32, "hbm"),
+    "mx_a4w4_4096_m16": (4096, 4096, 4, 32, 16, "mxa4", 32, "hbm"),
+    "nvfp4_4096_m16": (4096, 4096, 4, 16, 16, "nva4", 32, "hbm"),
+    "nvfp4_4096_m256": (4096, 4096, 4, 16, 256, "nva4", 32, "mfma"),
     "mx_a16w4_4096_m1": (4096, 4096, 4, 32, 1, "mxa16", 32, "hbm"),
     "mx_a16w4_4096_m256": (4096, 4096, 4, 32, 256, "mxa16", 32, "mfma"),
     "mx_a16w4_8192_m256": (8192, 8192, 4, 32, 256, "mxa16", 8, "mfma"),
     "mx_a16w8_8192_m256": (8192, 8192, 8, 32, 256, "mxa16", 4, "mfma"),
 }
-PREQUANT = ("int8", "fp8", "fp8w8", "mxa8", "mxa4")  # workloads whose x is quantised once, outside the timed matmul
-MX = ("mxa8", "mxa4", "mxa16")
+PREQUANT = ("int8", "fp8", "fp8w8", "mxa8", "mxa4", "nva4")  # workloads whose x is quantised once, outside the timed matmul
+MX = ("mxa8", "mxa4", "mxa16", "nva4")
 
 
 def algorithmic_bytes(M, N, K, nbits, group, esize=2):
@@ -113,7 +118,7 @@ def work_per_launch(name):
     if dt == "fp8":  # packed W + fp16 group metadata + fp8 x + fp32 token scales + fp16 out
         nbytes = K * N * nbits // 8 + 2 * (K // group) * N * 2 + M * K + M * 4 + M * N * 2
     if dt in MX:  # W elements + one scale byte per 32 k, x elements (+ its scale bytes), bf16 out
-        xb = {"mxa8": M * K + M * K // 32, "mxa4": M * K // 2 + M * K // 32, "mxa16": M * K * 2}[dt]
+        xb = {"mxa8": M * K + M * K // 32, "mxa4": M * K // 2 + M * K // 32, "mxa16": M * K * 2, "nva4": M * K // 2 + M * K // 16}[dt]
         nbytes = K * N * nbits // 8 + (K // 32) * N + xb + M * N * 2
     return nbytes, 2 * M * N * K
 
@@ -126,11 +131,12 @@ def build_layers(name, device, layers=None, raw_x=False):
     layers = nl if layers is None else layers
     if dt in MX:
         from gemlite_amd import helper as H
-        from gemlite_amd.quant_utils import scale_activations_mxfp4, scale_activations_mxfp8
+        from gemlite_amd.quant_utils import scale_activations_mxfp4, scale_activations_mxfp8, scale_activations_nvfp4
         g = torch.Generator(device=device).manual_seed(0)
         tdt = torch.bfloat16
         proc = {"mxa8": lambda: H.A8Wn_MXFP_dynamic(device=device, dtype=tdt, post_scale=False, W_nbits=nbits),
                 "mxa4": lambda: H.A4W4_MXFP_dynamic(device=device, dtype=tdt),
+                "nva4": lambda: H.A4W4_NVFP_dynamic(device=device, dtype=tdt),
                 "mxa16": lambda: H.A16Wn_MXFP(device=device, dtype=tdt, W_nbits=nbits)}[dt]()
         mods = []
         for _ in range(layers):
@@ -141,7 +147,9 @@ def build_layers(name, device, layers=None, raw_x=False):
         x = (torch.randn(M, K, generator=g, device=device) / 10).to(tdt)
         if dt == "mxa16":
             return mods, x
-        return mods, (scale_activations_mxfp8(x) if dt == "mxa8" else scale_activations_mxfp4(x))
+        if raw_x:
+            return mods, x
+        return mods, (scale_activations_mxfp8(x) if dt == "mxa8" else (scale_activations_nvfp4(x) if dt == "nva4" else scale_activations_mxfp4(x)))
     if dt in ("int8", "fp8w8"):
         from gemlite_amd.helper import A8W8_fp8_dynamic, A8W8_int8_dynamic
         from gemlite_amd.quant_utils import scale_activations_per_token
@@ -347,7 +355,7 @@ class Runner:
             peak, unit, work = HBM_PEAK_GBS, "GB/s", self.bytes / 1e9
         else:
             peak = {"int8": INT8_MFMA_PEAK_TOPS, "fp8": INT8_MFMA_PEAK_TOPS, "fp8w8": INT8_MFMA_PEAK_TOPS, "mxa8": MXFP8_MFMA_PEAK_TFLOPS,
-                    "mxa4": MXFP4_MFMA_PEAK_TFLOPS}.get(self.dt, MFMA_PEAK_TFLOPS)
+                    "mxa4": MXFP4_MFMA_PEAK_TFLOPS, "nva4": MFMA_PEAK_TFLOPS}.get(self.dt, MFMA_PEAK_TFLOPS)
             unit, work = "TFLOP/s", self.flops / 1e12
         ach = work / (c_us * 1e-6)
         out.update({"achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
@@ -529,6 +537,10 @@ def main():
                                      "fp8_16384_m1_layer_e2e": block("fp8_16384_m1", e2e=True),
                                      "fp8_16384_m256_layer_e2e": block("fp8_16384_m256", e2e=True)}
             # the large-M end of the same kernel family (north star: "tiled GEMM for large-M prefill"), same clock
+            # round 4: block-scaled formats at decode-batch sizes (few-row scaled-MFMA kernel; NVFP4 on the fp16 tile kernel), matmul on
+            # pre-quantised x and layer(x) with the activation quantiser
+            line["roofline_mx_fewrows"] = {w: block(w) for w in ("mx_a8w8_4096_m16", "mx_a4w4_4096_m16", "nvfp4_4096_m16", "nvfp4_4096_m256")}
+            line["roofline_mx_fewrows"].update({w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a4w4_4096_m16", "nvfp4_4096_m16")})
             line["roofline_prefill_m2048"] = block("a16w4_8192_m2048", 4)
             line["roofline_trend_m1"] = {"8192": block("a16w4_8192_m1"), "16384": block("a16w4_16384_m1")}
         except Exception as e:

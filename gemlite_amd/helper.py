@@ -458,9 +458,38 @@ def patch_model(model: torch.nn.Module, device, processor=None, skip_modules=("l
     return model.to(device)
 
 
-def warmup(*_a, **_k):
-    """The reference pre-runs Triton autotuning per shape (helper.py:1067-1118); HIP kernels are compiled
-    ahead of time, so there is nothing to warm up.  (autotune_layer() below is the optional measured search.)"""
+def warmup(processor=None, shapes=(), batch_sizes=None, group_size: int = 64, dtype: torch.dtype = torch.float16):
+    """The reference pre-runs Triton autotuning per (shape, M bucket) here (helper.py:1067-1118).  The HIP kernels are compiled ahead of
+    time, so what is left to warm is the first-use work of a serving process: loading the code object, the shipped tuning table, and —
+    with a processor and shapes, same call as the reference's `warmup(A8W8_INT8_dynamic(), shapes=[(4096, 4096)], batch_sizes=[1, 8])` —
+    one call per (out_features, in_features) and batch size on a random layer of that shape, which sizes the stream's workspace for the
+    largest plan, raises the kernels' LDS limits and fills the launch-template caches, so that no request pays for them.
+    (`group_size` belongs to the reference's hqq path; processors that need hqq are skipped.  autotune_layer() below is the measured
+    search over the planners' alternatives.)"""
+    from . import _hip
+    from .core import _M_BUCKETS, autoload_default_config
+    import logging
+    logger = logging.getLogger(__name__)
+    _hip.load()
+    if not torch.cuda.is_available():
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device())
+    autoload_default_config(dev.index)
+    if processor is None or not shapes or not hasattr(processor, "from_linear"):
+        return None
+    if batch_sizes is None:
+        batch_sizes = _M_BUCKETS[::-1]  # the reference's default: every M bucket (helper.py:1067)
+    for out_features, in_features in shapes:
+        linear = torch.nn.Linear(in_features, out_features, bias=False, device=dev, dtype=dtype)
+        try:
+            layer = processor.from_linear(linear)
+        except Exception as e:  # (a processor that only converts HQQ layers, a shape it rejects: same as the reference — say so, go on)
+            logger.warning(f"warmup: {type(processor).__name__} does not take a {out_features} x {in_features} layer: {e}")
+            continue
+        for bs in batch_sizes:
+            layer(torch.randn(int(bs), in_features, device=dev, dtype=dtype) / 10)
+        del layer, linear
+    torch.cuda.synchronize()
     return None
 
 

@@ -163,7 +163,8 @@ typedef struct gemlite_hip_forward_args {
      *   packed GEMV (M = 1)        [0] 2/3/4 = 16-/32-/64-column tiles   [1] K slices   [2] 4/8/16 waves per block
      *                              (82 = 8 waves, 2 rows per lane; 48 = 4 waves, 8 rows per lane)   [3] & 3: 1 = x through LDS,
      *                              2 = x direct; & 16 = the round-2 kernel instead of the 16-column decode kernel,
-     *                              & 32 = default-policy (not non-temporal) weight loads in the decode kernel
+     *                              & 32 = default-policy (not non-temporal) weight loads in the decode kernel,
+     *                              & 4096 = the round-3 decode kernel (struct arguments) instead of gemv_w4_decode3_kernel
      *   MFMA GEMV (M = 1..4, 4- and 2-bit words under 16-bit activations; default where it measured faster)
      *                              [0] 21/22/24 = 16-/32-/64-column tiles   [2] 4/8/16 waves per block
      *                              [3] & 512 = never, & 1024 = wherever it applies
@@ -174,15 +175,25 @@ typedef struct gemlite_hip_forward_args {
      *                              fallback for K = 64 * odd)
      *                              [1] K slices (any count <= K steps; slices may be uneven)
      *                              [2] tile rows / 32: 1/2/4/8 (8-wave kernel, 128-column tiles); 20 / 24 = 128 / 256 rows x 256
-     *                              columns (4- and 2-bit, 16-bit activations); with [0] = 2: 4 = one-step-ahead, 8 = 256 rows
-     *                              (both only in a library built with `make AB=1`)
+     *                              columns (4- and 2-bit, 16-bit activations); 32 .. 35 = the narrow 64-COLUMN tiles of round 4
+     *                              (32: 64 x 64, 256-k steps — the default where they fill the chip without K slices, e.g.
+     *                              4096^2 at M = 256; 33: 64 x 64, 512-k steps; 34 / 35: 128 x 64); with [0] = 2: 4 = one-step-ahead,
+     *                              8 = 256 rows (both only in a library built with `make AB=1`)
      *                              [3] K-slice combine: & 128 = slabs + ticket always, & 2048 = reduce-scatter with 2 slices too
-     *                              (default: from 4 slices), & 256 = reduce-scatter with immediate hand-over (test switch)
+     *                              (default: from 4 slices), & 256 = reduce-scatter with immediate hand-over (test switch);
+     *                              & 16384 = never the narrow tiles (the round-3 choice, A/B runs)
      *   unpacked 8-bit (A8W8)      [0] 1 = streaming (one wave per column), 2 = the 4-wave MFMA kernel of round 1 (the planner's
      *                              fallback for K % 256 != 0), 4 = the 16-column few-row kernel (default for 2..64 rows while
-     *                              M K N / 16 <= 88 MiB) at any M <= 64 and at M = 1
+     *                              M K N / 16 <= 88 MiB) at any M <= 64 and at M = 1, 5 = the unsplit 64 x 64 tiles of round 4
+     *                              (default from 65 rows where they fill the chip once or twice; [2] = 2/3/4 LDS stages),
+     *                              6 = the round-3 kernels instead
      *                              [1] K slices   [2] tile rows / 32 (forces the 8-wave kernels at any M)
      *                              [3] & 64: 128- / 256-row tiles with the weights straight from memory (default: through LDS)
+     *                              [3] & 32768: test switch of the in-launch activation quantisation (no producer block runs)
+     *   block-scaled (MX / NVFP4)  [0] 1 = coverage kernel, 2 = the 8-wave scaled-MFMA tile kernels at any M, 3 = the 256 x 256 tile
+     *                              kernel at any M, 4 = the few-row kernel (default for 1..64 rows of fp8 / fp4 activations) past
+     *                              its x re-read budget, 5 = the streaming kernel of rounds 2-3 (M <= 4)
+     *                              [1] K slices   [2] tile rows / 32   (NVFP4: [0] = 1 coverage kernel, else the fp16 tile kernel)
      *   [3] & 4: development timeline stamps (needs a workspace)   [3] & 8: XCD-aware (tile, K slice) map (opt-in).
      *   A value that does not apply to the shape makes the planner fall through to its own choice or to another family;
      *   it never produces a wrong result. */

@@ -1076,6 +1076,22 @@ def test_cooperative_activation_quant_under_graph_replay(M):
         gemlite_amd.core.FUSE_ACT_QUANT_ROWS = False
 
 
+def test_warmup_sizes_the_workspace_and_leaves_nothing_to_the_first_request():
+    """helper.warmup(processor, shapes, batch_sizes): one call per shape and batch size on a random layer — afterwards the stream's workspace
+    holds the largest plan of those shapes (no regrow, hence no allocation, inside a later graph capture)."""
+    H = gemlite_amd.helper
+    dev = torch.device(DEV)
+    stream = _hip.current_stream_handle(dev)
+    H.warmup(H.A8W8_int8_dynamic(device=DEV, dtype=torch.float16), shapes=[(2048, 4096)], batch_sizes=[1, 16, 300, 1024])
+    ws = _hip.workspace(dev, stream, 0)
+    lin = H.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights((torch.randn(2048, 4096) / 30).half())
+    for M in (1, 16, 300, 1024):
+        y = lin((torch.randn(M, 4096, device=DEV) / 10).half())
+        assert tuple(y.shape) == (M, 2048)
+    torch.cuda.synchronize()
+    assert _hip.workspace(dev, stream, 0).data_ptr() == ws.data_ptr()  # same buffer: nothing grew
+
+
 def test_shipped_tuning_table_autoloads_by_device_and_its_entries_stay_correct():
     """gemlite_amd/configs/mi355x.json is found from the device (name or ISA), loaded once on the first launch like the
     reference's configs/<gpu>.json (core.py:634-654), and launches that hit an entry still match the oracle."""

@@ -729,6 +729,16 @@ def test_in_launch_activation_quantisation_is_planned_from_two_rows_and_says_whe
     assert b"scales_x" in lib.gemlite_hip_status_string(_hip.ERR_NO_FUSED_QUANT)
 
 
+def test_warmup_takes_the_reference_arguments():
+    """helper.warmup(processor, shapes, batch_sizes, group_size, dtype) (reference: helper.py:1067-1118).  Without a GPU it loads the
+    library and returns; with one it runs every (shape, batch size) once (tests/test_gpu_parity.py)."""
+    import inspect
+    from gemlite_amd import helper
+    assert list(inspect.signature(helper.warmup).parameters)[:5] == ["processor", "shapes", "batch_sizes", "group_size", "dtype"]
+    assert helper.warmup() is None
+    assert helper.warmup(helper.A16W8(device="cpu"), shapes=[(64, 64)], batch_sizes=[1]) is None
+
+
 def test_tuning_table_mutations_bump_the_epoch_of_the_cpp_fast_path():
     """core.GEMLITE_HIP_CONFIG_CACHE counts its mutations (also those of the family dicts inside it): the C++ eager path caches tuning[]
     per (layer, M) for one epoch only."""
