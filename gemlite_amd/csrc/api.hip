@@ -39,6 +39,7 @@ const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
 const void* kmajor_w8a16_kernel_fn(int mb);
 const void* kmajor_fused_quant_kernel_fn(int qdt);
+const void* a8w8_decode_kernel_fn(int qdt, bool fused);
 const void* act_quant_kernel_fn();
 const void* act_quant_vec_kernel_fn(int in_dt, int out_dt, int64_t K, int64_t stride_xm, const void* x, const void* y);
 const void* pack_kernel_fn();
@@ -391,6 +392,20 @@ coverage:
         if (a.stride_wk != 1 || a.stride_xk != 1 || a.K % 16 != 0 || a.stride_wn % 16 != 0 || a.K > 65536 ||
             (((uintptr_t)a.w_q | (uintptr_t)a.x) % 16) != 0) { r.status = GEMLITE_ERR_UNSUPPORTED; return; }
         r.kind = K_KMAJOR;
+        // round 4: one wave per column with the whole weight row requested BEFORE the block quantises x (a8w8_decode_kernel);
+        // tuning[0] = 7 keeps the round-2 kernel, which quantises first
+        // (profiles/r04/probe_a8w8_decode.log: int8 faster on all 8 shapes tried, 4096^2 7.27 -> 6.18 us, 4096 x 14336 18.9 -> 14.5; fp8 —
+        //  8 converter + 16 fma instructions per 16 bytes — only while the tiles are one round of blocks: 4096^2 7.80 -> 6.62, but
+        //  8192^2 17.3 -> 18.9, 16384^2 54.5 -> 58.7)
+        const bool dec_ok = a.tuning[0] != 7 && a.K % 1024 == 0 && a.N % 16 == 0 && (a.w_dtype == GEMLITE_DT_INT8 || a.N <= 4096 || a.tuning[0] == 8);
+        if (dec_ok && a.stride_on == 1 && a.K <= 61440) {
+            r.lp.fn = a8w8_decode_kernel_fn(a.w_dtype, true);
+            r.lp.name = "a8w8_decode_fused_quant_kernel<tile16,16w>";
+            r.lp.grid = dim3((unsigned)(a.N / 16), 1, 1);
+            r.lp.block = dim3(1024, 1, 1);
+            r.lp.lds_bytes = (size_t)a.K + 64;
+            return;
+        }
         r.lp.fn = kmajor_fused_quant_kernel_fn(a.w_dtype);
         r.lp.name = "kmajor_fused_quant_kernel";
         r.lp.grid = dim3((unsigned)((a.N + 7) / 8), 1, 1);
@@ -446,6 +461,15 @@ coverage:
         !(a.M > 1 && (a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5))) {  // fp8 rows > 1: MFMA kernels / coverage
         const int mb = a.M == 1 ? 1 : 4;
         r.kind = K_KMAJOR;
+        // round 4: the 8-bit decode kernel (one wave per column, the whole row in flight at once); tuning[0] = 7 keeps kmajor_matmul_kernel
+        if (a.M == 1 && esz == 1 && a.tuning[0] != 7 && a.K % 1024 == 0 && a.N % 16 == 0 &&
+            (a.w_dtype == GEMLITE_DT_INT8 || ((a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5) && (a.N <= 4096 || a.tuning[0] == 8)))) {
+            r.lp.fn = a8w8_decode_kernel_fn(a.w_dtype, false);
+            r.lp.name = "a8w8_decode_kernel<tile16,16w>";
+            r.lp.grid = dim3((unsigned)(a.N / 16), 1, 1);
+            r.lp.block = dim3(1024, 1, 1);
+            return;
+        }
         r.lp.fn = kmajor_kernel_fn(mb);
         r.lp.name = "kmajor_matmul_kernel";
         r.lp.grid = dim3((unsigned)((a.N + 3) / 4), (unsigned)((a.M + mb - 1) / mb), 1);

@@ -300,6 +300,143 @@ __global__ __launch_bounds__(512) void kmajor_fused_quant_kernel(const GenericPa
         store_from_float(p.epi.out, n * p.epi.stride_on, p.epi.out_dt, v);
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// a8w8_decode_kernel (round 4): M = 1 of the unpacked 8-bit layers (A8W8 int8 / fp8 dynamic, BASELINE configs[3] / [4]) built like
+// gemv_w4_decode3_kernel — a launch this size is latency, not arithmetic.  Replaces gemv_INT_splitK_kernel (gemlite/triton_kernels/
+// gemv_splitK_kernels.py:240-420) for these layers and, in its FUSED form, scale_activations_per_token (quant_utils.py:268-347) in the
+// same launch (core.py:155-175 runs it as a launch of its own).  Block = 16 waves = 16 output columns; a wave owns ONE K-contiguous
+// weight row and requests it as 16-byte loads per lane (k = j * 1024 + lane * 16) in batches of up to 8 — at K = 4096 the whole row is
+// in flight before anything else happens.  FUSED: the block then quantises the one row of x into LDS (amax over the block, IEEE
+// divisions: bit-identical to act_quant_per_token_kernel) UNDER that round trip — kmajor_fused_quant_kernel quantised first and only
+// then asked for its weights.  v_dot4_i32_i8 (exact) / hardware fp8 converters + fp32 fma; one wave = one column: no cross-wave sum.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int QDT, bool FUSED>
+__global__ __launch_bounds__(1024, 1) void a8w8_decode_kernel(const GenericParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // FUSED: [K] quantised x, then 16 floats
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n = (int64_t)blockIdx.x * 16 + wave;
+    const uint8_t* wcol = (const uint8_t*)p.w + n * p.stride_wn;
+    constexpr int B = 8;  // 16-byte pieces of the row in flight per lane
+    const int npieces = p.K >> 10;  // K % 1024 == 0 (planner)
+    u32x4 wv[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+        if (j < npieces) wv[j] = __builtin_nontemporal_load((const u32x4*)(wcol + (j << 10) + lane * 16));
+
+    float sx = 1.f;
+    const uint8_t* xq;
+    if constexpr (FUSED) {
+        float* wmax = (float*)(smem + p.K);
+        const uint16_t* xr = (const uint16_t*)p.x;
+        const bool f16 = p.x_dt == GEMLITE_DT_FP16;
+        float amax = 0.f;
+        for (int k = tid * 8; k < p.K; k += 1024 * 8) {
+            const u32x4 v = *(const u32x4*)(xr + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint16_t hbits = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
+                amax = fmaxf(amax, fabsf(f16 ? F16Traits<half_tag>::to_float(hbits) : F16Traits<bf16_tag>::to_float(hbits)));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if (lane == 0) wmax[wave] = amax;
+        __syncthreads();
+        amax = wmax[lane & 15];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        constexpr float qmin = QDT == GEMLITE_DT_INT8 ? -128.f : (QDT == GEMLITE_DT_FP8E4 ? -448.f : -57344.f);
+        constexpr float qmax = QDT == GEMLITE_DT_INT8 ? 127.f : (QDT == GEMLITE_DT_FP8E4 ? 448.f : 57344.f);
+        sx = fmaxf(__fdiv_rn(amax, qmax), 1e-6f);
+        for (int k = tid * 8; k < p.K; k += 1024 * 8) {
+            const u32x4 v = *(const u32x4*)(xr + k);
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint16_t hbits = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
+                const float f = f16 ? F16Traits<half_tag>::to_float(hbits) : F16Traits<bf16_tag>::to_float(hbits);
+                t[e] = fminf(fmaxf(__fdiv_rn(f, sx), qmin), qmax);
+            }
+            uint32_t q[2] = {0u, 0u};
+            if constexpr (QDT == GEMLITE_DT_INT8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e >> 2] |= (uint32_t)(uint8_t)(int8_t)floorf(t[e] + 0.5f) << (8 * (e & 3));
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int w = 0;
+                    if constexpr (QDT == GEMLITE_DT_FP8E4) {
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * h], t[4 * h + 1], w, false);
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * h + 2], t[4 * h + 3], w, true);
+                    } else {
+                        w = __builtin_amdgcn_cvt_pk_bf8_f32(t[4 * h], t[4 * h + 1], w, false);
+                        w = __builtin_amdgcn_cvt_pk_bf8_f32(t[4 * h + 2], t[4 * h + 3], w, true);
+                    }
+                    q[h] = (uint32_t)w;
+                }
+            }
+            *(u32x2*)(smem + k) = (u32x2){q[0], q[1]};
+        }
+        __syncthreads();
+        xq = smem;
+    } else {
+        xq = (const uint8_t*)p.x;
+    }
+
+    float accf = 0.f;
+    int acci = 0;
+    auto consume = [&](u32x4 w, int j) __attribute__((always_inline)) {
+        const u32x4 xv = *(const u32x4*)(xq + (j << 10) + lane * 16);
+        if constexpr (QDT == GEMLITE_DT_INT8) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) acci = __builtin_amdgcn_sdot4((int)xv[qd], (int)w[qd], acci, false);
+        } else {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                float xf[4], wf[4];
+                fp8x4_to_f32(xv[qd], QDT != GEMLITE_DT_FP8E4, xf);
+                fp8x4_to_f32(w[qd], QDT != GEMLITE_DT_FP8E4, wf);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) accf = __builtin_fmaf(xf[b], wf[b], accf);
+            }
+        }
+    };
+    for (int base = 0; base < npieces; base += B) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (base + j < npieces) {
+                const u32x4 w = wv[j];
+                if (base + j + B < npieces) wv[j] = __builtin_nontemporal_load((const u32x4*)(wcol + ((base + j + B) << 10) + lane * 16));
+                consume(w, base + j);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        accf += __shfl_xor(accf, off);
+        acci += __shfl_xor(acci, off);
+    }
+    if (lane == 0) {
+        float v = QDT == GEMLITE_DT_INT8 ? (float)acci : accf;
+        if constexpr (FUSED) {  // same arithmetic as epilogue_scale(): acc * (s_x * s_w[n]) for mode 3, acc * s_x for mode 2
+            if (p.epi.c_mode == 3) v *= sx * load_as_float(p.epi.scales_w, n, p.epi.meta_dt);
+            else v *= sx;
+            store_from_float(p.epi.out, n * p.epi.stride_on, p.epi.out_dt, v);
+        } else {
+            epilogue_store(p.epi, v, 0, n);
+        }
+    }
+}
+const void* a8w8_decode_kernel_fn(int qdt, bool fused) {
+    typedef void (*fn_t)(const GenericParams);
+    fn_t f = nullptr;
+    if (qdt == GEMLITE_DT_INT8) f = fused ? a8w8_decode_kernel<GEMLITE_DT_INT8, true> : a8w8_decode_kernel<GEMLITE_DT_INT8, false>;
+    else if (qdt == GEMLITE_DT_FP8E4) f = fused ? a8w8_decode_kernel<GEMLITE_DT_FP8E4, true> : a8w8_decode_kernel<GEMLITE_DT_FP8E4, false>;
+    else if (qdt == GEMLITE_DT_FP8E5) f = fused ? a8w8_decode_kernel<GEMLITE_DT_FP8E5, true> : a8w8_decode_kernel<GEMLITE_DT_FP8E5, false>;
+    return (const void*)f;
+}
+
 const void* kmajor_fused_quant_kernel_fn(int qdt) {
     return qdt == GEMLITE_DT_INT8 ? (const void*)kmajor_fused_quant_kernel<GEMLITE_DT_INT8>
            : (qdt == GEMLITE_DT_FP8E4 ? (const void*)kmajor_fused_quant_kernel<GEMLITE_DT_FP8E4>

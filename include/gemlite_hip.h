@@ -186,7 +186,8 @@ typedef struct gemlite_hip_forward_args {
      *                              fallback for K % 256 != 0), 4 = the 16-column few-row kernel (default for 2..64 rows while
      *                              M K N / 16 <= 88 MiB) at any M <= 64 and at M = 1, 5 = the unsplit 64 x 64 tiles of round 4
      *                              (default from 65 rows where they fill the chip once or twice; [2] = 2/3/4 LDS stages),
-     *                              6 = the round-3 kernels instead
+     *                              6 = the round-3 kernels instead; M = 1: 7 = the round-2 streaming kernels instead of
+     *                              a8w8_decode_kernel, 8 = a8w8_decode_kernel also for fp8 with N > 4096
      *                              [1] K slices   [2] tile rows / 32 (forces the 8-wave kernels at any M)
      *                              [3] & 64: 128- / 256-row tiles with the weights straight from memory (default: through LDS)
      *                              [3] & 32768: test switch of the in-launch activation quantisation (no producer block runs)

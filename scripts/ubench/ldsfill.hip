@@ -36,8 +36,16 @@ template <int PAT, int D>
 __global__ __launch_bounds__(512, 1) void k_fill(const unsigned char* shared_rows, const unsigned char* own_rows, int rowbytes, uint32_t* sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const srd_t rsS = make_srd(shared_rows, (uint32_t)(64 * rowbytes));
-    const srd_t rsO = make_srd(own_rows + (size_t)blockIdx.x * 64 * rowbytes, (uint32_t)(64 * rowbytes));
+    // PAT 3 = the unsplit 64 x 64 tile kernels' real sharing: 4 row tiles of x (each read by 64 blocks) and 64 weight column tiles (each
+    // read by the 4 blocks of one XCD, back to back in its dispatch order: block b runs on XCD b % 8), pieces alternating like PAT 2
+    int st = 0, ot = blockIdx.x;
+    if (PAT == 3) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        st = idx % 4;
+        ot = (idx / 4) * 8 + xcd;
+    }
+    const srd_t rsS = make_srd(shared_rows + (size_t)st * 64 * rowbytes, (uint32_t)(64 * rowbytes));
+    const srd_t rsO = make_srd(own_rows + (size_t)ot * 64 * rowbytes, (uint32_t)(64 * rowbytes));
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem + (uint32_t)(wave * D) * 1024u;
     // piece p of this wave: rows wave * 8 + 4 (p & 1) + lane / 16, 16-byte slot lane % 16 of the 256-byte column step p >> 1
     const uint32_t voff0 = (uint32_t)((wave * 8 + (lane >> 4)) * rowbytes + (lane & 15) * 16);
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(512, 1) void k_fill(const unsigned char* shared_row
     for (int p = 0; p < npieces; ++p) {
         const uint32_t voff = voff0 + (uint32_t)((p & 1) * 4 * rowbytes);
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((p >> 1) * 256);
-        const bool own = PAT == 1 || (PAT == 2 && (p & 2));
+        const bool own = PAT == 1 || (PAT >= 2 && (p & 2));
         req_lds16(own ? rsO : rsS, lds0 + (uint32_t)(p % D) * 1024u, voff, soff);
         if (++issued >= D) wait_vm<D - 1>();
     }
@@ -93,10 +101,10 @@ int main(int argc, char** argv) {
     const int rowbytes = argc > 1 ? atoi(argv[1]) : 8192, reps = argc > 2 ? atoi(argv[2]) : 20;
     const int blocks = 256;
     unsigned char *sh, *own; uint32_t* sink;
-    CHECK(hipMalloc(&sh, (size_t)64 * rowbytes));
+    CHECK(hipMalloc(&sh, (size_t)256 * rowbytes));
     CHECK(hipMalloc(&own, (size_t)blocks * 64 * rowbytes));
     CHECK(hipMalloc(&sink, 64));
-    CHECK(hipMemset(sh, 1, (size_t)64 * rowbytes)); CHECK(hipMemset(own, 2, (size_t)blocks * 64 * rowbytes));
+    CHECK(hipMemset(sh, 1, (size_t)256 * rowbytes)); CHECK(hipMemset(own, 2, (size_t)blocks * 64 * rowbytes));
     const double bytes_per_block = 64.0 * rowbytes;
     printf("256 blocks x 8 waves, %d bytes per row, 64 rows per block = %.0f KB per block\n", rowbytes, bytes_per_block / 1024);
 #define RUN(KERN, PAT, D, LDS, NAME) { \
@@ -107,6 +115,7 @@ int main(int argc, char** argv) {
     RUN(k_fill, 0, 2, 16384, "lds-dma") RUN(k_fill, 0, 4, 32768, "lds-dma") RUN(k_fill, 0, 8, 65536, "lds-dma") RUN(k_fill, 0, 16, 131072, "lds-dma")
     RUN(k_fill, 1, 2, 16384, "lds-dma") RUN(k_fill, 1, 4, 32768, "lds-dma") RUN(k_fill, 1, 8, 65536, "lds-dma") RUN(k_fill, 1, 16, 131072, "lds-dma")
     RUN(k_fill, 2, 4, 32768, "lds-dma") RUN(k_fill, 2, 8, 65536, "lds-dma") RUN(k_fill, 2, 16, 131072, "lds-dma")
+    RUN(k_fill, 3, 4, 32768, "lds-dma") RUN(k_fill, 3, 8, 65536, "lds-dma") RUN(k_fill, 3, 12, 98304, "lds-dma") RUN(k_fill, 3, 16, 131072, "lds-dma")
     RUN(k_regs, 0, 4, 0, "registers") RUN(k_regs, 0, 8, 0, "registers") RUN(k_regs, 0, 16, 0, "registers")
     RUN(k_regs, 1, 4, 0, "registers") RUN(k_regs, 1, 8, 0, "registers") RUN(k_regs, 1, 16, 0, "registers")
     return 0;

@@ -964,6 +964,46 @@ def test_fused_activation_quant_at_m1_is_bit_identical_to_the_two_launch_path(ki
     _compare(f"fused-quant/{kind}", lin(x), y_or, 1, abs_gate=5e-3)
 
 
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+def test_a8w8_decode_kernel_against_the_round2_kernels_and_the_oracle(kind):
+    """a8w8_decode_kernel (round 4: one wave per column, the weight row requested before anything else; FUSED form quantises x under that
+    round trip): K below / at / above one batch of pieces (2048 / 8192 / 16384), fp16 and bf16 activations — int8 bit-identical to the
+    round-2 kernels (tuning[0] = 7) and to the two-launch path, fp8 within the fp32 summation-order tolerance; both against the oracle."""
+    from gemlite_amd import core
+    from gemlite_amd.core import _hip_matmul
+    torch.manual_seed(37)
+    qdt = torch.int8 if kind == "int8" else torch.float8_e4m3fn
+    for N, K, tdt in ((1024, 2048, torch.float16), (512, 8192, torch.bfloat16), (256, 16384, torch.float16), (8192, 1024, torch.float16)):
+        W = (torch.randn(N, K) / 30).to(tdt)
+        lin = (gemlite_amd.helper.A8W8_int8_dynamic if kind == "int8" else gemlite_amd.helper.A8W8_fp8_dynamic)(device=DEV, dtype=tdt).from_weights(W)
+        x = (torch.randn(1, K, device=DEV) / 10).to(tdt)
+        xq, sx = scale_activations_per_token(x, w_dtype=qdt)
+        a = core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
+        a.matmul_type, a.M, a.x, a.out = -1, 1, x.data_ptr(), 0x1000
+        a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = K, 1, N, 1
+        a.input_dtype = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+        new_default = kind == "int8" or N <= 4096  # fp8 above one round of tiles keeps the round-2 kernels (measured faster there)
+        assert _hip.load().gemlite_hip_kernel_name(_hip.C.byref(a)).decode() == ("a8w8_decode_fused_quant_kernel<tile16,16w>" if new_default else "kmajor_fused_quant_kernel")
+        if not new_default:
+            continue
+        y_fused = lin(x)                                                                               # new fused kernel
+        y_fused_old = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, (7, 0, 0, 0))   # round-2 fused kernel
+        y_two = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1)             # quantiser + new decode kernel
+        y_two_old = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, (7, 0, 0, 0))
+        torch.cuda.synchronize()
+        assert torch.equal(y_fused, y_two), (kind, N, K)
+        if kind == "int8":
+            assert torch.equal(y_fused, y_fused_old) and torch.equal(y_two, y_two_old), (kind, N, K)
+        else:
+            for other in (y_fused_old, y_two_old):
+                rel = float((y_fused.float() - other.float()).abs().mean() / other.float().abs().mean())
+                assert rel < 2e-3, (kind, N, K, rel)
+        code = O.INT8 if kind == "int8" else O.FP8E4
+        xq_o, sx_o = O.scale_activations_per_token(x, code)
+        y_or = (xq_o @ O.to_f64(lin.W_q.data)) * (sx_o.astype(np.float64) * O.to_f64(lin.scales.data).reshape(1, -1))
+        _compare(f"a8w8-decode/{kind}/{N}x{K}", y_fused, y_or, gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value, abs_gate=5e-3)
+
+
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("kind", ["int8", "fp8"])
 def test_cooperative_activation_quant_from_two_rows_is_bit_identical_to_the_two_launch_path(kind, tdt):

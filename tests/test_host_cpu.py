@@ -161,7 +161,9 @@ def test_struct_abi_and_validation():
     (dict(M=256, nbits=2), "gemm_w2_mma_kernel<64x64>"),
     (dict(M=256, N=16384, K=16384, nbits=2), "gemm_w2_mma_kernel<256x128>"),   # BASELINE config 5
     (dict(M=4, mt=3), "gemm_wn_direct_kernel<tile16>"),  # manual GEMM_SPLITK
-    (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "kmajor_matmul_kernel"),
+    (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_decode_kernel<tile16,16w>"),  # round 4: one wave per column, the row in flight at once
+    (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(7, 0, 0, 0)), "kmajor_matmul_kernel"),
+    (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, K=4096 + 512), "kmajor_matmul_kernel"),  # K % 1024 != 0
     (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),  # A8W8 int8, 2..16 rows: 16-column blocks
     (dict(M=2, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),
     (dict(M=17, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<32x16>"),  # round 3: 2 / 4 row tiles while the x re-reads stay < 88 MB
@@ -712,7 +714,9 @@ def test_in_launch_activation_quantisation_is_planned_from_two_rows_and_says_whe
         a.scales_x = None
         return lib.gemlite_hip_query(C.byref(a)), lib.gemlite_hip_kernel_name(C.byref(a)).decode(), int(lib.gemlite_hip_workspace_bytes(C.byref(a)))
 
-    assert ask(1)[:2] == (0, "kmajor_fused_quant_kernel")
+    assert ask(1)[:2] == (0, "a8w8_decode_fused_quant_kernel<tile16,16w>")
+    assert ask(1, tuning=(7, 0, 0, 0))[:2] == (0, "kmajor_fused_quant_kernel")  # the round-2 kernel (quantises before it asks for weights)
+    assert ask(1, K=4096 + 512)[:2] == (0, "kmajor_fused_quant_kernel")         # K % 1024 != 0
     for w in (4, 3):  # int8, fp8 e4m3
         assert ask(2, w=w)[:2] == (0, "a8w8_rows_fq_kernel<16x16>")
         assert ask(17, w=w)[:2] == (0, "a8w8_rows_fq_kernel<32x16>")
