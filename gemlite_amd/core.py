@@ -376,6 +376,21 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
                  x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0 and K_ % 16 == 0 and K_ <= 65536 and
                  W_q.stride(0) == 1 and W_q.stride(1) % 16 == 0 and W_q.data_ptr() % 16 == 0 and
                  (x.is_contiguous() and x.data_ptr() % 16 == 0))
+        if not fused and FUSE_ACT_QUANT_M1 and x.numel() == K_ and meta_args[4] > 1 and matmul_type < 0 and TUNING_OVERRIDE is None and \
+                x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.data_ptr() % 16 == 0:
+            # one row against PACKED weights (A8W4 / A8W2 fp8 dynamic, BitNet int8 dynamic): the decode kernel quantises the row itself
+            # (round 4); where the library has no such kernel for the shape it says so once and the answer is remembered
+            x2f = x if x.dim() == 2 else x.view(-1, K_)
+            fkey = (W_q.shape[1], K_, in_code, meta_args[1], x.dtype, 1, x.device.index)
+            if fkey not in _NO_FUSED_QUANT:
+                out = _hip_matmul(x2f, W_q, scales, zeros, None, meta_args, matmul_type, fused_quant_optional=True)
+                if out is not None:
+                    if len(out_shape) != 2:
+                        out = out.view(out_shape)
+                    if bias is not None:
+                        out += bias
+                    return out
+                _NO_FUSED_QUANT.add(fkey)
         if not fused and FUSE_ACT_QUANT_ROWS and x.numel() > K_ and meta_args[4] == 1 and meta_args[10] == 0 and \
                 x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0 and TUNING_OVERRIDE is None and x.is_contiguous():
             # 2 <= M: ONE launch where the library has a kernel whose blocks quantise the rows among themselves (same arithmetic,

@@ -18,12 +18,13 @@ namespace gl {
 // planners (defined next to their kernels)
 bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
-bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, bool fq = false);
 bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq = false);
+bool plan_a16w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
@@ -98,6 +99,16 @@ static bool wants_fused_quant(const gemlite_hip_forward_args* a) {
            (a->w_dtype == GEMLITE_DT_INT8 || a->w_dtype == GEMLITE_DT_FP8E4 || a->w_dtype == GEMLITE_DT_FP8E5);
 }
 
+// The same request for PACKED weights (A8Wn fp8 dynamic, BitNet int8 dynamic; round 4, M = 1): the layer's activation type rides in
+// type_id (= input_dtype * 100 + W_nbits, core.py:141-145), x is the unquantised 16-bit row.
+static int fused_quant_packed_dtype(const gemlite_hip_forward_args* a) {
+    if (a->M != 1 || a->elements_per_sample <= 1 || a->scales_x) return 0;
+    if (!(a->channel_scale_mode == 2 || a->channel_scale_mode == 3)) return 0;
+    if (!(a->input_dtype == GEMLITE_DT_FP16 || a->input_dtype == GEMLITE_DT_BF16)) return 0;
+    const int layer_dt = a->type_id / 100;
+    return (layer_dt == GEMLITE_DT_FP8E4 || layer_dt == GEMLITE_DT_INT8) && a->type_id % 100 == a->W_nbits ? layer_dt : 0;
+}
+
 static bool is_mx_input(int dt) { return dt >= GEMLITE_DT_MXFP16 && dt <= GEMLITE_DT_NVFP4; }
 
 // block-scaled formats (see the header): what must hold before any kernel is chosen
@@ -139,7 +150,7 @@ static int validate(const gemlite_hip_forward_args* a) {
     const bool need_z = a->W_group_mode == 1 || a->W_group_mode >= 3;
     if (need_s && !a->scales) return GEMLITE_ERR_BAD_ARGUMENT;
     if (need_z && !a->zeros) return GEMLITE_ERR_BAD_ARGUMENT;
-    if ((a->channel_scale_mode == 2 || a->channel_scale_mode == 3) && !a->scales_x && !wants_fused_quant(a)) return GEMLITE_ERR_BAD_ARGUMENT;
+    if ((a->channel_scale_mode == 2 || a->channel_scale_mode == 3) && !a->scales_x && !wants_fused_quant(a) && !fused_quant_packed_dtype(a)) return GEMLITE_ERR_BAD_ARGUMENT;
     if (a->elements_per_sample > 1) {
         if (a->w_pack_bits != 8 && a->w_pack_bits != 16 && a->w_pack_bits != 32 && a->w_pack_bits != 64)
             return GEMLITE_ERR_BAD_ARGUMENT;
@@ -255,6 +266,36 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
                                                         !(a.channel_scale_mode == 1 || a.channel_scale_mode == 3));
     const int eff_group = per_group_meta ? a.group_size : (int)a.K;
 
+    // ---- M = 1 of a dynamically quantised PACKED layer with the activation quantiser inside the launch (gemv_a8wn.hip) ---------------
+    if (const int qdt = fused_quant_packed_dtype(&a)) {
+        r.status = GEMLITE_ERR_NO_FUSED_QUANT;
+        if (a.tuning[0] != 0 || a.tuning[1] != 0 || a.tuning[2] != 0 || a.matmul_type != GEMLITE_MATMUL_AUTO) return;
+        if (a.stride_xk != 1 || ((uintptr_t)a.x % 16) != 0 || a.output_dtype != a.input_dtype || a.w_pack_bits != 32 || a.stride_wn != 1 || a.stride_on != 1) return;
+        const bool pgm = a.W_group_mode >= 2 || ((a.W_group_mode == 1) && !a.zero_is_scalar);
+        const int eg = pgm ? a.group_size : (int)a.K;
+        if (eg <= 0 || a.K % eg != 0 || (a.stride_meta_n != 1 && pgm)) return;
+        gemlite_hip_forward_args b = a;
+        b.input_dtype = qdt;
+        b.x = (const void*)(uintptr_t)0x1000;
+        b.scales_x = (const void*)(uintptr_t)0x1000;
+        b.stride_xm = a.K;
+        WnParams p{};
+        p.x = a.x; p.w = (const uint32_t*)a.w_q; p.scales = a.scales; p.zeros = a.zeros;
+        p.epi = make_epilogue(a);
+        p.M = 1; p.N = (int)a.N; p.K = (int)a.K;
+        p.group_size = eg;
+        p.w_mode = a.W_group_mode;
+        p.meta_dt = a.meta_dtype; p.zeros_dt = a.zeros_dtype; p.zero_is_scalar = a.zero_is_scalar;
+        p.stride_xm = a.K; p.stride_xk = 1; p.stride_wk = a.stride_wk;
+        p.stride_meta_g = (pgm && eg < a.K) ? a.stride_meta_g : 0;
+        p.flags = a.tuning[3];
+        p.gs_shift = eg >= a.K ? 31 : ((eg & (eg - 1)) == 0 ? __builtin_ctz((unsigned)eg) : -1);
+        LaunchPlan lp{};
+        if (p.gs_shift < 0 || !plan_gemv_a8wn(b, p, lp, true)) return;
+        r.status = GEMLITE_OK;
+        r.kind = K_GEMV_WN; r.wn = p; r.lp = lp;
+        return;
+    }
     // ---- specialised packed-weight kernels ---------------------------------------------------------
     const bool x8 = a.input_dtype == GEMLITE_DT_FP8E4 || a.input_dtype == GEMLITE_DT_INT8;  // A8Wn dynamic / BitNet int8
     if (packed && a.w_pack_bits == 32 && (x16 || x8) && a.stride_wn == 1 && a.stride_xk == 1 && a.stride_on == 1 &&
@@ -446,8 +487,10 @@ coverage:
         a.stride_xk == 1 && (a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_BF16) &&
         (a.w_dtype == GEMLITE_DT_INT8 || a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5) &&
         a.K % 16 == 0 && a.stride_wn % 16 == 0 && (a.stride_xm * 2) % 16 == 0 && (((uintptr_t)a.w_q | (uintptr_t)a.x) % 16 == 0)) {
-        const int mb = a.M == 1 ? 1 : 4;
         r.kind = K_KMAJOR;
+        // round 4: 16-column blocks, weights converted in registers, MFMA (tuning[0] = 7 keeps the streaming kernel of rounds 1-3)
+        if (a.tuning[0] != 7 && plan_a16w8_rows(a, r.lp)) return;
+        const int mb = a.M == 1 ? 1 : 4;
         r.lp.fn = kmajor_w8a16_kernel_fn(mb);
         r.lp.name = "kmajor_w8a16_kernel";
         r.lp.grid = dim3((unsigned)((a.N + 3) / 4), (unsigned)((a.M + mb - 1) / mb), 1);

@@ -1089,4 +1089,157 @@ bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq) 
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// A16W8 (round 4): 8-bit weight-only layers — int8 / fp8 unpacked K-contiguous weights under fp16 / bf16 activations, no metadata or one
+// scale per output channel (helper.py:88-171; the reference runs them through its GEMV / GEMM_SPLITK / GEMM kernels with W_nbits = 8).
+// Rounds 1-3 had one kernel for them, kmajor_w8a16_kernel: a wave per column, 4 rows of x per pass, the weights re-streamed for every
+// 4 rows — 9.2 us at 4096^2 M = 1, 36.6 us at M = 16 (profiles/r04/probe_processors.log).  This is a8w8_rows_kernel's shape with the
+// weights converted in registers: block = 16 output columns x all of K, 8 waves dealing 64-k chunks, lane (c = lane & 15, q = lane >> 4)
+// loads the 16 weight bytes k = 16 q .. 16 q + 15 of column c and, per 16-row tile, the 32 bytes of x that face them; a chunk is two
+// v_mfma_f32_16x16x32_{f16,bf16} per row tile (k = 16 q + j and 16 q + 8 + j: any k assignment works as long as both operands use it).
+// int8 -> fp16: 0x6400 | (b ^ 0x80) = 1024 + (b + 128) exactly, minus 1152 (packed); int8 -> bf16 and fp8 -> either: hardware converters.
+// The channel scale multiplies the fp32 sum once (pre-scale: a per-column constant; post-scale: the reference's epilogue).  More than 64
+// rows: 64-row tiles along grid.y (weights re-read from L2 per tile) until a tile kernel takes these layers.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename Tag, int WDT, int MT>
+__global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) {
+    using TR = F16Traits<Tag>;
+    __shared__ __attribute__((aligned(16))) float red[MT][8][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const int mbase = (int)blockIdx.y * (16 * MT);
+    const int nchunks = p.K / 64;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + p.K), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)(((int64_t)(p.M - 1) * p.stride_xm + p.K) * 2), 0x00020000);
+    const uint32_t wvoff = (uint32_t)((n0 + c) * p.stride_wn + q * 16);
+    uint32_t xvoff[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = mbase + c + 16 * t;
+        xvoff[t] = m < p.M ? (uint32_t)(((int64_t)m * p.stride_xm + q * 16) * 2) : 0x80000000u;  // rows >= M: zeros
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int D = MT == 1 ? 8 : (MT == 2 ? 4 : 2);  // chunks in flight per wave (16 + 32 MT bytes per lane each; 8 = all of K = 4096)
+    u32x4 wb[D], xb[D][MT][2];
+    const int mine = (nchunks - wave + 7) >> 3;  // chunks wave, wave + 8, ...
+    auto load = [&](int slot, int i) __attribute__((always_inline)) {
+        const int ch = wave + 8 * i;
+        wb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane(ch * 64), 0);
+        const uint32_t xo = (uint32_t)__builtin_amdgcn_readfirstlane(ch * 128);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            xb[slot][t][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], xo, 0);
+            xb[slot][t][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], xo + 16u, 0);
+        }
+    };
+    // 8 weight bytes (two dwords) -> one B fragment: 8 values of the activation type
+    auto convert = [&](uint32_t lo, uint32_t hi) __attribute__((always_inline)) -> u32x4 {
+        u32x4 f;
+        const uint32_t d[2] = {lo, hi};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (WDT == GEMLITE_DT_INT8) {
+                if constexpr (TR::DT == GEMLITE_DT_FP16) {
+                    const uint32_t u = d[h] ^ 0x80808080u;  // b + 128 as an unsigned byte
+                    const h2_t off = {(_Float16)1152.0f, (_Float16)1152.0f};
+                    // {0x64, u.b1, 0x64, u.b0} / {0x64, u.b3, 0x64, u.b2}: 1024 + (b + 128)
+                    const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, u, 0x04010400u), p1 = __builtin_amdgcn_perm(0x64646464u, u, 0x04030402u);
+                    f[2 * h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2_t, p0) - off);
+                    f[2 * h + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2_t, p1) - off);
+                } else {
+                    const int v = (int)d[h];
+                    const b2_t a = {(__bf16)(float)(int8_t)(v & 0xFF), (__bf16)(float)(int8_t)((v >> 8) & 0xFF)};
+                    const b2_t b = {(__bf16)(float)(int8_t)((v >> 16) & 0xFF), (__bf16)(float)(int8_t)((v >> 24) & 0xFF)};
+                    f[2 * h] = __builtin_bit_cast(uint32_t, a);
+                    f[2 * h + 1] = __builtin_bit_cast(uint32_t, b);
+                }
+            } else {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                constexpr bool E5 = WDT == GEMLITE_DT_FP8E5;
+                const f32x2 a = E5 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)d[h], false) : __builtin_amdgcn_cvt_pk_f32_fp8((int)d[h], false);
+                const f32x2 b = E5 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)d[h], true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)d[h], true);
+                f[2 * h] = (uint32_t)TR::from_float(a[0]) | ((uint32_t)TR::from_float(a[1]) << 16);
+                f[2 * h + 1] = (uint32_t)TR::from_float(b[0]) | ((uint32_t)TR::from_float(b[1]) << 16);
+            }
+        }
+        return f;
+    };
+    auto mma = [&](int slot) __attribute__((always_inline)) {
+        const u32x4 b0 = convert(wb[slot][0], wb[slot][1]), b1 = convert(wb[slot][2], wb[slot][3]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            if constexpr (TR::DT == GEMLITE_DT_FP16) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, xb[slot][t][0]), __builtin_bit_cast(h8_t, b0), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, xb[slot][t][1]), __builtin_bit_cast(h8_t, b1), acc[t], 0, 0, 0);
+            } else {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8_t, xb[slot][t][0]), __builtin_bit_cast(b8_t, b0), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8_t, xb[slot][t][1]), __builtin_bit_cast(b8_t, b1), acc[t], 0, 0, 0);
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        if (j < mine) load(j, j);
+    for (int base = 0; base < mine; base += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (base + j < mine) {
+                mma(j);
+                if (base + j + D < mine) load(j, base + j + D);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *(f32x4*)&red[t][wave][lane][0] = acc[t];
+    __syncthreads();
+    for (int u = tid; u < MT * 256; u += 512) {
+        const int t = u >> 8, l = u & 63, r = (u >> 6) & 3;
+        const int m = mbase + 16 * t + 4 * (l >> 4) + r;  // C fragment of a 16 x 16 MFMA: column lane & 15, rows 4 (lane >> 4) + r
+        const int64_t n = n0 + (l & 15);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[t][w][l][r];
+        if (m < p.M) {
+            const float sc = p.w_mode == 2 ? load_as_float(p.scales, n, p.meta_dt) : 1.f;  // per-channel pre-scale: once, on the sum
+            epilogue_store(p.epi, v * sc, m, n);
+        }
+    }
+}
+
+bool plan_a16w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
+    if (a.elements_per_sample != 1 || a.M < 1 || a.M > 65535 * 64) return false;
+    if (!(a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_BF16)) return false;
+    if (!(a.w_dtype == GEMLITE_DT_INT8 || a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5)) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.N % 16 != 0 || a.K % 64 != 0) return false;
+    if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || (a.stride_xm * 2) % 16 != 0 || a.stride_wn % 16 != 0) return false;
+    if (((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31) || (int64_t)a.N * a.stride_wn + a.K >= (1ll << 31)) return false;
+    const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    typedef void (*fn_t)(const GenericParams);
+    fn_t fn = nullptr;
+    auto pick = [&](auto tag, auto wdt) -> fn_t {
+        using T = decltype(tag);
+        constexpr int W = decltype(wdt)::value;
+        return mt == 1 ? a16w8_rows_kernel<T, W, 1> : (mt == 2 ? a16w8_rows_kernel<T, W, 2> : a16w8_rows_kernel<T, W, 4>);
+    };
+    typedef std::integral_constant<int, GEMLITE_DT_INT8> I8;
+    typedef std::integral_constant<int, GEMLITE_DT_FP8E4> F8;
+    typedef std::integral_constant<int, GEMLITE_DT_FP8E5> B8;
+    const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
+    if (a.w_dtype == GEMLITE_DT_INT8) fn = f16 ? pick(half_tag{}, I8{}) : pick(bf16_tag{}, I8{});
+    else if (a.w_dtype == GEMLITE_DT_FP8E4) fn = f16 ? pick(half_tag{}, F8{}) : pick(bf16_tag{}, F8{});
+    else fn = f16 ? pick(half_tag{}, B8{}) : pick(bf16_tag{}, B8{});
+    lp.fn = (const void*)fn;
+    lp.name = mt == 1 ? "a16w8_rows_kernel<16x16>" : (mt == 2 ? "a16w8_rows_kernel<32x16>" : "a16w8_rows_kernel<64x16>");
+    lp.grid = dim3((unsigned)(a.N / 16), (unsigned)((a.M + 16 * mt - 1) / (16 * mt)), 1);
+    lp.block = dim3(512, 1, 1);
+    lp.lds_bytes = 0;
+    lp.ws_bytes = 0;
+    lp.slab_bytes = 0;
+    return true;
+}
+
 }  // namespace gl

@@ -44,8 +44,15 @@ struct Codes<2> {
 
 }  // namespace a8
 
-template <typename Tag, int NBITS, int XDT, int MB>
+// FQ (round 4, MB = 1): the launch takes the UNQUANTISED 16-bit row of x and quantises it per token itself — both of a wave's weight
+// requests go out first, then the block computes amax / the scale and writes the quantised row into LDS under that round trip (same
+// arithmetic as act_quant_per_token_kernel: bit-identical to quantiser + this kernel), reads x from LDS instead of L2 and applies the
+// row scale in its epilogue.  layer(x) of A8W4 / A8W2 fp8-dynamic and BitNet int8-dynamic at M = 1: one launch instead of two
+// (10.4 / 9.2 / 8.5 us -> see profiles/r04/probe_processors*.log).
+template <typename Tag, int NBITS, int XDT, int MB, bool FQ = false>
 __global__ __launch_bounds__(1024) void gemv_a8wn_kernel(const WnParams p) {
+    static_assert(!FQ || MB == 1, "in-launch activation quantisation: one row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char xq_lds[];  // FQ: [K] quantised x, then 16 floats
     using TR = F16Traits<Tag>;
     using CD = a8::Codes<NBITS>;
     constexpr bool INT = XDT == GEMLITE_DT_INT8;
@@ -79,6 +86,10 @@ __global__ __launch_bounds__(1024) void gemv_a8wn_kernel(const WnParams p) {
         const int64_t mg = (int64_t)(((int64_t)row * E) >> p.gs_shift) * p.stride_meta_g + n0;
         if (need_s) q.s = *(const u32x2*)((const uint16_t*)p.scales + mg);
         if (need_z) q.z = *(const u32x2*)((const uint16_t*)p.zeros + mg);
+        if constexpr (FQ) {  // x comes from LDS at consume time
+            q.x[0][0] = (uint32_t)row;
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             const uint8_t* xr = xb + (int64_t)(m < p.M ? m : 0) * p.stride_xm + (int64_t)row * XB;
@@ -100,7 +111,13 @@ __global__ __launch_bounds__(1024) void gemv_a8wn_kernel(const WnParams p) {
             uint32_t xe[MB], xo[MB];
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
-                const uint32_t lo = q.x[m][2 * t], hi = q.x[m][2 * t + 1];
+                uint32_t lo, hi;
+                if constexpr (FQ) {
+                    const u32x2 v = *(const u32x2*)(xq_lds + (size_t)q.x[0][0] * XB + 8 * t);
+                    lo = v[0]; hi = v[1];
+                } else {
+                    lo = q.x[m][2 * t]; hi = q.x[m][2 * t + 1];
+                }
                 if (INT) {  // even / odd k, like the weight codes
                     xe[m] = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
                     xo[m] = __builtin_amdgcn_perm(hi, lo, 0x07050301u);
@@ -160,9 +177,50 @@ __global__ __launch_bounds__(1024) void gemv_a8wn_kernel(const WnParams p) {
     qa.s = qa.z = qb.s = qb.z = (u32x2){0, 0};
     int g = wave;
     if (g < ngroups) request(qa, g);
+    float sx_row = 1.f;
+    if constexpr (FQ) {
+        if (g + NW < ngroups) request(qb, g + NW);  // both of the wave's first requests are out before x is touched
+        float* wmax = (float*)(xq_lds + p.K);
+        const uint16_t* xr = (const uint16_t*)p.x;
+        float amax = 0.f;
+        for (int k = tid * 8; k < p.K; k += 1024 * 8) {
+            const u32x4 v = *(const u32x4*)(xr + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(TR::to_float((uint16_t)(v[e >> 1] >> (16 * (e & 1))))));
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if (lane == 0) wmax[wave] = amax;
+        __syncthreads();
+        amax = wmax[lane & 15];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        constexpr float qmin = INT ? -128.f : -448.f, qmax = INT ? 127.f : 448.f;
+        sx_row = fmaxf(__fdiv_rn(amax, qmax), 1e-6f);
+        for (int k = tid * 8; k < p.K; k += 1024 * 8) {
+            const u32x4 v = *(const u32x4*)(xr + k);
+            float tq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tq[e] = fminf(fmaxf(__fdiv_rn(TR::to_float((uint16_t)(v[e >> 1] >> (16 * (e & 1)))), sx_row), qmin), qmax);
+            uint32_t o[2] = {0u, 0u};
+            if constexpr (INT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e >> 2] |= (uint32_t)(uint8_t)(int8_t)floorf(tq[e] + 0.5f) << (8 * (e & 3));
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int w = __builtin_amdgcn_cvt_pk_fp8_f32(tq[4 * h], tq[4 * h + 1], 0, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(tq[4 * h + 2], tq[4 * h + 3], w, true);
+                    o[h] = (uint32_t)w;
+                }
+            }
+            *(u32x2*)(xq_lds + k) = (u32x2){o[0], o[1]};
+        }
+        __syncthreads();
+    }
     for (; g < ngroups; g += 2 * NW) {
         const bool more = g + NW < ngroups;
-        if (more) request(qb, g + NW);
+        if (more && !(FQ && g == wave)) request(qb, g + NW);
         consume(qa);
         if (more) {
             if (g + 2 * NW < ngroups) request(qa, g + 2 * NW);
@@ -193,7 +251,14 @@ __global__ __launch_bounds__(1024) void gemv_a8wn_kernel(const WnParams p) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[w][m][c];
-        if (m < p.M) epilogue_store(p.epi, v, m, (int64_t)blockIdx.x * 16 + c);
+        if constexpr (FQ) {  // same arithmetic as epilogue_scale(): acc * (s_x * s_w[n]) for mode 3, acc * s_x for mode 2
+            const int64_t n = (int64_t)blockIdx.x * 16 + c;
+            if (p.epi.c_mode == 3) v *= sx_row * load_as_float(p.epi.scales_w, n, p.epi.meta_dt);
+            else v *= sx_row;
+            store_from_float(p.epi.out, n * p.epi.stride_on, p.epi.out_dt, v);
+        } else {
+            if (m < p.M) epilogue_store(p.epi, v, m, (int64_t)blockIdx.x * 16 + c);
+        }
     }
 }
 
@@ -203,6 +268,7 @@ template <typename Tag, int NBITS, int XDT>
 static const void* a8wn_pick_mb(int mb) {
     a8wn_kernel_fn f = nullptr;
     switch (mb) {
+        case -1: f = gemv_a8wn_kernel<Tag, NBITS, XDT, 1, true>; break;  // one row, activation quantiser inside
         case 1: f = gemv_a8wn_kernel<Tag, NBITS, XDT, 1>; break;
         case 2: f = gemv_a8wn_kernel<Tag, NBITS, XDT, 2>; break;
         case 4: f = gemv_a8wn_kernel<Tag, NBITS, XDT, 4>; break;
@@ -216,7 +282,9 @@ static const void* a8wn_pick(int nbits, int xdt, int mb) {
     return nbits == 4 ? a8wn_pick_mb<Tag, 4, GEMLITE_DT_INT8>(mb) : a8wn_pick_mb<Tag, 2, GEMLITE_DT_INT8>(mb);
 }
 
-bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
+// fq: `a` describes the call AS THE MATMUL SEES IT (8-bit input dtype, placeholder x / scales_x); the launch gets the raw 16-bit row
+bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, bool fq) {
+    if (fq && (a.M != 1 || a.K > 61440 || a.K % 8 != 0)) return false;
     const int nbits = a.W_nbits;
     if (nbits != 4 && nbits != 2) return false;
     if (a.M < 1 || a.M > 4) return false;
@@ -236,17 +304,18 @@ bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& 
     if (((uintptr_t)a.x % 16) != 0 || (a.stride_xm % 16) != 0) return false;
     if ((loop_s && ((uintptr_t)a.scales % 8) != 0) || (has_z && !a.zero_is_scalar && ((uintptr_t)a.zeros % 8) != 0)) return false;
     if ((loop_s || (has_z && !a.zero_is_scalar)) && p.stride_meta_g % 4 != 0) return false;
-    const int mb = a.M == 1 ? 1 : (a.M == 2 ? 2 : 4);
+    const int mb = fq ? -1 : (a.M == 1 ? 1 : (a.M == 2 ? 2 : 4));
     const void* fn = a.output_dtype == GEMLITE_DT_FP16 ? a8wn_pick<half_tag>(nbits, a.input_dtype, mb)
                                                        : a8wn_pick<bf16_tag>(nbits, a.input_dtype, mb);
     if (!fn) return false;
     p.splitk = 1;
     p.rows_per_slice = (int)(a.K / e);
     lp.fn = fn;
-    lp.name = nbits == 4 ? "gemv_a8w4_kernel<tile16,16w>" : "gemv_a8w2_kernel<tile16,16w>";
+    lp.name = fq ? (nbits == 4 ? "gemv_a8w4_fused_quant_kernel<tile16,16w>" : "gemv_a8w2_fused_quant_kernel<tile16,16w>")
+                 : (nbits == 4 ? "gemv_a8w4_kernel<tile16,16w>" : "gemv_a8w2_kernel<tile16,16w>");
     lp.grid = dim3((unsigned)(a.N / 16), 1, 1);
     lp.block = dim3(1024, 1, 1);
-    lp.lds_bytes = 0;
+    lp.lds_bytes = fq ? (size_t)a.K + 64 : 0;
     lp.slab_bytes = 0;
     lp.ws_bytes = 0;
     return true;

@@ -665,16 +665,21 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
     const int e = 32 / nbits;
     if (a.M > 1 || a.K % e != 0) return false;  // M >= 2 goes to the MFMA streaming kernel (16-row tiles)
     if (a.output_dtype != a.input_dtype) return false;  // typed epilogue
-    const bool uses_s = a.W_group_mode >= 2 || a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    const bool loop_s = a.W_group_mode >= 2, post_s = a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    const bool uses_s = loop_s || post_s;
     const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
-    if (uses_s && a.meta_dtype != a.input_dtype) return false;
+    // metadata read in the K loop: the kernel's 16-bit type.  Channel scales of the epilogue alone (round 4: BitNet's fp32 scale,
+    // A16W158_INT — it ran on the 32-row MFMA tile at M = 1, 12.6 us at 4096^2): any float type (store_out_t)
+    if (loop_s && a.meta_dtype != a.input_dtype) return false;
+    if (post_s && !loop_s && a.meta_dtype != a.input_dtype && a.meta_dtype != GEMLITE_DT_FP32 && a.meta_dtype != GEMLITE_DT_FP16 && a.meta_dtype != GEMLITE_DT_BF16) return false;
     if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
     if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0 || a.K % 32 != 0) return false;  // 16-byte x loads
     // 16-byte weight loads and 8-byte metadata loads: sliced / offset views that break the alignment go to the
     // coverage kernel instead of faulting
     if (((uintptr_t)a.w_q % 16) != 0 || (a.stride_wk % 4) != 0) return false;
-    if ((uses_s && ((uintptr_t)a.scales % 8) != 0) || (has_z && !a.zero_is_scalar && ((uintptr_t)a.zeros % 8) != 0)) return false;
+    if ((loop_s && ((uintptr_t)a.scales % 8) != 0) || (has_z && !a.zero_is_scalar && ((uintptr_t)a.zeros % 8) != 0)) return false;
+    (void)uses_s;
     if (p.stride_meta_g % 4 != 0) return false;
     const int rows = (int)(a.K / e);
     const int64_t gs = p.group_size;

@@ -222,12 +222,14 @@ __device__ __forceinline__ f32x4 load4_t(const void* p, int64_t i) {  // 4 conse
 template <typename Tag>
 __device__ __forceinline__ void store_out_t(const Epilogue& e, float v, int64_t m, int64_t n) {
     using TR = F16Traits<Tag>;
+    // channel scales of the kernel's own 16-bit type, or (round 4: BitNet's fp32 scale, helper.py:173-208) any float type
+    auto sw = [&]() -> float { return e.meta_dt == TR::DT ? TR::to_float(((const uint16_t*)e.scales_w)[n]) : load_as_float(e.scales_w, n, e.meta_dt); };
     if (e.c_mode == 1) {
-        v *= TR::to_float(((const uint16_t*)e.scales_w)[n]);
+        v *= sw();
     } else if (e.c_mode == 2) {
         v *= e.scales_x[m * e.stride_sx_m];
     } else if (e.c_mode == 3) {
-        v *= e.scales_x[m * e.stride_sx_m] * TR::to_float(((const uint16_t*)e.scales_w)[n]);
+        v *= e.scales_x[m * e.stride_sx_m] * sw();
     }
     ((uint16_t*)e.out)[m * e.stride_om + n] = TR::from_float(v);
 }

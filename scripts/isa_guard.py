@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # Kernels known to spill when the guard was introduced (round 3) — fallback paths, none of them on a BASELINE configuration:
 # the round-1 LDS-staged streaming kernel (groups of 32, manual GEMM_SPLITK at 33..64 rows) and the 4-row form of the A8Wn decode
 # kernel (128 registers at 1024 threads).  Anything else with scratch or spills fails the build.
-KNOWN_SPILLERS = (r"gemm_wn_stream_kernel<", r"gemv_a8wn_kernel<gl::\w+, [24], \d+, 4>")
+KNOWN_SPILLERS = (r"gemm_wn_stream_kernel<", r"gemv_a8wn_kernel<gl::\w+, [24], \d+, 4(, false)?>")
 BUILD = os.path.join(ROOT, "gemlite_amd", "csrc", "build")
 
 

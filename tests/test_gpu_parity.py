@@ -664,7 +664,7 @@ def test_remaining_helper_processors_against_the_oracle(M):
                       ("a16w8-fp8", H.A16W8_FP8(device=DEV).from_weights(W))):
         y = lin(x)
         torch.cuda.synchronize()
-        assert _kernel_name(lin, x) == "kmajor_w8a16_kernel", _kernel_name(lin, x)
+        assert _kernel_name(lin, x).startswith("a16w8_rows_kernel"), _kernel_name(lin, x)
         _compare(f"helpers/{name}/M{M}", y, _oracle_from_layer(lin, x), 1, abs_gate=5e-3, extra=dict(kernel=_kernel_name(lin, x)))
     W_q, sc, zr = O.gen_data(N, K, 4, 128, seed=3)
     Wt = torch.randint(-1, 2, (N, K)).half()
@@ -690,7 +690,8 @@ def test_remaining_helper_processors_against_the_oracle(M):
     lin = H.A16W158_INT(device=DEV).from_weights(Wt, torch.tensor(0.02))
     y = lin(x)
     torch.cuda.synchronize()
-    assert _kernel_name(lin, x) == "gemm_w2_mma_kernel<32x128>", _kernel_name(lin, x)  # fp32 channel scale: untyped epilogue
+    # fp32 channel scale: at M = 1 the GEMV family (its epilogue reads any float scale type, round 4), above it the untyped epilogue of the tile kernel
+    assert _kernel_name(lin, x).startswith("gemv_wn_kernel<tile" if M == 1 else "gemm_w2_mma_kernel<32x128>"), _kernel_name(lin, x)
     _compare(f"helpers/a16w158/M{M}", y, _oracle_from_layer(lin, x), 1, extra=dict(kernel=_kernel_name(lin, x)))
 
 
@@ -962,6 +963,80 @@ def test_fused_activation_quant_at_m1_is_bit_identical_to_the_two_launch_path(ki
     xq, sx = O.scale_activations_per_token(x, O.INT8 if kind == "int8" else O.FP8E4)
     y_or = (xq @ O.to_f64(lin.W_q.data)) * (sx.astype(np.float64) * O.to_f64(lin.scales.data).reshape(1, -1))
     _compare(f"fused-quant/{kind}", lin(x), y_or, 1, abs_gate=5e-3)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("proc", ["A8W4_fp8", "A8W2_fp8", "A8W158_int8"])
+def test_packed_dynamic_layers_quantise_the_row_inside_the_decode_kernel(proc, tdt):
+    """M = 1 of A8W4 / A8W2 fp8-dynamic and BitNet int8-dynamic (helper.py:502-615, 1006-1062): `layer(x)` is ONE launch — the decode kernel
+    requests its weights, then quantises the 16-bit row per token into LDS (gemv_a8wn_kernel<..., FQ>).  Bit-identical to quantiser +
+    the same kernel on the quantised row (same arithmetic, same summation order), for grouped and channel-wise metadata, 3-d inputs, and
+    launch after launch with different rows."""
+    from gemlite_amd import core
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    torch.manual_seed(43)
+    N, K = 1024, 4096
+    if proc == "A8W158_int8":
+        lins = [H.A8W158_INT_dynamic(device=DEV, dtype=tdt).from_weights(torch.randint(-1, 2, (N, K)).to(tdt), torch.tensor(0.02))]
+        qdt = torch.int8
+    else:
+        nbits = 4 if proc == "A8W4_fp8" else 2
+        lins = []
+        for gs, post in ((128, False), (K, True)):
+            W_q, sc, zr = O.gen_data(N, K, nbits, gs, seed=50 + nbits)
+            lins.append(H.A8Wn_HQQ_INT_dynamic(device=DEV, dtype=tdt, post_scale=post, W_nbits=nbits).from_weights(
+                torch.from_numpy(W_q), torch.from_numpy(sc).to(tdt), torch.from_numpy(zr).to(tdt)))
+        qdt = torch.float8_e4m3fn
+    for lin in lins:
+        for rep, shape in enumerate(((1, K), (1, 1, K), (K,))):
+            x = (torch.randn(*shape, device=DEV) * (0.05 + 0.1 * rep)).to(tdt)
+            a = core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
+            a.matmul_type, a.M, a.x, a.out = -1, 1, x.data_ptr(), 0x1000
+            a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = K, 1, N, 1
+            a.input_dtype = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+            name = _hip.load().gemlite_hip_kernel_name(_hip.C.byref(a)).decode()
+            assert "fused_quant_kernel" in name, name
+            y_fused = lin(x)
+            xq, sx = scale_activations_per_token(x.reshape(1, K), w_dtype=qdt)
+            y_two = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1)
+            torch.cuda.synchronize()
+            assert torch.equal(y_fused.reshape(1, N), y_two), (proc, tdt, shape, float((y_fused.reshape(1, N).float() - y_two.float()).abs().max()))
+        core.FUSE_ACT_QUANT_M1 = False
+        try:
+            assert torch.equal(lin(x), y_fused)  # the switch: quantiser + matmul
+        finally:
+            core.FUSE_ACT_QUANT_M1 = True
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("proc", ["A16W8_INT8", "A16W8_INT8_post", "A16W8_FP8"])
+def test_a16w8_rows_kernel_against_the_oracle_and_the_streaming_kernel(proc, tdt):
+    """8-bit weight-only layers (helper.py:88-171) on a16w8_rows_kernel (round 4): int8 / fp8 weights converted in registers (int8 -> fp16
+    through the 1024 + (b + 128) bit pattern, exact), two v_mfma_f32_16x16x32 per 64-k chunk and 16 rows, pre- and post-scale, every
+    row-tile height, ragged M, 64-row tiles along grid.y above 64 rows, K an odd multiple of 64; against the float64 evaluation of the
+    stored tensors and against kmajor_w8a16_kernel (tuning[0] = 7)."""
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    torch.manual_seed(41)
+    N, K = 1024, 2048 + 64
+    W = (torch.randn(N, K) / 30).to(tdt)
+    W[3, :] *= 6.0  # a column whose int8 codes use the whole range
+    mk = {"A16W8_INT8": lambda: H.A16W8(device=DEV, dtype=tdt), "A16W8_INT8_post": lambda: H.A16W8(device=DEV, dtype=tdt, post_scale=True),
+          "A16W8_FP8": lambda: H.A16W8_FP8(device=DEV, dtype=tdt)}[proc]
+    lin = mk().from_weights(W)
+    out_code = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+    for M in (1, 2, 16, 17, 33, 64, 65, 200):
+        x = (torch.randn(M, K, device=DEV) / 10).to(tdt)
+        name = _kernel_name(lin, x)
+        assert name == "a16w8_rows_kernel<%s>" % ("16x16" if M <= 16 else ("32x16" if M <= 32 else "64x16")), (M, name)
+        y = lin(x)
+        y_old = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, (7, 0, 0, 0))
+        torch.cuda.synchronize()
+        y_or = _oracle_from_layer(lin, x)
+        _compare(f"a16w8-rows/{proc}/{str(tdt)[6:]}/M{M}", y, y_or, out_code, abs_gate=5e-3)
+        rel = float((y.float() - y_old.float()).abs().mean() / y_old.float().abs().mean())
+        assert rel < (2e-3 if tdt == torch.float16 else 8e-3), (proc, M, rel)
 
 
 @pytest.mark.parametrize("kind", ["int8", "fp8"])

@@ -185,8 +185,12 @@ def test_struct_abi_and_validation():
     (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<256x128>"),  # config 5: 128 tiles x 2 slices of a long K
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(2, 0, 0, 0)), "gemm_a8w8_kernel<64x64>"),  # round-1 kernel
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(1, 0, 0, 0)), "kmajor_matmul_kernel"),
-    (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "kmajor_w8a16_kernel"),   # A16W8 int8, pre-scale
-    (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "kmajor_w8a16_kernel"),  # fp8 W, bf16 x
+    (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<16x16>"),   # A16W8 int8, pre-scale (round 4: MFMA, weights converted in registers)
+    (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "a16w8_rows_kernel<16x16>"),  # fp8 W, bf16 x
+    (dict(M=40, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<64x16>"),
+    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<64x16>"),  # 64-row tiles along grid.y
+    (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(7, 0, 0, 0)), "kmajor_w8a16_kernel"),  # A/B switch: rounds 1-3
+    (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096 + 16, K=4096 + 16), "kmajor_w8a16_kernel"),    # K % 64 != 0
     (dict(M=1, N=1000), "generic_matmul_kernel"),    # N not a multiple of 64
     (dict(M=1, in_dt=4, w_mode=1, c_mode=1, out_dt=0), "generic_matmul_kernel"),  # int8 x W4 with tensor zeros, fp32 out
     # 8-bit activations x packed weights (A8Wn fp8 dynamic, BitNet int8: helper.py:502-615, 1006-1062): fp8 / int8 MFMA
@@ -203,7 +207,8 @@ def test_struct_abi_and_validation():
     (dict(M=300, nbits=2, in_dt=4, out_dt=2, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w2_mma_kernel<64x128>"),
     (dict(M=1, in_dt=8, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "generic_matmul_kernel"),   # e5m2 activations: coverage kernel
     # 16-bit activations whose output / channel-scale type differs (BitNet A16W158 with its fp32 scale; fp32 output)
-    (dict(M=1, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_w2_mma_kernel<32x128>"),
+    (dict(M=1, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemv_wn_kernel<tile16>"),   # round 4: fp32 post-scale in the GEMV epilogue
+    (dict(M=8, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_w2_mma_kernel<32x128>"),
     (dict(M=64, in_dt=1, out_dt=0), "gemm_w4_mma_kernel<32x128>"),
 ])
 def test_kernel_selection(kw, kernel):
