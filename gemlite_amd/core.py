@@ -296,7 +296,11 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
     out = torch.empty((M, a.N), dtype=DTYPE_TO_TORCH[a.output_dtype], device=x.device)
     a.matmul_type = matmul_type
     a.x, a.out, a.M = x.data_ptr(), out.data_ptr(), M
-    if mx:  # the layer's format pair names what x holds (include/gemlite_hip.h "Block-scaled formats")
+    raw_mx = (mx and fused_quant_optional and scales_x is None and x.dtype in (torch.float16, torch.bfloat16) and
+              meta_args[5] in (DType.MXFP8.value, DType.MXFP4.value))
+    if raw_mx:  # one unquantised row of a block-scaled dynamic layer: the kernel quantises it (the layer's format rides in type_id)
+        a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
+    elif mx:  # the layer's format pair names what x holds (include/gemlite_hip.h "Block-scaled formats")
         if x.dtype != DTYPE_TO_TORCH[meta_args[5]]:
             raise _hip.GemliteHipError(f"{DType(meta_args[5]).name} layer called with {x.dtype} activations")
         a.input_dtype = meta_args[5]
@@ -356,6 +360,22 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
     if bool(meta_args[0]) and is_mx_dtype(in_code):
         # block-scaled activations (core.py:165-175): microscales (channel_scale_mode 4) or one fp32 scale per token (2)
         c_mode = meta_args[9]
+        K_ = x.shape[-1]
+        if FUSE_ACT_QUANT_M1 and ((c_mode == 4 and in_code in (DType.MXFP8.value, DType.MXFP4.value)) or (c_mode == 2 and in_code == DType.MXFP8.value)) and \
+                x.numel() == K_ and matmul_type < 0 and \
+                TUNING_OVERRIDE is None and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.data_ptr() % 16 == 0:
+            # ONE row: the few-row kernel quantises it block by block itself (round 4; bit-identical to quantiser + matmul); where the
+            # library has no such kernel for the shape it says so once and the answer is remembered
+            fkey = (W_q.shape[1], K_, in_code, meta_args[1], x.dtype, "mx", c_mode, x.device.index)
+            if fkey not in _NO_FUSED_QUANT:
+                out = _hip_matmul(x if x.dim() == 2 else x.view(-1, K_), W_q, scales, zeros, None, meta_args, matmul_type, fused_quant_optional=True)
+                if out is not None:
+                    if len(out_shape) != 2:
+                        out = out.view(out_shape)
+                    if bias is not None:
+                        out += bias
+                    return out
+                _NO_FUSED_QUANT.add(fkey)
         if in_code == DType.MXFP8.value and c_mode == 4:
             x, scales_x = scale_activations_mxfp8(x, w_dtype=torch.float8_e4m3fn)
         elif in_code == DType.MXFP8.value and c_mode == 2:

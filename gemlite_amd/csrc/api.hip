@@ -34,7 +34,7 @@ bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPla
 bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 const void* mx_generic_kernel_fn();
 const void* act_quant_mx_kernel_fn(int mode);
-bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp, bool any_m = false);
+bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp, bool any_m = false, bool fq = false);
 const void* nvfp4_expand_f16_kernel_fn();
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
@@ -92,7 +92,9 @@ static Epilogue make_epilogue(const gemlite_hip_forward_args& a) {
 // Dynamic activation quantisation fused into the matmul: the caller passes the UNQUANTISED 16-bit x, no scales_x, and the 8-bit
 // unpacked weights of a dynamically quantised layer (channel_scale_mode 2 / 3).  M = 1: every block quantises the row itself
 // (kmajor_fused_quant_kernel); 2 <= M: the blocks of the A8W8 kernels deal the rows among themselves (gl_coopquant.h).
+static bool is_mx_input(int dt);
 static bool wants_fused_quant(const gemlite_hip_forward_args* a) {
+    if (is_mx_input(a->type_id / 100)) return false;  // a block-scaled layer (its weights carry e8m0 block scales): not this kernel family
     return a->M >= 1 && a->elements_per_sample == 1 && !a->scales_x &&
            (a->channel_scale_mode == 2 || a->channel_scale_mode == 3) && a->W_group_mode == 0 &&
            (a->input_dtype == GEMLITE_DT_FP16 || a->input_dtype == GEMLITE_DT_BF16) &&
@@ -107,6 +109,18 @@ static int fused_quant_packed_dtype(const gemlite_hip_forward_args* a) {
     if (!(a->input_dtype == GEMLITE_DT_FP16 || a->input_dtype == GEMLITE_DT_BF16)) return 0;
     const int layer_dt = a->type_id / 100;
     return (layer_dt == GEMLITE_DT_FP8E4 || layer_dt == GEMLITE_DT_INT8) && a->type_id % 100 == a->W_nbits ? layer_dt : 0;
+}
+
+static bool is_mx_input(int dt);
+// ... and for the block-scaled dynamic layers (round 4, M = 1, MXFP8 / MXFP4 activations with block scales): x is the unquantised 16-bit
+// row, input_dtype names ITS type, the layer's format rides in type_id like above, scales_x is NULL, channel_scale_mode 4 (block
+// scales) or 2 (MXFP8 with one scale per token)
+static int fused_quant_mx_dtype(const gemlite_hip_forward_args* a) {
+    if (a->M != 1 || a->scales_x || !(a->channel_scale_mode == 4 || a->channel_scale_mode == 2)) return 0;
+    if (!(a->input_dtype == GEMLITE_DT_FP16 || a->input_dtype == GEMLITE_DT_BF16)) return 0;
+    const int layer_dt = a->type_id / 100;
+    if (a->channel_scale_mode == 2 && layer_dt != GEMLITE_DT_MXFP8) return 0;  // one fp32 scale per token: fp8 activations
+    return (layer_dt == GEMLITE_DT_MXFP8 || layer_dt == GEMLITE_DT_MXFP4) && a->type_id % 100 == a->W_nbits ? layer_dt : 0;
 }
 
 static bool is_mx_input(int dt) { return dt >= GEMLITE_DT_MXFP16 && dt <= GEMLITE_DT_NVFP4; }
@@ -137,6 +151,12 @@ static int validate(const gemlite_hip_forward_args* a) {
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return GEMLITE_ERR_BAD_ARGUMENT;
     if (a->M > 0x7FFFFFFF || a->N > 0x7FFFFFFF || a->K > 0x7FFFFFFF) return GEMLITE_ERR_BAD_SHAPE;
     if (is_mx_input(a->input_dtype)) return validate_mx(a);
+    if (const int mxdt = fused_quant_mx_dtype(a)) {  // validated as the block-scaled call it stands for
+        gemlite_hip_forward_args b = *a;
+        b.input_dtype = mxdt;
+        b.scales_x = (const void*)(uintptr_t)0x1000;
+        return validate_mx(&b);
+    }
     if (a->W_group_mode < 0 || a->W_group_mode > 4) return GEMLITE_ERR_UNSUPPORTED;
     if (a->channel_scale_mode < 0 || a->channel_scale_mode > 3) return GEMLITE_ERR_UNSUPPORTED;  // 4: block-scaled inputs only
     if (a->elements_per_sample < 1) return GEMLITE_ERR_BAD_ARGUMENT;
@@ -166,7 +186,14 @@ static int validate(const gemlite_hip_forward_args* a) {
 
 // Block-scaled formats: the scaled-MFMA kernel for 8 / 4-bit activations, the coverage kernel for everything else
 // (16-bit activations x MX weights, NVFP4, layouts that are not K-contiguous).  tuning[0] = 1 forces the coverage kernel.
+static GenericParams mx_params(const gemlite_hip_forward_args& a);
+static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, const GenericParams& g);
 static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
+    GenericParams g = mx_params(a);
+    r.gp = g;
+    resolve_mx_plan(a, r, g);
+}
+static GenericParams mx_params(const gemlite_hip_forward_args& a) {
     GenericParams g{};
     g.x = a.x; g.w = a.w_q; g.scales = a.scales; g.zeros = nullptr;
     g.epi = make_epilogue(a);
@@ -184,7 +211,9 @@ static void resolve_mx(const gemlite_hip_forward_args& a, Resolved& r) {
     g.stride_sx_blk_m = a.stride_sx_m;
     g.mx_post = a.input_dtype == GEMLITE_DT_NVFP4 ? 0.0025f : 1.0f;  // meta_scale_norm = 0.05 ** 2 (gemm_kernels.py:461, 530-531)
     g.splitk = 1;
-    r.gp = g;
+    return g;
+}
+static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, const GenericParams& g) {
     // 1 .. 64 rows of fp8 / fp4 activations (round 4): 16-column blocks, one 16-row scaled MFMA per 128-k chunk straight from memory.
     // Faster than the streaming kernel below from ONE row (4096^2 fp4 x fp4: 5.4 vs 6.3 us at M = 1, 5.6 vs 9.9 at M = 4) and than the
     // 32-row tile up to 64 rows (M = 16: 5.8 vs 17.3 us) — profiles/r04/probe_mx_rows.log.  tuning[0] = 4 forces it past its
@@ -259,6 +288,26 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
     r.status = validate(&a);
     if (r.status != GEMLITE_OK) return;
     if (is_mx_input(a.input_dtype)) { resolve_mx(a, r); return; }
+    if (const int mxdt = fused_quant_mx_dtype(&a)) {  // one row of a block-scaled dynamic layer, quantiser inside the launch (mx_rows_kernel<..., FQ>)
+        r.status = GEMLITE_ERR_NO_FUSED_QUANT;
+        if (a.tuning[0] != 0 || a.tuning[1] != 0 || a.tuning[2] != 0 || a.matmul_type != GEMLITE_MATMUL_AUTO) return;
+        if (a.stride_xk != 1 || ((uintptr_t)a.x % 16) != 0) return;
+        gemlite_hip_forward_args b = a;
+        b.input_dtype = mxdt;
+        b.x = (const void*)(uintptr_t)0x1000;
+        b.scales_x = (const void*)(uintptr_t)0x1000;
+        b.stride_xm = mxdt == GEMLITE_DT_MXFP8 ? a.K : a.K / 2;
+        b.stride_sx_m = a.K / 32;
+        GenericParams g = mx_params(b);
+        LaunchPlan lp{};
+        if (!plan_mx_rows(b, g, lp, false, true)) return;
+        g.x = a.x;                 // the raw row
+        g.x_dt = a.input_dtype;    // ... and its type
+        g.sx_blocks = a.channel_scale_mode == 4 ? a.x : nullptr;  // (non-null: block-scaled activations)
+        r.status = GEMLITE_OK;
+        r.kind = K_KMAJOR; r.gp = g; r.lp = lp;
+        return;
+    }
     const bool packed = a.elements_per_sample > 1;
     const bool x16 = a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_BF16;
     // metadata rows actually indexed by K: channel-wise / scalar metadata behaves like one K-long group

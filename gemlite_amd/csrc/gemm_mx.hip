@@ -50,6 +50,57 @@ __device__ __forceinline__ float e8m0_to_float(uint32_t b) {  // 2^(b - 127); 0 
 // Rows M .. M_pad - 1 of the scale tensor (the reference pads M to a multiple of the group size and its programs store
 // the scale of an all-zero block there) are written with that value; no element output exists for them.
 // ---------------------------------------------------------------------------------------------------------------------
+// One block of G values -> its scale byte and packed elements (MODE 0: 8 dwords of e4m3, MODE 1 / 2: G / 8 dwords of e2m1 codes).  The
+// arithmetic of act_quant_mx_kernel, shared with the kernels that quantise a row themselves (mx_rows_kernel<..., FQ>).
+template <int MODE>
+__device__ __forceinline__ uint8_t mx_quant_block(const float (&v)[MODE == 2 ? 16 : 32], float amax, uint32_t (&o)[8]) {
+    constexpr int G = MODE == 2 ? 16 : 32;
+    float s, rinv = 1.f;
+    bool use_mul = false;
+    uint8_t sb;
+    if (MODE == 2) {
+        const float s32 = fminf(__fdiv_rn(amax, 0.3f), 448.f);  // 6 * 0.05 folded to the fp32 constant 0.3f
+        sb = float_to_fp8e4m3(s32);
+        s = fmaxf(fp8e4m3_to_float(sb) * 0.05f, 1e-6f);
+    } else {
+        const uint32_t xi = __builtin_bit_cast(uint32_t, __fdiv_rn(amax, MODE == 0 ? 448.f : 6.f));
+        int ex = (int)((xi >> 23) & 0xFFu) + ((xi & 0x7FFFFFu) != 0u ? 1 : 0);
+        ex = ex > 254 ? 254 : (ex < 97 ? 97 : ex);
+        sb = (uint8_t)ex;
+        s = __builtin_bit_cast(float, (uint32_t)ex << 23);
+        // (round 3) x / 2^k == x * 2^-k bit for bit — one exact real value, one rounding — so the IEEE division (~12 VALU per
+        // element) becomes a multiplication whenever 2^-k is a normal float (ex <= 253; 254 keeps the division)
+        rinv = __builtin_bit_cast(float, (uint32_t)(254 - (ex > 253 ? 253 : ex)) << 23);
+        use_mul = ex <= 253;
+    }
+    if (MODE == 0) {
+        // hardware e4m3 converter (RNE, subnormals kept; the clamp keeps it away from overflow): two values per instruction
+#pragma unroll
+        for (int e4 = 0; e4 < 8; ++e4) {
+            float q[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                q[t] = fminf(fmaxf(use_mul ? v[4 * e4 + t] * rinv : __fdiv_rn(v[4 * e4 + t], s), -448.f), 448.f);
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true);
+            o[e4] = (uint32_t)w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < G; ++e) {
+            const float q = (MODE == 1 && use_mul) ? v[e] * rinv : __fdiv_rn(v[e], s), a = fabsf(q);
+            uint32_t c = (a > 0.25f) + (a > 0.75f) + (a > 1.25f) + (a > 1.75f) + (a > 2.5f) + (a > 3.5f) + (a > 5.0f) + (a > 7.0f);
+            if (!(q >= 0.f)) c += 8u;
+            // byte = lo | (hi << 4) in uint8 arithmetic, like the reference's pack (quant_utils.py:805-806): a code above 15 —
+            // only when the block scale was floored (|q| > 7) — spills into / out of the byte exactly as it does there
+            const uint32_t part = ((e & 1) ? ((c << 4) & 0xFFu) : c) << (8 * ((e & 7) >> 1));
+            if ((e & 7) == 0) o[e >> 3] = part;
+            else o[e >> 3] |= part;
+        }
+    }
+    return sb;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void act_quant_mx_kernel(const void* x, uint8_t* y, uint8_t* scales, int64_t M, int64_t M_pad,
                                                           int64_t K, int64_t stride_xm, int in_dt) {
@@ -83,54 +134,15 @@ __global__ __launch_bounds__(256) void act_quant_mx_kernel(const void* x, uint8_
 #pragma unroll
         for (int e = 0; e < G; ++e) v[e] = 0.f;
     }
-    float s, rinv = 1.f;
-    bool use_mul = false;
-    if (MODE == 2) {
-        const float s32 = fminf(__fdiv_rn(amax, 0.3f), 448.f);  // 6 * 0.05 folded to the fp32 constant 0.3f
-        const uint8_t s8 = float_to_fp8e4m3(s32);
-        scales[idx] = s8;
-        s = fmaxf(fp8e4m3_to_float(s8) * 0.05f, 1e-6f);
-    } else {
-        const uint32_t xi = __builtin_bit_cast(uint32_t, __fdiv_rn(amax, MODE == 0 ? 448.f : 6.f));
-        int ex = (int)((xi >> 23) & 0xFFu) + ((xi & 0x7FFFFFu) != 0u ? 1 : 0);
-        ex = ex > 254 ? 254 : (ex < 97 ? 97 : ex);
-        scales[idx] = (uint8_t)ex;
-        s = __builtin_bit_cast(float, (uint32_t)ex << 23);
-        // (round 3) x / 2^k == x * 2^-k bit for bit — one exact real value, one rounding — so the IEEE division (~12 VALU per
-        // element) becomes a multiplication whenever 2^-k is a normal float (ex <= 253; 254 keeps the division)
-        rinv = __builtin_bit_cast(float, (uint32_t)(254 - (ex > 253 ? 253 : ex)) << 23);
-        use_mul = ex <= 253;
-    }
+    uint32_t o[8];
+    const uint8_t sb = mx_quant_block<MODE>(v, amax, o);
+    scales[idx] = sb;
     if (m >= M) return;
     if (MODE == 0) {
-        uint32_t o[8];
-        // hardware e4m3 converter (RNE, subnormals kept; the clamp keeps it away from overflow): two values per instruction
-#pragma unroll
-        for (int e4 = 0; e4 < 8; ++e4) {
-            float q[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                q[t] = fminf(fmaxf(use_mul ? v[4 * e4 + t] * rinv : __fdiv_rn(v[4 * e4 + t], s), -448.f), 448.f);
-            int w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true);
-            o[e4] = (uint32_t)w;
-        }
         u32x4* dst = (u32x4*)(y + m * K + g * 32);
         dst[0] = (u32x4){o[0], o[1], o[2], o[3]};
         dst[1] = (u32x4){o[4], o[5], o[6], o[7]};
     } else {
-        uint32_t o[G / 8];
-#pragma unroll
-        for (int e = 0; e < G; ++e) {
-            const float q = (MODE == 1 && use_mul) ? v[e] * rinv : __fdiv_rn(v[e], s), a = fabsf(q);
-            uint32_t c = (a > 0.25f) + (a > 0.75f) + (a > 1.25f) + (a > 1.75f) + (a > 2.5f) + (a > 3.5f) + (a > 5.0f) + (a > 7.0f);
-            if (!(q >= 0.f)) c += 8u;
-            // byte = lo | (hi << 4) in uint8 arithmetic, like the reference's pack (quant_utils.py:805-806): a code above 15 —
-            // only when the block scale was floored (|q| > 7) — spills into / out of the byte exactly as it does there
-            const uint32_t part = ((e & 1) ? ((c << 4) & 0xFFu) : c) << (8 * ((e & 7) >> 1));
-            if ((e & 7) == 0) o[e >> 3] = part;
-            else o[e >> 3] |= part;
-        }
         uint8_t* dst = y + m * (K / 2) + g * (G / 2);
         if (G == 32) *(u32x4*)dst = (u32x4){o[0], o[1], o[2], o[3]};
         else *(u32x2*)dst = (u32x2){o[0], o[1]};
@@ -380,10 +392,19 @@ bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPla
 // Mixed formats (fp8 x rows against fp4 weight rows) pair by k, each side in its own layout.  c_mode 2 (per-token fp32 scale in the
 // epilogue): the activation block scale is the constant 127.  Rows >= M read zeros through the descriptor's range check.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int XF, int WF, int MT>
+// FQ (round 4, one row): p.x is the UNQUANTISED 16-bit row; the block requests its first weights, then quantises the row block by block
+// (mx_quant_block: the arithmetic of act_quant_mx_kernel, thread = one 32-k block) into LDS and reads its x fragments from there —
+// layer(x) of the MXFP8 / MXFP4 dynamic layers at M = 1 in one launch instead of quantiser + matmul.
+// FQ = 2: the same for the per-token form of the fp8 activations (channel_scale_mode 2, the processors' default `post_scale=True`): one
+// fp32 scale for the row (amax / 448 over the block, IEEE divisions: the arithmetic of act_quant_per_token_kernel), unit block scales,
+// the row scale applied in the epilogue.
+template <int XF, int WF, int MT, int FQ = 0>
 __global__ __launch_bounds__(512) void mx_rows_kernel(const GenericParams p) {
+    static_assert(!FQ || MT == 1, "in-launch activation quantisation: one row");
+    static_assert(FQ != 2 || XF == 0, "per-token scales: fp8 activations");
     constexpr int XV = XF == 0 ? 2 : 1, WV = WF == 0 ? 2 : 1;  // 16-byte pieces per fragment
     __shared__ __attribute__((aligned(16))) float red[MT][8][64][4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];  // FQ: [row bytes of quantised x][K / 32 scale bytes]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4;
@@ -413,24 +434,41 @@ __global__ __launch_bounds__(512) void mx_rows_kernel(const GenericParams p) {
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sx_row = 1.f;  // FQ = 2: the row's per-token scale
     constexpr int D = MT == 1 ? 4 : (MT == 2 ? 3 : 2);  // chunks in flight per wave
     struct Chunk { u32x4 w[WV]; uint32_t sw; u32x4 x[MT][XV]; uint32_t sx[MT]; };
     Chunk ring[D];
     const int mine = (nchunks - wave + 7) >> 3;  // chunks wave, wave + 8, ...
-    auto load = [&](int slot, int i) __attribute__((always_inline)) {
+    auto load_w = [&](int slot, int i) __attribute__((always_inline)) {
         const int ch = wave + 8 * i;
         Chunk& k = ring[slot];
         const uint32_t wo = (uint32_t)__builtin_amdgcn_readfirstlane(ch * (WF == 0 ? 128 : 64));
-        const uint32_t xo = (uint32_t)__builtin_amdgcn_readfirstlane(ch * (XF == 0 ? 128 : 64));
         k.w[0] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, wo, 0);
         if constexpr (WV == 2) k.w[1] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, wo + 64u, 0);
         k.sw = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsS, svoff, (uint32_t)__builtin_amdgcn_readfirstlane(ch * 4 * (int)p.stride_meta_g), 0);
+    };
+    auto load_x = [&](int slot, int i) __attribute__((always_inline)) {
+        const int ch = wave + 8 * i;
+        Chunk& k = ring[slot];
+        if constexpr (FQ) {  // the one row, from LDS (lanes of row 0 only; every other row of the 16-row operand is zero)
+            const unsigned char* src = xlds + ch * (XF == 0 ? 128 : 64) + q * 16;
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            k.x[0][0] = c == 0 ? *(const u32x4*)src : zero;
+            if constexpr (XV == 2) k.x[0][1] = c == 0 ? *(const u32x4*)(src + 64) : zero;
+            k.sx[0] = (FQ == 1 && c == 0) ? (uint32_t)xlds[xk_bytes + ch * 4 + q] : 127u;
+            return;
+        }
+        const uint32_t xo = (uint32_t)__builtin_amdgcn_readfirstlane(ch * (XF == 0 ? 128 : 64));
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             k.x[t][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], xo, 0);
             if constexpr (XV == 2) k.x[t][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], xo + 64u, 0);
             k.sx[t] = blk_x ? (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, avoff[t], (uint32_t)__builtin_amdgcn_readfirstlane(ch * 4), 0) : 127u;
         }
+    };
+    auto load = [&](int slot, int i) __attribute__((always_inline)) {
+        load_w(slot, i);
+        load_x(slot, i);
     };
     auto mma = [&](int slot) __attribute__((always_inline)) {
         const Chunk& k = ring[slot];
@@ -451,9 +489,79 @@ __global__ __launch_bounds__(512) void mx_rows_kernel(const GenericParams p) {
             acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc[t], XF, WF, 0, (int)k.sx[t], 0, (int)k.sw);
         }
     };
+    if constexpr (FQ) {
 #pragma unroll
-    for (int j = 0; j < D; ++j)
-        if (j < mine) load(j, j);
+        for (int j = 0; j < D; ++j)
+            if (j < mine) load_w(j, j);
+        // thread = one 32-k block of the row: 64 bytes in, 32 (fp8) / 16 (fp4) bytes + the scale byte out
+        const uint16_t* xr = (const uint16_t*)p.x;
+        const bool f16 = p.x_dt == GEMLITE_DT_FP16;
+        if constexpr (FQ == 2) {
+            float* wmax = (float*)(xlds + ((xk_bytes + 15) & ~15));
+            float amax = 0.f;
+            for (int k = tid * 8; k < p.K; k += 512 * 8) {
+                const u32x4 d = *(const u32x4*)(xr + k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint16_t hb = (uint16_t)(d[e >> 1] >> (16 * (e & 1)));
+                    amax = fmaxf(amax, fabsf(f16 ? F16Traits<half_tag>::to_float(hb) : F16Traits<bf16_tag>::to_float(hb)));
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+            if (lane == 0) wmax[wave] = amax;
+            __syncthreads();
+            amax = fmaxf(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])), fmaxf(fmaxf(wmax[4], wmax[5]), fmaxf(wmax[6], wmax[7])));
+            sx_row = fmaxf(__fdiv_rn(amax, 448.f), 1e-6f);
+            for (int k = tid * 8; k < p.K; k += 512 * 8) {
+                const u32x4 d = *(const u32x4*)(xr + k);
+                float tq[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint16_t hb = (uint16_t)(d[e >> 1] >> (16 * (e & 1)));
+                    const float f = f16 ? F16Traits<half_tag>::to_float(hb) : F16Traits<bf16_tag>::to_float(hb);
+                    tq[e] = fminf(fmaxf(__fdiv_rn(f, sx_row), -448.f), 448.f);
+                }
+                int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(tq[0], tq[1], 0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(tq[2], tq[3], w0, true);
+                int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(tq[4], tq[5], 0, false);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(tq[6], tq[7], w1, true);
+                *(u32x2*)(xlds + k) = (u32x2){(uint32_t)w0, (uint32_t)w1};
+            }
+        } else
+        for (int b = tid; b < blocks_k; b += 512) {
+            float v[32];
+            float amax = 0.f;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const u32x4 d = *(const u32x4*)(xr + b * 32 + 8 * qd);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint16_t hb = (uint16_t)(d[e >> 1] >> (16 * (e & 1)));
+                    v[8 * qd + e] = f16 ? F16Traits<half_tag>::to_float(hb) : F16Traits<bf16_tag>::to_float(hb);
+                    amax = fmaxf(amax, fabsf(v[8 * qd + e]));
+                }
+            }
+            uint32_t o[8];
+            const uint8_t sb = mx_quant_block<(XF == 0 ? 0 : 1)>(v, amax, o);
+            xlds[xk_bytes + b] = sb;
+            if constexpr (XF == 0) {
+                u32x4* dst = (u32x4*)(xlds + b * 32);
+                dst[0] = (u32x4){o[0], o[1], o[2], o[3]};
+                dst[1] = (u32x4){o[4], o[5], o[6], o[7]};
+            } else {
+                *(u32x4*)(xlds + b * 16) = (u32x4){o[0], o[1], o[2], o[3]};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < mine) load_x(j, j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < mine) load(j, j);
+    }
     for (int base = 0; base < mine; base += D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -472,7 +580,11 @@ __global__ __launch_bounds__(512) void mx_rows_kernel(const GenericParams p) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[t][w][l][r];
-        if (m < p.M) epilogue_store(p.epi, v * p.mx_post, m, n0 + (l & 15));
+        if constexpr (FQ == 2) {  // out = acc * s_x (channel_scale_mode 2: epilogue_scale() with the scale computed here)
+            if (m < p.M) store_from_float(p.epi.out, (int64_t)m * p.epi.stride_om + (n0 + (l & 15)) * p.epi.stride_on, p.epi.out_dt, v * p.mx_post * sx_row);
+        } else {
+            if (m < p.M) epilogue_store(p.epi, v * p.mx_post, m, n0 + (l & 15));
+        }
     }
 }
 
@@ -480,7 +592,11 @@ __global__ __launch_bounds__(512) void mx_rows_kernel(const GenericParams p) {
 // (8192^2 fp8: M = 32 25.7 vs 24.2 us, M = 64 42.0 vs 25.1 for the tile kernel).  tuning[0] = 4 forces it past the budget.
 // any_m: the fall-back for shapes no tile kernel takes (fp4 activations with K % 512 != 0 — K = 11008 — ran on the coverage kernel:
 // 4.5 ms at 4096 x 11008, M = 1): 64-row tiles along grid.y, any M.
-bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp, bool any_m) {
+// fq: one row, the activation quantiser inside the launch (`a` describes the call as the matmul sees it; the launch gets the raw row)
+bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp, bool any_m, bool fq) {
+    if (fq && (a.M != 1 || a.K > 49152)) return false;
+    const bool fq_token = fq && a.channel_scale_mode == 2;  // per-token scale (fp8 activations only)
+    if (fq_token && g.mx_x != MX_FP8) return false;
     if ((a.M > 64 && !any_m) || a.M < 1 || a.M > 65535 * 64 || g.mx_scale_e4m3 || g.group_size != 32) return false;
     if (!(g.mx_x == MX_FP8 || g.mx_x == MX_FP4) || (g.mx_x == MX_FP4 && g.mx_w != MX_FP4)) return false;
     if (a.stride_wk != 1 || a.stride_xk != 1 || a.K % 128 != 0 || a.N % 16 != 0) return false;
@@ -494,6 +610,10 @@ bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPla
     fn_t fn = nullptr;
     auto pick = [&](auto xf, auto wf) -> fn_t {
         constexpr int XF = decltype(xf)::value, WF = decltype(wf)::value;
+        if (fq) {
+            if constexpr (XF == 0) { if (fq_token) return mx_rows_kernel<XF, WF, 1, 2>; }
+            return mx_rows_kernel<XF, WF, 1, 1>;
+        }
         return mt == 1 ? mx_rows_kernel<XF, WF, 1> : (mt == 2 ? mx_rows_kernel<XF, WF, 2> : mx_rows_kernel<XF, WF, 4>);
     };
     typedef std::integral_constant<int, 0> F8;
@@ -504,10 +624,11 @@ bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPla
     static const char* names[3][3] = {{"mx_rows_a8w8_kernel<16x16>", "mx_rows_a8w8_kernel<32x16>", "mx_rows_a8w8_kernel<64x16>"},
                                       {"mx_rows_a8w4_kernel<16x16>", "mx_rows_a8w4_kernel<32x16>", "mx_rows_a8w4_kernel<64x16>"},
                                       {"mx_rows_a4w4_kernel<16x16>", "mx_rows_a4w4_kernel<32x16>", "mx_rows_a4w4_kernel<64x16>"}};
-    lp.name = names[x8 ? (w8 ? 0 : 1) : 2][mt == 1 ? 0 : (mt == 2 ? 1 : 2)];
+    static const char* fq_names[3] = {"mx_rows_a8w8_fused_quant_kernel<16x16>", "mx_rows_a8w4_fused_quant_kernel<16x16>", "mx_rows_a4w4_fused_quant_kernel<16x16>"};
+    lp.name = fq ? fq_names[x8 ? (w8 ? 0 : 1) : 2] : names[x8 ? (w8 ? 0 : 1) : 2][mt == 1 ? 0 : (mt == 2 ? 1 : 2)];
     lp.grid = dim3((unsigned)(a.N / 16), (unsigned)((a.M + 16 * mt - 1) / (16 * mt)), 1);
     lp.block = dim3(512, 1, 1);
-    lp.lds_bytes = 0;
+    lp.lds_bytes = fq ? (size_t)(xrow + a.K / 32 + 64) : 0;
     lp.ws_bytes = 0;
     lp.slab_bytes = 0;
     return true;

@@ -248,6 +248,39 @@ def test_few_row_scaled_mfma_kernel(proc):
         assert _kernel_name(layer, x).startswith("mx_rows_"), _kernel_name(layer, x)
 
 
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("proc", ["A8W8_MXFP_dynamic", "A8W4_MXFP_dynamic", "A4W4_MXFP_dynamic", "A8W8_MXFP_dynamic_post", "A8W4_MXFP_dynamic_post"])
+def test_one_row_is_quantised_inside_the_few_row_kernel(proc, tdt):
+    """M = 1 of the block-scaled dynamic layers: `layer(x)` is ONE launch — mx_rows_kernel<..., FQ> requests its weights, quantises the row
+    block by block into LDS (mx_quant_block = the arithmetic of the quantiser kernel; `_post`: one fp32 scale per token, the processors'
+    default) and multiplies.  Bit-identical to quantiser + the same kernel on the quantised row; 2-d / 3-d / 1-d inputs, rows with very
+    different block magnitudes, K = 1152 and 4096; the switch."""
+    for N, K in ((256, 1152), (512, 4096)):
+        lin = _linear(N, K, tdt, seed=31)
+        lin.bias = None
+        layer = PROCS[proc](tdt).from_linear(lin, del_orig=False)
+        g = torch.Generator().manual_seed(19)
+        for rep, shape in enumerate(((1, K), (1, 1, K), (K,))):
+            x = (torch.randn(*shape, generator=g) * (0.1 + 0.3 * rep)).to(tdt).to(DEV)
+            x.view(-1)[:32] *= 40.0
+            x.view(-1)[64:96] = 0.0  # an all-zero block: the floored scale
+            a = C._static_args(layer.W_q, layer.scales, layer.zeros, layer.get_meta_args())
+            a.matmul_type, a.M, a.x, a.out = -1, 1, x.data_ptr(), 0x1000
+            a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = K, 1, N, 1
+            a.input_dtype = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+            name = _hip.load().gemlite_hip_kernel_name(_hip.C.byref(a)).decode()
+            assert name.startswith("mx_rows_") and "fused_quant" in name, name
+            y_fused = layer(x)
+            C.FUSE_ACT_QUANT_M1 = False
+            try:
+                y_two = layer(x)
+            finally:
+                C.FUSE_ACT_QUANT_M1 = True
+            torch.cuda.synchronize()
+            assert y_fused.shape == y_two.shape and torch.equal(y_fused, y_two), (proc, tdt, N, K, shape, float((y_fused.float() - y_two.float()).abs().max()))
+        _check(f"{proc} fused M=1 {name}", layer(x).reshape(1, N), _oracle(layer, x.reshape(1, K)), tdt)
+
+
 def test_fp4_activations_with_k_not_a_multiple_of_512_leave_the_coverage_kernel():
     """The fp4 x fp4 tile kernels step 512 k; K = 11008 (Llama down_proj) is 21.5 such steps and ran on the coverage kernel in rounds 2-3
     (4.5 ms at 4096 x 11008).  Round 4: any M on 64-row tiles of the few-row kernel (grid.y), 128-k chunks."""
