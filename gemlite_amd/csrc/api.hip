@@ -219,7 +219,12 @@ static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, cons
     // 32-row tile up to 64 rows (M = 16: 5.8 vs 17.3 us) — profiles/r04/probe_mx_rows.log.  tuning[0] = 4 forces it past its
     // x re-read budget, 5 = the streaming kernel, 2 = the tile kernels.
     if ((a.tuning[0] == 4 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0)) && plan_mx_rows(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
-    // decode sizes of what is left (16-bit activations x MX weights, K % 128 != 0): the streaming kernel
+    // 16-bit activations x block-scaled weights, 1 .. 64 rows (round 4): the A16W8 rows kernel with the scaled converters — while every
+    // block's re-read of x (M K 2 bytes x N / 16 blocks) stays in budget.  tuning[0] = 4 forces it, 5 / 2 keep the streaming / tile kernels
+    if ((a.input_dtype == GEMLITE_DT_MXFP16 || a.input_dtype == GEMLITE_DT_MXBF16) && a.M <= 64 &&
+        (a.tuning[0] == 4 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && (a.M <= 16 || (int64_t)a.M * a.K * 2 * (a.N / 16) <= (176ll << 20)))) &&
+        plan_a16w8_rows(a, r.lp)) { r.kind = K_KMAJOR; return; }
+    // decode sizes of what is left (K % 64 != 0 ...): the streaming kernel
     if ((a.tuning[0] == 0 || a.tuning[0] == 5) && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
     // prefill sizes of the same-format pairs: 256 x 256 tiles, both operands through LDS (tuning[0] = 3 forces it at any M)
     if (plan_gemm_mx_tile(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }

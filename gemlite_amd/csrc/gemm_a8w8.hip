@@ -1101,9 +1101,15 @@ bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq) 
 // The channel scale multiplies the fp32 sum once (pre-scale: a per-column constant; post-scale: the reference's epilogue).  More than 64
 // rows: 64-row tiles along grid.y (weights re-read from L2 per tile) until a tile kernel takes these layers.
 // ---------------------------------------------------------------------------------------------------------------------
+// WDT 103 / 104 (round 4): the block-scaled weight-only layers (A16W8_MXFP / A16W4_MXFP, helper.py:372-400) on the same kernel — fp8 e4m3 /
+// fp4 e2m1 weights, K-contiguous, one e8m0 scale per 32 k ([K/32][N] bytes).  A lane's 16 k of a chunk lie inside ONE block, so it loads
+// one scale byte per chunk and the hardware converters apply it (v_cvt_scalef32_pk_{f16,bf16}_{fp8,fp4}: exact, a power of two).
+constexpr int A16_MXW8 = 103, A16_MXW4 = 104;
 template <typename Tag, int WDT, int MT>
 __global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) {
     using TR = F16Traits<Tag>;
+    constexpr bool MXW = WDT == A16_MXW8 || WDT == A16_MXW4;
+    constexpr int WB = WDT == A16_MXW4 ? 8 : 16;  // weight bytes per lane and 64-k chunk
     __shared__ __attribute__((aligned(16))) float red[MT][8][64][4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1111,9 +1117,12 @@ __global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) 
     const int64_t n0 = (int64_t)blockIdx.x * 16;
     const int mbase = (int)blockIdx.y * (16 * MT);
     const int nchunks = p.K / 64;
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + p.K), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + p.K * WB / 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)(((int64_t)(p.M - 1) * p.stride_xm + p.K) * 2), 0x00020000);
-    const uint32_t wvoff = (uint32_t)((n0 + c) * p.stride_wn + q * 16);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(MXW ? p.scales : p.w), (short)0, MXW ? (int)((int64_t)(p.K / 32 - 1) * p.stride_meta_g + (int64_t)(p.N - 1) * p.stride_meta_n + 1) : 4, 0x00020000);
+    const uint32_t wvoff = (uint32_t)((n0 + c) * p.stride_wn + q * WB);
+    const uint32_t svoff = MXW ? (uint32_t)((n0 + c) * p.stride_meta_n + (int64_t)(q >> 1) * p.stride_meta_g) : 0u;
     uint32_t xvoff[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -1125,10 +1134,17 @@ __global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) 
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int D = MT == 1 ? 8 : (MT == 2 ? 4 : 2);  // chunks in flight per wave (16 + 32 MT bytes per lane each; 8 = all of K = 4096)
     u32x4 wb[D], xb[D][MT][2];
+    uint32_t sb[D];  // MXW: this lane's block scale of the chunk (e8m0 byte)
     const int mine = (nchunks - wave + 7) >> 3;  // chunks wave, wave + 8, ...
     auto load = [&](int slot, int i) __attribute__((always_inline)) {
         const int ch = wave + 8 * i;
-        wb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane(ch * 64), 0);
+        if constexpr (WB == 16) {
+            wb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane(ch * 64), 0);
+        } else {
+            const u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(rsW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane(ch * 32), 0);
+            wb[slot] = (u32x4){w2[0], w2[1], 0u, 0u};
+        }
+        if constexpr (MXW) sb[slot] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsS, svoff, (uint32_t)__builtin_amdgcn_readfirstlane(ch * 2 * (int)p.stride_meta_g), 0);
         const uint32_t xo = (uint32_t)__builtin_amdgcn_readfirstlane(ch * 128);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -1138,7 +1154,7 @@ __global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) 
     };
     // 8 weight bytes (two dwords) -> one B fragment: 8 values of the activation type
     auto convert = [&](uint32_t lo, uint32_t hi) __attribute__((always_inline)) -> u32x4 {
-        u32x4 f;
+        u32x4 f = {0u, 0u, 0u, 0u};
         const uint32_t d[2] = {lo, hi};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1157,7 +1173,7 @@ __global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) 
                     f[2 * h] = __builtin_bit_cast(uint32_t, a);
                     f[2 * h + 1] = __builtin_bit_cast(uint32_t, b);
                 }
-            } else {
+            } else if constexpr (!MXW) {
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
                 constexpr bool E5 = WDT == GEMLITE_DT_FP8E5;
                 const f32x2 a = E5 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)d[h], false) : __builtin_amdgcn_cvt_pk_f32_fp8((int)d[h], false);
@@ -1168,8 +1184,48 @@ __global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) 
         }
         return f;
     };
+    // block-scaled rows: 8 values (k = 8 h .. 8 h + 7 of the lane's 16) with the block scale applied by the converter
+    auto convert_mx = [&](int slot, int h) __attribute__((always_inline)) -> u32x4 {
+        const float sc = __builtin_bit_cast(float, sb[slot] << 23);  // e8m0 byte = the exponent field (0 -> 0.0: the quantisers floor at 2^-30)
+        u32x4 f;
+        if constexpr (WDT == A16_MXW8) {
+            const uint32_t d0 = wb[slot][2 * h], d1 = wb[slot][2 * h + 1];
+            if constexpr (TR::DT == GEMLITE_DT_FP16) {
+                f[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d0, sc, false));
+                f[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d0, sc, true));
+                f[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d1, sc, false));
+                f[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d1, sc, true));
+            } else {
+                f[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, sc, false));
+                f[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, sc, true));
+                f[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, sc, false));
+                f[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, sc, true));
+            }
+        } else {
+            const uint32_t d = wb[slot][h];  // 8 nibbles, k even in the low nibble
+            if constexpr (TR::DT == GEMLITE_DT_FP16) {
+                f[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(d, sc, 0));
+                f[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(d, sc, 1));
+                f[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(d, sc, 2));
+                f[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(d, sc, 3));
+            } else {
+                f[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(d, sc, 0));
+                f[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(d, sc, 1));
+                f[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(d, sc, 2));
+                f[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(d, sc, 3));
+            }
+        }
+        return f;
+    };
     auto mma = [&](int slot) __attribute__((always_inline)) {
-        const u32x4 b0 = convert(wb[slot][0], wb[slot][1]), b1 = convert(wb[slot][2], wb[slot][3]);
+        u32x4 b0, b1;
+        if constexpr (MXW) {
+            b0 = convert_mx(slot, 0);
+            b1 = convert_mx(slot, 1);
+        } else {
+            b0 = convert(wb[slot][0], wb[slot][1]);
+            b1 = convert(wb[slot][2], wb[slot][3]);
+        }
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             if constexpr (TR::DT == GEMLITE_DT_FP16) {
@@ -1204,16 +1260,24 @@ __global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) 
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[t][w][l][r];
         if (m < p.M) {
-            const float sc = p.w_mode == 2 ? load_as_float(p.scales, n, p.meta_dt) : 1.f;  // per-channel pre-scale: once, on the sum
+            const float sc = (!MXW && p.w_mode == 2) ? load_as_float(p.scales, n, p.meta_dt) : 1.f;  // per-channel pre-scale: once, on the sum
             epilogue_store(p.epi, v * sc, m, n);
         }
     }
 }
 
+// (block-scaled weight-only layers: input_dtype MXFP16 / MXBF16, W_nbits 8 (fp8 bytes) or 4 (two e2m1 codes per byte), group 32)
 bool plan_a16w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
-    if (a.elements_per_sample != 1 || a.M < 1 || a.M > 65535 * 64) return false;
-    if (!(a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_BF16)) return false;
-    if (!(a.w_dtype == GEMLITE_DT_INT8 || a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5)) return false;
+    const bool mx = a.input_dtype == GEMLITE_DT_MXFP16 || a.input_dtype == GEMLITE_DT_MXBF16;
+    if (a.M < 1 || a.M > 65535 * 64) return false;
+    if (mx) {
+        if (a.group_size != 32 || !a.scales || !(a.W_nbits == 8 || a.W_nbits == 4)) return false;
+        if ((int64_t)(a.K / 32) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    } else {
+        if (a.elements_per_sample != 1) return false;
+        if (!(a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_BF16)) return false;
+        if (!(a.w_dtype == GEMLITE_DT_INT8 || a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5)) return false;
+    }
     if (a.stride_wk != 1 || a.stride_xk != 1 || a.N % 16 != 0 || a.K % 64 != 0) return false;
     if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || (a.stride_xm * 2) % 16 != 0 || a.stride_wn % 16 != 0) return false;
     if (((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31) || (int64_t)a.N * a.stride_wn + a.K >= (1ll << 31)) return false;
@@ -1228,12 +1292,18 @@ bool plan_a16w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
     typedef std::integral_constant<int, GEMLITE_DT_INT8> I8;
     typedef std::integral_constant<int, GEMLITE_DT_FP8E4> F8;
     typedef std::integral_constant<int, GEMLITE_DT_FP8E5> B8;
-    const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
-    if (a.w_dtype == GEMLITE_DT_INT8) fn = f16 ? pick(half_tag{}, I8{}) : pick(bf16_tag{}, I8{});
+    const bool f16 = a.input_dtype == GEMLITE_DT_FP16 || a.input_dtype == GEMLITE_DT_MXFP16;
+    typedef std::integral_constant<int, A16_MXW8> M8;
+    typedef std::integral_constant<int, A16_MXW4> M4;
+    if (mx) fn = a.W_nbits == 8 ? (f16 ? pick(half_tag{}, M8{}) : pick(bf16_tag{}, M8{})) : (f16 ? pick(half_tag{}, M4{}) : pick(bf16_tag{}, M4{}));
+    else if (a.w_dtype == GEMLITE_DT_INT8) fn = f16 ? pick(half_tag{}, I8{}) : pick(bf16_tag{}, I8{});
     else if (a.w_dtype == GEMLITE_DT_FP8E4) fn = f16 ? pick(half_tag{}, F8{}) : pick(bf16_tag{}, F8{});
     else fn = f16 ? pick(half_tag{}, B8{}) : pick(bf16_tag{}, B8{});
     lp.fn = (const void*)fn;
-    lp.name = mt == 1 ? "a16w8_rows_kernel<16x16>" : (mt == 2 ? "a16w8_rows_kernel<32x16>" : "a16w8_rows_kernel<64x16>");
+    static const char* names[3][3] = {{"a16w8_rows_kernel<16x16>", "a16w8_rows_kernel<32x16>", "a16w8_rows_kernel<64x16>"},
+                                      {"a16w8_mxfp_rows_kernel<16x16>", "a16w8_mxfp_rows_kernel<32x16>", "a16w8_mxfp_rows_kernel<64x16>"},
+                                      {"a16w4_mxfp_rows_kernel<16x16>", "a16w4_mxfp_rows_kernel<32x16>", "a16w4_mxfp_rows_kernel<64x16>"}};
+    lp.name = names[mx ? (a.W_nbits == 8 ? 1 : 2) : 0][mt == 1 ? 0 : (mt == 2 ? 1 : 2)];
     lp.grid = dim3((unsigned)(a.N / 16), (unsigned)((a.M + 16 * mt - 1) / (16 * mt)), 1);
     lp.block = dim3(512, 1, 1);
     lp.lds_bytes = 0;

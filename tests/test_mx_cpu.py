@@ -160,7 +160,13 @@ def test_c_abi_routes_block_scaled_formats():
     a.tuning[0] = 5                                                       # A/B switch: the streaming kernel of rounds 2-3 (up to 4 rows)
     assert name(a) == "mx_gemv_w8_kernel"
     assert name(args(16, 8, 1, 4, K=4096 + 32)) == "mx_gemv_w8_kernel"   # K % 128 != 0
-    assert name(args(14, 8, 1, 0)) == "mx_gemv_w8_kernel"                # 16-bit activations x MX weights
+    assert name(args(14, 8, 1, 0)) == "a16w8_mxfp_rows_kernel<16x16>"    # round 4: 16-bit activations x MX weights, 1 .. 64 rows: the A16W8 rows kernel
+    assert name(args(15, 4, 40, 0)) == "a16w4_mxfp_rows_kernel<64x16>"
+    assert name(args(14, 8, 1, 0, K=4096 + 32)) == "mx_gemv_w8_kernel"   # K % 64 != 0: the streaming kernel
+    a = args(14, 8, 1, 0)
+    a.tuning[0] = 5
+    assert name(a) == "mx_gemv_w8_kernel"
+    assert name(args(15, 8, 100, 0)) == "gemm_a16w8_mxfp_kernel<64x128>"     # above 64 rows: the tile kernel (bf16 x, bf16 out)
     assert name(args(17, 4, 300, 4, K=11008)) == "mx_rows_a4w4_kernel<64x16>"   # fp4 activations, K % 512 != 0: no tile kernel -> 64-row tiles of the few-row kernel
     assert name(args(17, 4, 300, 4, K=4096)) == "gemm_mx_a4w4_kernel<128x128>"
     assert name(args(16, 8, 5, 4)) == "mx_rows_a8w8_kernel<16x16>"       # round 4: 5 .. 64 rows, 16-column blocks

@@ -163,12 +163,21 @@ def test_processor_forward_vs_oracle(proc, tdt):
         want = EXPECT[proc] if (M > 4 or "NVFP" in proc) else "mx_gemv_w"
         if M <= 64 and "dynamic" in proc and "NVFP" not in proc:
             want = "mx_rows_"  # round 4: 1 .. 64 rows of the fp8 / fp4 activation formats
+        if M <= 64 and proc.startswith("A16"):
+            want = "a16w8_mxfp_rows_kernel" if "W8" in proc else "a16w4_mxfp_rows_kernel"  # round 4: the weight-only layers on the A16W8 rows kernel
         assert name.startswith(want), (proc, M, name)
         y = layer(x)
         assert y.dtype == tdt and tuple(y.shape) == (M, N)
         ref = _oracle(layer, x) + bias.float().cpu().numpy().astype(np.float64)
         _check(f"{proc} {tdt} M={M} {name}", y, ref, tdt)
         if M <= 4 and "dynamic" in proc and "NVFP" not in proc:  # the streaming kernel of rounds 2-3 (A/B switch) gives the same answer
+            try:
+                C.TUNING_OVERRIDE = (5, 0, 0, 0)
+                assert _kernel_name(layer, x, (5, 0, 0, 0)).startswith("mx_gemv_w")
+                _check(f"{proc} {tdt} M={M} gemv", layer(x), ref, tdt)
+            finally:
+                C.TUNING_OVERRIDE = None
+        if M <= 4 and proc.startswith("A16"):  # the streaming kernel of rounds 2-3 (A/B switch) gives the same answer
             try:
                 C.TUNING_OVERRIDE = (5, 0, 0, 0)
                 assert _kernel_name(layer, x, (5, 0, 0, 0)).startswith("mx_gemv_w")
@@ -279,6 +288,38 @@ def test_one_row_is_quantised_inside_the_few_row_kernel(proc, tdt):
             torch.cuda.synchronize()
             assert y_fused.shape == y_two.shape and torch.equal(y_fused, y_two), (proc, tdt, N, K, shape, float((y_fused.float() - y_two.float()).abs().max()))
         _check(f"{proc} fused M=1 {name}", layer(x).reshape(1, N), _oracle(layer, x.reshape(1, K)), tdt)
+
+
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("proc", ["A16W8_MXFP", "A16W4_MXFP"])
+def test_weight_only_block_scaled_layers_on_the_rows_kernel(proc, tdt):
+    """A16W8_MXFP / A16W4_MXFP (helper.py:372-400) for 1 .. 64 rows on a16w8_rows_kernel<MXW8 / MXW4> (round 4): fp8 / fp4 weights turned
+    into the activation type by the scaled converters (the e8m0 block scale applied exactly), two v_mfma_f32_16x16x32 per 64-k chunk;
+    every row-tile height with ragged M, K an odd multiple of 64, against the float64 oracle and against the tile kernel it replaces."""
+    N, K = 256, 1088
+    lin = _linear(N, K, tdt, seed=27)
+    bias = lin.bias.data.float().cpu().numpy().astype(np.float64)
+    layer = PROCS[proc](tdt).from_linear(lin, del_orig=False)
+    g = torch.Generator().manual_seed(23)
+    for M in (1, 3, 16, 17, 32, 50, 64):
+        x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
+        ref = _oracle(layer, x) + bias
+        name = _kernel_name(layer, x)
+        assert name.startswith("a16w8_mxfp_rows_kernel" if "W8" in proc else "a16w4_mxfp_rows_kernel") and \
+            name.endswith("<16x16>" if M <= 16 else ("<32x16>" if M <= 32 else "<64x16>")), (M, name)
+        y = layer(x)
+        _check(f"{proc} rows M={M} {name}", y, ref, tdt)
+    x = (torch.randn(40, 1152, generator=g) / 4).to(tdt).to(DEV)  # K % 128 == 0: the tile kernel applies (A/B switch)
+    lin2 = _linear(N, 1152, tdt, seed=28)
+    lin2.bias = None
+    layer2 = PROCS[proc](tdt).from_linear(lin2, del_orig=False)
+    y_rows = layer2(x)
+    try:
+        C.TUNING_OVERRIDE = (2, 0, 0, 0)
+        assert _kernel_name(layer2, x, (2, 0, 0, 0)).startswith("gemm_a16w")
+        _check(f"{proc} rows vs tile kernel", y_rows, layer2(x).float().cpu().numpy(), tdt)
+    finally:
+        C.TUNING_OVERRIDE = None
 
 
 def test_fp4_activations_with_k_not_a_multiple_of_512_leave_the_coverage_kernel():
