@@ -352,9 +352,13 @@ bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     const int e = 32 / nbits;
     if (a.M > 32) return false;
     if (a.output_dtype != a.input_dtype) return false;  // typed epilogue / metadata
-    const bool uses_s = a.W_group_mode >= 2 || a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    // metadata read in the K loop: the kernel's 16-bit type; channel scales of the epilogue alone: any float type (store_out_t; round 4:
+    // BitNet's fp32 scale, A16W158_INT)
+    const bool loop_s = a.W_group_mode >= 2, post_s = a.channel_scale_mode == 1 || a.channel_scale_mode == 3;
+    const bool uses_s = loop_s;
     const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
-    if (uses_s && a.meta_dtype != a.input_dtype) return false;
+    if (loop_s && a.meta_dtype != a.input_dtype) return false;
+    if (post_s && !loop_s && a.meta_dtype != a.input_dtype && a.meta_dtype != GEMLITE_DT_FP32 && a.meta_dtype != GEMLITE_DT_FP16 && a.meta_dtype != GEMLITE_DT_BF16) return false;
     if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
     if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte x loads
