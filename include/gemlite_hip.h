@@ -124,9 +124,15 @@ typedef struct gemlite_hip_forward_args {
                            * channel_scale_mode 2/3, 16-bit float x and unpacked int8 / fp8 weights asks for
                            * the FUSED dynamic quantisation: x is quantised per token inside the matmul launch
                            * (same arithmetic as gemlite_hip_scale_activations_per_token, one launch instead of two).
-                           * M == 1: always available.  M >= 2: the blocks of the launch deal the rows among themselves
-                           * (needs the workspace: flags + M*K bytes + M floats); GEMLITE_ERR_NO_FUSED_QUANT where no such
-                           * kernel applies (gemlite_hip_query() answers without launching). */
+                           * M == 1: always available.  2 <= M <= 64: producer blocks of the launch quantise the rows
+                           * (needs the workspace: flags + M*K bytes + M floats; measured slower than two launches, the
+                           * Python host does not use it by default); GEMLITE_ERR_NO_FUSED_QUANT where no such kernel
+                           * applies (gemlite_hip_query() answers without launching).
+                           * The same request exists at M == 1 for the layers whose activation format cannot be read off
+                           * the weights — PACKED weights under fp8 / int8 activations (A8Wn dynamic, BitNet) and the
+                           * block-scaled MXFP8 / MXFP4 layers (channel_scale_mode 4: block scales; 2: one scale per
+                           * token): input_dtype names the type of the 16-bit x that is passed, the layer's activation
+                           * format rides in type_id (= its DType code * 100 + W_nbits), scales_x is NULL. */
     void* out;            /* [M, N] output_dtype                                           */
     void* workspace;      /* >= gemlite_hip_workspace_bytes(); zero-filled ONCE by the owner */
     uint64_t workspace_bytes;
