@@ -297,7 +297,7 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
     a.matmul_type = matmul_type
     a.x, a.out, a.M = x.data_ptr(), out.data_ptr(), M
     raw_mx = (mx and fused_quant_optional and scales_x is None and x.dtype in (torch.float16, torch.bfloat16) and
-              meta_args[5] in (DType.MXFP8.value, DType.MXFP4.value))
+              meta_args[5] in (DType.MXFP8.value, DType.MXFP4.value, DType.NVFP4.value))
     if raw_mx:  # one unquantised row of a block-scaled dynamic layer: the kernel quantises it (the layer's format rides in type_id)
         a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
     elif mx:  # the layer's format pair names what x holds (include/gemlite_hip.h "Block-scaled formats")
@@ -361,7 +361,7 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
         # block-scaled activations (core.py:165-175): microscales (channel_scale_mode 4) or one fp32 scale per token (2)
         c_mode = meta_args[9]
         K_ = x.shape[-1]
-        if FUSE_ACT_QUANT_M1 and ((c_mode == 4 and in_code in (DType.MXFP8.value, DType.MXFP4.value)) or (c_mode == 2 and in_code == DType.MXFP8.value)) and \
+        if FUSE_ACT_QUANT_M1 and ((c_mode == 4 and in_code in (DType.MXFP8.value, DType.MXFP4.value, DType.NVFP4.value)) or (c_mode == 2 and in_code == DType.MXFP8.value)) and \
                 x.numel() == K_ and matmul_type < 0 and \
                 TUNING_OVERRIDE is None and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.data_ptr() % 16 == 0:
             # ONE row: the few-row kernel quantises it block by block itself (round 4; bit-identical to quantiser + matmul); where the

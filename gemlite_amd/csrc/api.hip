@@ -35,6 +35,7 @@ bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, Laun
 const void* mx_generic_kernel_fn();
 const void* act_quant_mx_kernel_fn(int mode);
 bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp, bool any_m = false, bool fq = false);
+bool plan_nvfp4_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp, bool fq = false);
 const void* nvfp4_expand_f16_kernel_fn();
 const void* generic_kernel_fn();
 const void* kmajor_kernel_fn(int mb);
@@ -120,7 +121,7 @@ static int fused_quant_mx_dtype(const gemlite_hip_forward_args* a) {
     if (!(a->input_dtype == GEMLITE_DT_FP16 || a->input_dtype == GEMLITE_DT_BF16)) return 0;
     const int layer_dt = a->type_id / 100;
     if (a->channel_scale_mode == 2 && layer_dt != GEMLITE_DT_MXFP8) return 0;  // one fp32 scale per token: fp8 activations
-    return (layer_dt == GEMLITE_DT_MXFP8 || layer_dt == GEMLITE_DT_MXFP4) && a->type_id % 100 == a->W_nbits ? layer_dt : 0;
+    return (layer_dt == GEMLITE_DT_MXFP8 || layer_dt == GEMLITE_DT_MXFP4 || layer_dt == GEMLITE_DT_NVFP4) && a->type_id % 100 == a->W_nbits ? layer_dt : 0;
 }
 
 static bool is_mx_input(int dt) { return dt >= GEMLITE_DT_MXFP16 && dt <= GEMLITE_DT_NVFP4; }
@@ -243,6 +244,8 @@ static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, cons
     }
     // fp8 / fp4 activations that no tile kernel took (K % 512 != 0 with fp4 activations ...): the few-row kernel over 64-row tiles
     if (a.tuning[0] == 0 && plan_mx_rows(a, r.gp, r.lp, true)) { r.kind = K_KMAJOR; return; }
+    // NVFP4, 1 .. 64 rows (round 4): 16-column blocks, both operands expanded to fp16 in registers (tuning[0] = 2 keeps the tile kernel)
+    if ((a.tuning[0] == 0 || a.tuning[0] == 4) && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_nvfp4_rows(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
     // NVFP4 (round 4): both operands are exact in fp16 — x is expanded into the workspace by a small kernel in front, the weights in
     // the K loop of the fp16 MFMA tile kernel (Geo<NVW4>), the layer's constant output factor rides as a per-row scale.  Two launches
     // inside this call.  tuning[0] = 1 keeps the coverage kernel.
@@ -302,10 +305,10 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         b.x = (const void*)(uintptr_t)0x1000;
         b.scales_x = (const void*)(uintptr_t)0x1000;
         b.stride_xm = mxdt == GEMLITE_DT_MXFP8 ? a.K : a.K / 2;
-        b.stride_sx_m = a.K / 32;
+        b.stride_sx_m = mxdt == GEMLITE_DT_NVFP4 ? a.K / 16 : a.K / 32;
         GenericParams g = mx_params(b);
         LaunchPlan lp{};
-        if (!plan_mx_rows(b, g, lp, false, true)) return;
+        if (!(mxdt == GEMLITE_DT_NVFP4 ? plan_nvfp4_rows(b, g, lp, true) : plan_mx_rows(b, g, lp, false, true))) return;
         g.x = a.x;                 // the raw row
         g.x_dt = a.input_dtype;    // ... and its type
         g.sx_blocks = a.channel_scale_mode == 4 ? a.x : nullptr;  // (non-null: block-scaled activations)

@@ -635,6 +635,171 @@ bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPla
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// NVFP4 x NVFP4, few rows (round 4): the rows shape with BOTH operands expanded in registers.  An e2m1 code times its e4m3 block-16 scale is
+// exact in fp16 (nvfp4_expand_f16_kernel above), a lane's 16 k of a 64-k chunk are exactly ONE block of either operand, so lane (c, q)
+// loads 8 code bytes + 1 scale byte of weight row n0 + c and of x row c (+ 16 t), converts each to 16 fp16 values (v_cvt_scalef32_pk_f16_fp4
+// at scale 1 + v_pk_mul_f16 by the block scale) and issues two v_mfma_f32_16x16x32_f16 per row tile.  The layer's constant 0.05^2 multiplies
+// the fp32 sum.  FQ (one row): p.x is the unquantised 16-bit row, quantised per 16-k block into LDS first (mx_quant_block<2>: the arithmetic
+// of the NVFP4 quantiser kernel) under the weight round trip.  The 32-row tile of gemm_nvfp4_f16_kernel took 15-17 us at these sizes.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MT, bool FQ>
+__global__ __launch_bounds__(512) void nvfp4_rows_kernel(const GenericParams p) {
+    static_assert(!FQ || MT == 1, "in-launch activation quantisation: one row");
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+    __shared__ __attribute__((aligned(16))) float red[MT][8][64][4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];  // FQ: [K / 2 code bytes][K / 16 scale bytes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const int mbase = (int)blockIdx.y * (16 * MT);
+    const int nchunks = p.K / 64, blocks_k = p.K / 16, row_bytes = p.K / 2;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)((int64_t)(p.N - 1) * p.stride_wn + row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.scales, (short)0, (int)((int64_t)(blocks_k - 1) * p.stride_meta_g + (int64_t)(p.N - 1) * p.stride_meta_n + 1), 0x00020000);
+    const int m_pad = (p.M + 15) / 16 * 16;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(FQ ? p.w : p.x), (short)0, FQ ? 4 : (int)((int64_t)(p.M - 1) * p.stride_xm + row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(FQ ? p.w : p.sx_blocks), (short)0, FQ ? 4 : (int)((int64_t)(m_pad - 1) * p.stride_sx_blk_m + blocks_k), 0x00020000);
+    const uint32_t wvoff = (uint32_t)((n0 + c) * p.stride_wn + q * 8);
+    const uint32_t svoff = (uint32_t)((n0 + c) * p.stride_meta_n + (int64_t)q * p.stride_meta_g);
+    uint32_t xvoff[MT], avoff[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = mbase + c + 16 * t;
+        xvoff[t] = m < p.M ? (uint32_t)((int64_t)m * p.stride_xm + q * 8) : 0x80000000u;  // rows >= M: zeros
+        avoff[t] = m < p.M ? (uint32_t)((int64_t)m * p.stride_sx_blk_m + q) : 0x80000000u;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int D = MT == 1 ? 8 : (MT == 2 ? 6 : 4);  // chunks in flight per wave (8 + 8 MT bytes per lane each)
+    struct Chunk { u32x2 w; uint32_t sw; u32x2 x[MT]; uint32_t sx[MT]; };
+    Chunk ring[D];
+    const int mine = (nchunks - wave + 7) >> 3;
+    auto load_w = [&](int slot, int i) __attribute__((always_inline)) {
+        const int ch = wave + 8 * i;
+        ring[slot].w = __builtin_amdgcn_raw_buffer_load_b64(rsW, wvoff, (uint32_t)__builtin_amdgcn_readfirstlane(ch * 32), 0);
+        ring[slot].sw = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsS, svoff, (uint32_t)__builtin_amdgcn_readfirstlane(ch * 4 * (int)p.stride_meta_g), 0);
+    };
+    auto load_x = [&](int slot, int i) __attribute__((always_inline)) {
+        const int ch = wave + 8 * i;
+        if constexpr (FQ) {
+            const u32x2 zero = {0u, 0u};
+            ring[slot].x[0] = c == 0 ? *(const u32x2*)(xlds + ch * 32 + q * 8) : zero;
+            ring[slot].sx[0] = c == 0 ? (uint32_t)xlds[row_bytes + ch * 4 + q] : 0u;
+            return;
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            ring[slot].x[t] = __builtin_amdgcn_raw_buffer_load_b64(rsX, xvoff[t], (uint32_t)__builtin_amdgcn_readfirstlane(ch * 32), 0);
+            ring[slot].sx[t] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, avoff[t], (uint32_t)__builtin_amdgcn_readfirstlane(ch * 4), 0);
+        }
+    };
+    // 8 code bytes + the e4m3 block scale -> 16 fp16 values (two MFMA operands of 8)
+    auto expand = [&](u32x2 codes, uint32_t sbyte, u32x4& lo, u32x4& hi) __attribute__((always_inline)) {
+        const _Float16 hs = (_Float16)__builtin_amdgcn_cvt_f32_fp8((int)sbyte, 0);
+        const h2v s2 = {hs, hs};
+        lo[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[0], 1.0f, 0) * s2);
+        lo[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[0], 1.0f, 1) * s2);
+        lo[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[0], 1.0f, 2) * s2);
+        lo[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[0], 1.0f, 3) * s2);
+        hi[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[1], 1.0f, 0) * s2);
+        hi[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[1], 1.0f, 1) * s2);
+        hi[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[1], 1.0f, 2) * s2);
+        hi[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes[1], 1.0f, 3) * s2);
+    };
+    auto mma = [&](int slot) __attribute__((always_inline)) {
+        const Chunk& k = ring[slot];
+        u32x4 b0, b1;
+        expand(k.w, k.sw, b0, b1);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            u32x4 a0, a1;
+            expand(k.x[t], k.sx[t], a0, a1);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a0), __builtin_bit_cast(h8v, b0), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a1), __builtin_bit_cast(h8v, b1), acc[t], 0, 0, 0);
+        }
+    };
+    if constexpr (FQ) {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < mine) load_w(j, j);
+        const uint16_t* xr = (const uint16_t*)p.x;
+        const bool f16 = p.x_dt == GEMLITE_DT_FP16;
+        for (int b = tid; b < blocks_k; b += 512) {  // thread = one 16-k block: 32 bytes in, 8 code bytes + the scale byte out
+            float v[16];
+            float amax = 0.f;
+#pragma unroll
+            for (int qd = 0; qd < 2; ++qd) {
+                const u32x4 d = *(const u32x4*)(xr + b * 16 + 8 * qd);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint16_t hb = (uint16_t)(d[e >> 1] >> (16 * (e & 1)));
+                    v[8 * qd + e] = f16 ? F16Traits<half_tag>::to_float(hb) : F16Traits<bf16_tag>::to_float(hb);
+                    amax = fmaxf(amax, fabsf(v[8 * qd + e]));
+                }
+            }
+            uint32_t o[8];
+            xlds[row_bytes + b] = mx_quant_block<2>(v, amax, o);
+            *(u32x2*)(xlds + b * 8) = (u32x2){o[0], o[1]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < mine) load_x(j, j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < mine) { load_w(j, j); load_x(j, j); }
+    }
+    for (int base = 0; base < mine; base += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (base + j < mine) {
+                mma(j);
+                if (base + j + D < mine) { load_w(j, base + j + D); load_x(j, base + j + D); }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *(f32x4*)&red[t][wave][lane][0] = acc[t];
+    __syncthreads();
+    for (int u = tid; u < MT * 256; u += 512) {
+        const int t = u >> 8, l = u & 63, r = (u >> 6) & 3;
+        const int m = mbase + 16 * t + 4 * (l >> 4) + r;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[t][w][l][r];
+        if (m < p.M) epilogue_store(p.epi, v * p.mx_post, m, n0 + (l & 15));
+    }
+}
+
+// NVFP4 layers, 1 <= M <= 64 (x re-read budget like the other rows kernels); fq: one row, the quantiser inside
+bool plan_nvfp4_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp, bool fq) {
+    if (!g.mx_scale_e4m3 || g.group_size != 16 || g.mx_x != MX_FP4 || g.mx_w != MX_FP4) return false;
+    if (a.M < 1 || a.M > 64 || (fq && (a.M != 1 || a.K > 65536))) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.K % 64 != 0 || a.N % 16 != 0) return false;
+    if (((uintptr_t)a.w_q % 8) != 0 || a.stride_wn % 8 != 0) return false;
+    if (!fq && (((uintptr_t)a.x % 8) != 0 || a.stride_xm % 8 != 0)) return false;
+    if ((int64_t)a.M * a.stride_xm + a.K >= (1ll << 31) || (int64_t)a.N * a.stride_wn + a.K >= (1ll << 31)) return false;
+    if ((int64_t)(a.K / 16) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    if (mt > 1 && a.tuning[0] != 4 && (int64_t)a.M * (a.K / 2) * (a.N / 16) > (88ll << 20)) return false;
+    typedef void (*fn_t)(const GenericParams);
+    fn_t fn = fq ? nvfp4_rows_kernel<1, true> : (mt == 1 ? nvfp4_rows_kernel<1, false> : (mt == 2 ? nvfp4_rows_kernel<2, false> : nvfp4_rows_kernel<4, false>));
+    lp.fn = (const void*)fn;
+    lp.name = fq ? "nvfp4_rows_fused_quant_kernel<16x16>" : (mt == 1 ? "nvfp4_rows_kernel<16x16>" : (mt == 2 ? "nvfp4_rows_kernel<32x16>" : "nvfp4_rows_kernel<64x16>"));
+    lp.grid = dim3((unsigned)(a.N / 16), 1, 1);
+    lp.block = dim3(512, 1, 1);
+    lp.lds_bytes = fq ? (size_t)(a.K / 2 + a.K / 16 + 16) : 0;
+    lp.ws_bytes = 0;
+    lp.slab_bytes = 0;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // scaled-MFMA kernel.  AF / BF: element format of x / w as the instruction's cbsz / blgp code (0 = fp8 e4m3, 4 = fp4 e2m1).
 // A K step moves 256 BYTES of every x row (256 k of fp8, 512 k of fp4); wave (cg, kh) owns all rows x 32 columns x the
 // kh-th half of the step = NS slices of 64 k.  Per slice and lane: A fragment = 16 (fp4) or 2 x 16 (fp8) bytes read from

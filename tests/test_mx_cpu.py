@@ -180,14 +180,17 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(args(17, 4, 40, 4, N=16384)) == "mx_rows_a4w4_kernel<64x16>"
     # NVFP4: no scaled-MFMA form takes e4m3 block-16 scales; both operands are exact in fp16, so the fp16 tile kernel runs it (round 4:
     # x expanded by a kernel in front, the weights in the K loop; workspace = tickets + slabs + M K fp16 + M floats)
-    assert name(args(18, 4, 8, 4, group=16)) == "gemm_nvfp4_f16_kernel<32x128>"
+    assert name(args(18, 4, 8, 4, group=16)) == "nvfp4_rows_kernel<16x16>"   # 1 .. 64 rows: both operands expanded in registers
+    assert name(args(18, 4, 40, 4, group=16)) == "nvfp4_rows_kernel<64x16>"
     assert name(args(18, 4, 256, 4, group=16)) == "gemm_nvfp4_f16_kernel<64x128>"
     a = args(18, 4, 8, 4, group=16)
+    a.tuning[0] = 2                                                       # A/B switch: the tile kernel at any M
+    assert name(a) == "gemm_nvfp4_f16_kernel<32x128>"
     assert lib.gemlite_hip_workspace_bytes(C.byref(a)) >= 65536 * 4 + 8 * 4096 * 2 + 256
     a.tuning[0] = 1
     assert name(a) == "mx_generic_kernel"                                 # A/B switch: the coverage kernel of rounds 2-3
-    a = args(18, 4, 8, 4, group=16, N=4096 + 64)
-    assert name(a) == "mx_generic_kernel"                                 # N % 128 != 0
+    assert name(args(18, 4, 8, 4, group=16, N=4096 + 64)) == "nvfp4_rows_kernel<16x16>"   # the rows kernel only needs N % 16 == 0
+    assert name(args(18, 4, 300, 4, group=16, N=4096 + 64)) == "mx_generic_kernel"        # above 64 rows with N % 128 != 0: coverage
     assert lib.gemlite_hip_query(C.byref(args(18, 4, 8, 4, group=32))) == _hip.ERR_UNSUPPORTED
     assert lib.gemlite_hip_query(C.byref(args(17, 8, 8, 4))) == _hip.ERR_UNSUPPORTED  # fp4 activations x fp8 weights
     a = args(16, 8, 64, 4)

@@ -163,6 +163,8 @@ def test_processor_forward_vs_oracle(proc, tdt):
         want = EXPECT[proc] if (M > 4 or "NVFP" in proc) else "mx_gemv_w"
         if M <= 64 and "dynamic" in proc and "NVFP" not in proc:
             want = "mx_rows_"  # round 4: 1 .. 64 rows of the fp8 / fp4 activation formats
+        if M <= 64 and "NVFP" in proc:
+            want = "nvfp4_rows_"  # round 4: both operands expanded to fp16 in registers, two v_mfma_f32_16x16x32_f16 per chunk and 16 rows
         if M <= 64 and proc.startswith("A16"):
             want = "a16w8_mxfp_rows_kernel" if "W8" in proc else "a16w4_mxfp_rows_kernel"  # round 4: the weight-only layers on the A16W8 rows kernel
         assert name.startswith(want), (proc, M, name)
@@ -258,7 +260,7 @@ def test_few_row_scaled_mfma_kernel(proc):
 
 
 @pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("proc", ["A8W8_MXFP_dynamic", "A8W4_MXFP_dynamic", "A4W4_MXFP_dynamic", "A8W8_MXFP_dynamic_post", "A8W4_MXFP_dynamic_post"])
+@pytest.mark.parametrize("proc", ["A8W8_MXFP_dynamic", "A8W4_MXFP_dynamic", "A4W4_MXFP_dynamic", "A8W8_MXFP_dynamic_post", "A8W4_MXFP_dynamic_post", "A4W4_NVFP_dynamic"])
 def test_one_row_is_quantised_inside_the_few_row_kernel(proc, tdt):
     """M = 1 of the block-scaled dynamic layers: `layer(x)` is ONE launch — mx_rows_kernel<..., FQ> requests its weights, quantises the row
     block by block into LDS (mx_quant_block = the arithmetic of the quantiser kernel; `_post`: one fp32 scale per token, the processors'
@@ -278,7 +280,7 @@ def test_one_row_is_quantised_inside_the_few_row_kernel(proc, tdt):
             a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = K, 1, N, 1
             a.input_dtype = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
             name = _hip.load().gemlite_hip_kernel_name(_hip.C.byref(a)).decode()
-            assert name.startswith("mx_rows_") and "fused_quant" in name, name
+            assert name.startswith(("mx_rows_", "nvfp4_rows_")) and "fused_quant" in name, name
             y_fused = layer(x)
             C.FUSE_ACT_QUANT_M1 = False
             try:
@@ -320,6 +322,30 @@ def test_weight_only_block_scaled_layers_on_the_rows_kernel(proc, tdt):
         _check(f"{proc} rows vs tile kernel", y_rows, layer2(x).float().cpu().numpy(), tdt)
     finally:
         C.TUNING_OVERRIDE = None
+
+
+def test_nvfp4_few_row_kernel_against_the_oracle_and_the_tile_kernel():
+    """nvfp4_rows_kernel: every row-tile height with ragged M, K an odd multiple of 64 (no tile kernel there: K % 128 != 0), bf16 and fp16
+    layers; against the float64 oracle, and where both apply against gemm_nvfp4_f16_kernel (tuning[0] = 2)."""
+    for tdt in (torch.bfloat16, torch.float16):
+        for N, K in ((256, 1088), (256, 1152)):
+            lin = _linear(N, K, tdt, seed=33)
+            bias = lin.bias.data.float().cpu().numpy().astype(np.float64)
+            layer = PROCS["A4W4_NVFP_dynamic"](tdt).from_linear(lin, del_orig=False)
+            g = torch.Generator().manual_seed(29)
+            for M in (2, 16, 17, 32, 50, 64):
+                x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
+                name = _kernel_name(layer, x)
+                assert name == "nvfp4_rows_kernel<%s>" % ("16x16" if M <= 16 else ("32x16" if M <= 32 else "64x16")), (M, name)
+                y = layer(x)
+                _check(f"nvfp4 rows {tdt} K={K} M={M}", y, _oracle(layer, x) + bias, tdt)
+                if K % 128 == 0:
+                    try:
+                        C.TUNING_OVERRIDE = (2, 0, 0, 0)
+                        assert _kernel_name(layer, x, (2, 0, 0, 0)).startswith("gemm_nvfp4_f16_kernel")
+                        _check(f"nvfp4 rows vs tile M={M}", y, layer(x).float().cpu().numpy(), tdt)
+                    finally:
+                        C.TUNING_OVERRIDE = None
 
 
 def test_fp4_activations_with_k_not_a_multiple_of_512_leave_the_coverage_kernel():
