@@ -42,6 +42,7 @@ const void* kmajor_kernel_fn(int mb);
 const void* kmajor_w8a16_kernel_fn(int mb);
 const void* kmajor_fused_quant_kernel_fn(int qdt);
 const void* a8w8_decode_kernel_fn(int qdt, bool fused);
+const void* a16w8_decode_kernel_fn(int x_dt, int w_dt);
 const void* act_quant_kernel_fn();
 const void* act_quant_vec_kernel_fn(int in_dt, int out_dt, int64_t K, int64_t stride_xm, const void* x, const void* y);
 const void* pack_kernel_fn();
@@ -545,6 +546,15 @@ coverage:
         (a.w_dtype == GEMLITE_DT_INT8 || a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5) &&
         a.K % 16 == 0 && a.stride_wn % 16 == 0 && (a.stride_xm * 2) % 16 == 0 && (((uintptr_t)a.w_q | (uintptr_t)a.x) % 16 == 0)) {
         r.kind = K_KMAJOR;
+        // round 4, one row: a wave per column, the weight row in flight before x is staged (tuning[0] = 4 keeps the rows kernel)
+        if (a.M == 1 && a.tuning[0] == 0 && a.K % 1024 == 0 && a.K <= 30720 && a.N % 16 == 0) {
+            r.lp.fn = a16w8_decode_kernel_fn(a.input_dtype, a.w_dtype);
+            r.lp.name = "a16w8_decode_kernel<tile16,16w>";
+            r.lp.grid = dim3((unsigned)(a.N / 16), 1, 1);
+            r.lp.block = dim3(1024, 1, 1);
+            r.lp.lds_bytes = (size_t)a.K * 2;
+            return;
+        }
         // round 4: 16-column blocks, weights converted in registers, MFMA (tuning[0] = 7 keeps the streaming kernel of rounds 1-3)
         if (a.tuning[0] != 7 && plan_a16w8_rows(a, r.lp)) return;
         const int mb = a.M == 1 ? 1 : 4;

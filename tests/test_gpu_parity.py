@@ -664,7 +664,7 @@ def test_remaining_helper_processors_against_the_oracle(M):
                       ("a16w8-fp8", H.A16W8_FP8(device=DEV).from_weights(W))):
         y = lin(x)
         torch.cuda.synchronize()
-        assert _kernel_name(lin, x).startswith("a16w8_rows_kernel"), _kernel_name(lin, x)
+        assert _kernel_name(lin, x).startswith(("a16w8_rows_kernel", "a16w8_decode_kernel")), _kernel_name(lin, x)
         _compare(f"helpers/{name}/M{M}", y, _oracle_from_layer(lin, x), 1, abs_gate=5e-3, extra=dict(kernel=_kernel_name(lin, x)))
     W_q, sc, zr = O.gen_data(N, K, 4, 128, seed=3)
     Wt = torch.randint(-1, 2, (N, K)).half()
@@ -1030,6 +1030,17 @@ def test_a16w8_rows_kernel_against_the_oracle_and_the_streaming_kernel(proc, tdt
           "A16W8_FP8": lambda: H.A16W8_FP8(device=DEV, dtype=tdt)}[proc]
     lin = mk().from_weights(W)
     out_code = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+    # one row, K % 1024 == 0: a16w8_decode_kernel (a wave per column, weights first, x through LDS) — against the oracle and the rows kernel
+    for K1 in (2048, 9216):
+        W1 = (torch.randn(512, K1) / 30).to(tdt)
+        lin1 = mk().from_weights(W1)
+        x1 = (torch.randn(1, K1, device=DEV) / 10).to(tdt)
+        assert _kernel_name(lin1, x1) == "a16w8_decode_kernel<tile16,16w>", _kernel_name(lin1, x1)
+        y1 = lin1(x1)
+        y1_rows = _hip_matmul(x1, lin1.W_q, lin1.scales, lin1.zeros, None, lin1.get_meta_args(), -1, (4, 0, 0, 0))
+        torch.cuda.synchronize()
+        _compare(f"a16w8-decode/{proc}/{str(tdt)[6:]}/K{K1}", y1, _oracle_from_layer(lin1, x1), out_code, abs_gate=5e-3)
+        assert float((y1.float() - y1_rows.float()).abs().mean() / y1_rows.float().abs().mean()) < (2e-3 if tdt == torch.float16 else 8e-3)
     for M in (1, 2, 16, 17, 33, 64, 65, 200):
         x = (torch.randn(M, K, device=DEV) / 10).to(tdt)
         name = _kernel_name(lin, x)

@@ -185,7 +185,9 @@ def test_struct_abi_and_validation():
     (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<256x128>"),  # config 5: 128 tiles x 2 slices of a long K
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(2, 0, 0, 0)), "gemm_a8w8_kernel<64x64>"),  # round-1 kernel
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(1, 0, 0, 0)), "kmajor_matmul_kernel"),
-    (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<16x16>"),   # A16W8 int8, pre-scale (round 4: MFMA, weights converted in registers)
+    (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_decode_kernel<tile16,16w>"),   # A16W8 int8, pre-scale, one row (round 4)
+    (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(4, 0, 0, 0)), "a16w8_rows_kernel<16x16>"),
+    (dict(M=2, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<16x16>"),   # from 2 rows: MFMA, weights converted in registers
     (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "a16w8_rows_kernel<16x16>"),  # fp8 W, bf16 x
     (dict(M=40, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<64x16>"),
     (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<64x16>"),  # 64-row tiles along grid.y
