@@ -19,6 +19,7 @@ namespace gl {
 bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemv_mfma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, bool fq = false);
+bool plan_a8wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
@@ -377,6 +378,11 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
                                 mt == GEMLITE_MATMUL_GEMV_SPLITK || (mt == GEMLITE_MATMUL_AUTO && a.M <= 1));
         LaunchPlan lp{};
         if (p.gs_shift < 0) goto coverage;  // group size not a power of two
+        // 5 .. 64 rows of 8-bit activations x packed weights (round 4): 16-column blocks on the 16-row fp8 / int8 MFMA (tuning[0] = 4: from 2 rows)
+        if (x8 && (want_gemv || mt == GEMLITE_MATMUL_AUTO) && a.tuning[1] == 0 && a.tuning[2] == 0 &&
+            (a.tuning[0] == 4 || (a.tuning[0] == 0 && a.M >= 5)) && plan_a8wn_rows(a, p, lp)) {
+            r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
+        }
         // decode sizes of 8-bit activations x packed weights (A8Wn fp8 dynamic, BitNet int8): per-weight cast to the activation type
         if (x8 && a.M <= 4 && (want_gemv || mt == GEMLITE_MATMUL_AUTO) && a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 &&
             plan_gemv_a8wn(a, p, lp)) {

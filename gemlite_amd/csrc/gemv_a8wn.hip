@@ -15,6 +15,8 @@
 //   all blocks).  Partial sums: 4 xor-shuffles inside the wave, then 16 waves through LDS in fixed order (deterministic).
 #include "gl_common.h"
 
+#include <type_traits>
+
 namespace gl {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -316,6 +318,202 @@ bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& 
     lp.grid = dim3((unsigned)(a.N / 16), 1, 1);
     lp.block = dim3(1024, 1, 1);
     lp.lds_bytes = fq ? (size_t)a.K + 64 : 0;
+    lp.slab_bytes = 0;
+    lp.ws_bytes = 0;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a8wn_rows_kernel (round 4): 2 .. 64 rows of the same layers (A8W4 / A8W2 fp8-dynamic, BitNet int8-dynamic; reference: gemm_splitK_INT_kernel,
+// gemlite/triton_kernels/gemm_splitK_kernels.py:277-450) — they ran on the 32-row tile of the 8-wave MFMA kernel, one eighth of the chip's
+// blocks, 11 us at 4096^2 whatever M.  The rows shape: block = 16 output columns x all of K, 8 waves dealing the chunks; lane (c = lane & 15,
+// q = lane >> 4) owns column n0 + c and KL consecutive k of every chunk (chunk = 4 KL k):
+//   fp8 activations: KL = 32 / NBITS = the k of ONE packed word.  The word is dequantised weight by weight — fma(q, s, -z s) in fp32, ONE
+//     rounding to e4m3 with the hardware converter: the reference's `b.to(a.dtype)` (gemm_kernels.py:384) — and its 8 (4-bit) or 2 x 8
+//     (2-bit) values ARE the B fragment(s) of v_mfma_f32_16x16x32_fp8_fp8; A = 8 bytes of x row c (+ 16 t).
+//   int8 activations (integer codes minus an integer zero): KL = 16 = one 2-bit word or two 4-bit words = the B fragment of
+//     v_mfma_i32_16x16x64_i8, exact.
+// Words are 4 bytes per lane, 64-byte row segments per lane group: adjacent tiles are placed on ONE XCD so that the two halves of a
+// 128-byte line meet in one L2 (the pairing of gemv_w4_decode3_kernel).  (scale, zero) of the lane's group come as 2-byte loads per chunk.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Tag, int NBITS, int XDT, int MT>
+__global__ __launch_bounds__(512) void a8wn_rows_kernel(const WnParams p) {
+    using TR = F16Traits<Tag>;
+    using CD = a8::Codes<NBITS>;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    constexpr bool INT = XDT == GEMLITE_DT_INT8;
+    constexpr int E = 32 / NBITS;            // k per packed word
+    constexpr int KL = INT ? 16 : E;          // k per lane and chunk
+    constexpr int WPL = KL / E;               // packed words per lane and chunk (1, or 2 for int8 x 4-bit)
+    constexpr int NF = INT ? 1 : KL / 8;      // MFMAs per chunk and row tile
+    constexpr int CK = 4 * KL;                // k per chunk
+    __shared__ __attribute__((aligned(16))) float red[MT][8][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    int tile = blockIdx.x;
+    if ((gridDim.x & 15) == 0) {  // adjacent half-line tiles on one XCD (speed only; any mapping is correct)
+        const int xcd = tile & 7, idx = tile >> 3;
+        tile = (((idx >> 1) << 3) + xcd) * 2 + (idx & 1);
+    }
+    const int n = tile * 16 + c;
+    const int nchunks = p.K / CK;
+    const bool need_s = p.w_mode >= 2, need_z = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
+    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
+    const float u13 = (p.w_mode == 1 || p.w_mode == 3) ? 1.f : 0.f, u4 = p.w_mode == 4 ? 1.f : 0.f;
+    const int rows = p.K / E;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)(((int64_t)(rows - 1) * p.stride_wk + p.N) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((int64_t)(p.M - 1) * p.stride_xm + p.K), 0x00020000);
+    const int meta_rows = p.gs_shift >= 31 ? 1 : (p.K >> p.gs_shift);
+    const int meta_bytes = (int)(((int64_t)(meta_rows - 1) * p.stride_meta_g + p.N) * 2);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(need_s ? p.scales : (const void*)p.w), (short)0, need_s ? meta_bytes : 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)(need_z ? p.zeros : (const void*)p.w), (short)0, need_z ? meta_bytes : 4, 0x00020000);
+    const uint32_t wvoff = (uint32_t)(((int64_t)(q * WPL) * p.stride_wk + n) * 4);
+    uint32_t xvoff[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) xvoff[t] = c + 16 * t < p.M ? (uint32_t)((int64_t)(c + 16 * t) * p.stride_xm + q * KL) : 0x80000000u;  // rows >= M: zeros
+    typedef typename std::conditional<INT, i32x4, f32x4>::type acc_t;
+    acc_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+    constexpr int D = MT == 1 ? 8 : (MT == 2 ? 6 : 4);
+    struct Chunk { uint32_t w[WPL]; uint32_t s, z; u32x4 x[MT]; };
+    Chunk ring[D];
+    const int mine = (nchunks - wave + 7) >> 3;
+    auto load = [&](int slot, int i) __attribute__((always_inline)) {
+        const int ch = wave + 8 * i;
+        Chunk& k = ring[slot];
+        const uint32_t wo = (uint32_t)__builtin_amdgcn_readfirstlane((int)((int64_t)ch * (CK / E) * p.stride_wk * 4));
+#pragma unroll
+        for (int i2 = 0; i2 < WPL; ++i2) k.w[i2] = __builtin_amdgcn_raw_buffer_load_b32(rsW, wvoff + (uint32_t)(i2 * (int)p.stride_wk * 4), wo, 2);
+        const uint32_t mo = (uint32_t)((((int64_t)ch * CK + q * KL) >> p.gs_shift) * p.stride_meta_g + n) * 2u;
+        k.s = need_s ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsS, mo, 0, 0) : 0u;
+        k.z = need_z ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsZ, mo, 0, 0) : 0u;
+        const uint32_t xo = (uint32_t)__builtin_amdgcn_readfirstlane(ch * CK);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            if constexpr (KL == 16) k.x[t] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], xo, 0);
+            else {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsX, xvoff[t], xo, 0);
+                k.x[t] = (u32x4){v[0], v[1], 0u, 0u};
+            }
+        }
+    };
+    auto mma = [&](int slot) __attribute__((always_inline)) {
+        const Chunk& k = ring[slot];
+        const float s = need_s ? TR::to_float((uint16_t)k.s) : 1.f;
+        const float z = need_z ? TR::to_float((uint16_t)k.z) : scalar_zero;
+        if constexpr (INT) {
+            const uint32_t zz = 0x01010101u * ((uint32_t)(int)(z * u13) & 0xFFu);
+            uint32_t b[4];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {  // the lane's 16 k = 2 slices of 8: slice sl of the 2-bit word, or word sl (4-bit)
+                uint32_t ev, od;
+                CD::run(k.w[WPL == 2 ? sl : 0], WPL == 2 ? 0 : sl, ev, od);
+                ev = ((ev | 0x80808080u) - zz) ^ 0x80808080u;  // bytewise q - z, no borrows between bytes
+                od = ((od | 0x80808080u) - zz) ^ 0x80808080u;
+                b[2 * sl] = __builtin_amdgcn_perm(od, ev, 0x05010400u);      // k 0 .. 3 of the slice in natural order
+                b[2 * sl + 1] = __builtin_amdgcn_perm(od, ev, 0x07030602u);  // k 4 .. 7
+            }
+            const i32x4 bv = {(int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, k.x[t]), bv, acc[t], 0, 0, 0);
+        } else {
+            const float A = s, B = z * __builtin_fmaf(-u13, s, u4);  // w = fma(q, A, B): all five W_group_modes
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                uint32_t ev, od;
+                CD::run(k.w[0], f, ev, od);
+                int lo = 0, hi = 0;
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_fmaf((float)(ev & 0xFFu), A, B), __builtin_fmaf((float)(od & 0xFFu), A, B), lo, false);
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_fmaf((float)((ev >> 8) & 0xFFu), A, B), __builtin_fmaf((float)((od >> 8) & 0xFFu), A, B), lo, true);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_fmaf((float)((ev >> 16) & 0xFFu), A, B), __builtin_fmaf((float)((od >> 16) & 0xFFu), A, B), hi, false);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_fmaf((float)(ev >> 24), A, B), __builtin_fmaf((float)(od >> 24), A, B), hi, true);
+                const long bw = (long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const long aw = (long)(((uint64_t)k.x[t][2 * f + 1] << 32) | k.x[t][2 * f]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aw, bw, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        if (j < mine) load(j, j);
+    for (int base = 0; base < mine; base += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (base + j < mine) {
+                mma(j);
+                if (base + j + D < mine) load(j, base + j + D);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)acc[t][r];  // int32 sums: exact in fp32 below 2^24 (K <= 65536 codes of |q - z| <= 255 ... checked by the planner)
+        *(f32x4*)&red[t][wave][lane][0] = v;
+    }
+    __syncthreads();
+    for (int u = tid; u < MT * 256; u += 512) {
+        const int t = u >> 8, l = u & 63, r = (u >> 6) & 3;
+        const int m = 16 * t + 4 * (l >> 4) + r;  // C fragment of a 16 x 16 MFMA: column lane & 15, rows 4 (lane >> 4) + r
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[t][w][l][r];
+        if (m < p.M) epilogue_store(p.epi, v, m, (int64_t)tile * 16 + (l & 15));
+    }
+}
+
+// 2 <= M <= 64; the conditions of plan_gemv_a8wn plus whole chunks and the x re-read budget of the rows kernels
+bool plan_a8wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
+    const int nbits = a.W_nbits;
+    if (nbits != 4 && nbits != 2) return false;
+    if (a.M < 2 || a.M > 64) return false;
+    if (a.input_dtype != GEMLITE_DT_FP8E4 && a.input_dtype != GEMLITE_DT_INT8) return false;
+    if (a.output_dtype != GEMLITE_DT_FP16 && a.output_dtype != GEMLITE_DT_BF16) return false;
+    const bool isint = a.input_dtype == GEMLITE_DT_INT8;
+    const bool loop_s = a.W_group_mode >= 2;
+    const bool has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
+    if (loop_s && a.meta_dtype != a.output_dtype) return false;
+    if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.output_dtype) return false;
+    if (has_z && a.zero_is_scalar && a.zeros_dtype != GEMLITE_DT_INT32) return false;
+    if (isint && (a.W_group_mode >= 2 || (has_z && !a.zero_is_scalar))) return false;  // integer codes only
+    const int e = 32 / nbits, kl = isint ? 16 : e, ck = 4 * kl;
+    if (a.N % 16 != 0 || a.K % ck != 0 || a.K > (isint ? 65536 : (1 << 30))) return false;
+    if (p.gs_shift < 0 || p.group_size < kl || p.group_size % kl != 0) return false;  // a lane's k of a chunk lie inside one group
+    if (((uintptr_t)a.w_q % 4) != 0 || ((uintptr_t)a.x % 16) != 0 || (a.stride_xm % 16) != 0) return false;
+    if ((loop_s && ((uintptr_t)a.scales % 2) != 0) || (has_z && !a.zero_is_scalar && ((uintptr_t)a.zeros % 2) != 0)) return false;
+    if (((int64_t)(a.K / e) * a.stride_wk + a.N) * 4 >= (1ll << 31) || (int64_t)a.M * a.stride_xm + a.K >= (1ll << 31)) return false;
+    if (((int64_t)(a.K / (p.group_size > 0 ? p.group_size : a.K)) * p.stride_meta_g + a.N) * 2 >= (1ll << 31)) return false;
+    const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    if (mt > 1 && a.tuning[0] != 4 && (int64_t)a.M * a.K * (a.N / 16) > (88ll << 20)) return false;
+    typedef void (*fn_t)(const WnParams);
+    fn_t fn = nullptr;
+    auto pick = [&](auto tag, auto nb, auto xd) -> fn_t {
+        using T = decltype(tag);
+        constexpr int NB = decltype(nb)::value, XD = decltype(xd)::value;
+        return mt == 1 ? a8wn_rows_kernel<T, NB, XD, 1> : (mt == 2 ? a8wn_rows_kernel<T, NB, XD, 2> : a8wn_rows_kernel<T, NB, XD, 4>);
+    };
+    typedef std::integral_constant<int, 4> N4;
+    typedef std::integral_constant<int, 2> N2;
+    typedef std::integral_constant<int, GEMLITE_DT_FP8E4> XF;
+    typedef std::integral_constant<int, GEMLITE_DT_INT8> XI;
+    const bool f16 = a.output_dtype == GEMLITE_DT_FP16;
+    if (isint) fn = nbits == 4 ? (f16 ? pick(half_tag{}, N4{}, XI{}) : pick(bf16_tag{}, N4{}, XI{})) : (f16 ? pick(half_tag{}, N2{}, XI{}) : pick(bf16_tag{}, N2{}, XI{}));
+    else fn = nbits == 4 ? (f16 ? pick(half_tag{}, N4{}, XF{}) : pick(bf16_tag{}, N4{}, XF{})) : (f16 ? pick(half_tag{}, N2{}, XF{}) : pick(bf16_tag{}, N2{}, XF{}));
+    p.splitk = 1;
+    p.rows_per_slice = (int)(a.K / e);
+    lp.fn = (const void*)fn;
+    static const char* names[2][3] = {{"a8w4_rows_kernel<16x16>", "a8w4_rows_kernel<32x16>", "a8w4_rows_kernel<64x16>"},
+                                      {"a8w2_rows_kernel<16x16>", "a8w2_rows_kernel<32x16>", "a8w2_rows_kernel<64x16>"}};
+    lp.name = names[nbits == 4 ? 0 : 1][mt == 1 ? 0 : (mt == 2 ? 1 : 2)];
+    lp.grid = dim3((unsigned)(a.N / 16), 1, 1);
+    lp.block = dim3(512, 1, 1);
+    lp.lds_bytes = 0;
     lp.slab_bytes = 0;
     lp.ws_bytes = 0;
     return true;

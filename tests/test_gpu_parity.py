@@ -683,8 +683,8 @@ def test_remaining_helper_processors_against_the_oracle(M):
                                 # here; gemv_revsplitK_kernels.py:331-332, pinned by tests/golden/fullsize_ref_r4.npz a8w4_fp8dyn_m1)
                                 weight_cast_code=(O.FP8E4 if M > 1 else O.FP16) if code == O.FP8E4 else None)
         kname = _kernel_name(lin, x)
-        want = {(O.FP8E4, 1): "gemv_a8w4_kernel<tile16,16w>", (O.FP8E4, 8): "gemm_a8w4_mma_kernel<32x128>",
-                (O.INT8, 1): "gemv_a8w2_kernel<tile16,16w>", (O.INT8, 8): "gemm_a8w2_mma_kernel<32x128>"}[(code, M)]
+        want = {(O.FP8E4, 1): "gemv_a8w4_kernel<tile16,16w>", (O.FP8E4, 8): "a8w4_rows_kernel<16x16>",
+                (O.INT8, 1): "gemv_a8w2_kernel<tile16,16w>", (O.INT8, 8): "a8w2_rows_kernel<16x16>"}[(code, M)]
         assert kname == want, kname
         _compare(f"helpers/{name}/M{M}", y, y_or, 1, abs_gate=5e-3, extra=dict(kernel=kname))
     lin = H.A16W158_INT(device=DEV).from_weights(Wt, torch.tensor(0.02))
@@ -1274,7 +1274,7 @@ def test_a8wn_fp8_activations_on_the_mfma_kernel(nbits, tdt):
         lin = H.A8Wn_HQQ_INT_dynamic(device=DEV, dtype=tdt, post_scale=post, W_nbits=nbits).from_weights(
             torch.from_numpy(W_q), torch.from_numpy(sc).to(tdt), torch.from_numpy(zr).to(tdt))
         assert (lin.W_group_mode, lin.channel_scale_mode) == ((3, 2) if gs == 128 or not post else (1, 3))
-        for mi, M in ((1, 1), (1, 2), (1, 3), (1, 29), (2, 64), (4, 100), (8, 300)):
+        for mi, M in ((1, 1), (1, 2), (1, 3), (1, 16), (1, 29), (2, 50), (2, 64), (4, 100), (8, 300)):
             x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
             xq_t, sx_t = scale_activations_per_token(x, w_dtype=torch.float8_e4m3fn)
             xq, sx = O.scale_activations_per_token(x, O.FP8E4)
@@ -1293,6 +1293,19 @@ def test_a8wn_fp8_activations_on_the_mfma_kernel(nbits, tdt):
                     xq, lin.W_q.data.cpu().numpy(), O.to_f64(lin.scales.data), z, W_nbits=nbits, group_size=lin.group_size,
                     W_group_mode=lin.W_group_mode, channel_scale_mode=lin.channel_scale_mode, scales_x=sx, weight_cast_code=out_code)
                 _compare(f"a8wn/w{nbits}/{str(tdt)[6:]}/g{gs}/post{int(post)}/M{M}/gemv", y, y_or1, out_code, abs_gate=None)
+            if 2 <= M <= 64:  # round 4: the rows kernel (default from 5 rows, forced below): per-weight cast to e4m3 like the tile kernel
+                tun = (0, 0, 0, 0) if M >= 5 else (4, 0, 0, 0)
+                a = gemlite_amd.core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
+                a.matmul_type, a.M, a.x, a.out, a.scales_x = -1, M, 0x1000, 0x1000, 0x1000
+                a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = K, 1, N, 1
+                a.input_dtype = lin.input_dtype.value
+                for i in range(4):
+                    a.tuning[i] = tun[i]
+                name = _hip.load().gemlite_hip_kernel_name(_hip.C.byref(a)).decode()
+                assert name == f"a8w{nbits}_rows_kernel<%s>" % ("16x16" if M <= 16 else ("32x16" if M <= 32 else "64x16")), (M, name)
+                y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1, tun)
+                torch.cuda.synchronize()
+                _compare(f"a8wn/w{nbits}/{str(tdt)[6:]}/g{gs}/post{int(post)}/M{M}/rows", y, y_or, out_code, abs_gate=None)
             for sk in (0, 3):
                 tuning = (0, sk, mi, 0)
                 y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1, tuning)
@@ -1310,7 +1323,7 @@ def test_a8wn_fp8_activations_on_the_mfma_kernel(nbits, tdt):
                          extra=dict(kernel=name))
 
 
-@pytest.mark.parametrize("M", [1, 2, 4, 7, 200])
+@pytest.mark.parametrize("M", [1, 2, 4, 7, 16, 40, 64, 200])
 def test_bitnet_int8_activations_on_the_int8_mfma_are_exact(M):
     """A8W158_INT_dynamic (helper.py:1006-1062): int8 activations x ternary 2-bit codes with a scalar zero of 1, fp32
     per-tensor scale, modes (1, 3).  (q - 1) is exact int8, v_mfma_i32_32x32x16_i8 accumulates exact int32: the result must
@@ -1323,7 +1336,8 @@ def test_bitnet_int8_activations_on_the_int8_mfma_are_exact(M):
     x = (torch.randn(M, K) / 10).half().to(DEV)
     y = lin(x)
     torch.cuda.synchronize()
-    assert _kernel_name(lin, x).startswith("gemv_a8w2_kernel<" if M <= 4 else "gemm_a8w2_mma_kernel<"), _kernel_name(lin, x)
+    # (round 4: 5 .. 64 rows on a8wn_rows_kernel — v_mfma_i32_16x16x64_i8 — the 8-wave tile kernel above)
+    assert _kernel_name(lin, x).startswith("gemv_a8w2_kernel<" if M <= 4 else ("a8w2_rows_kernel<" if M <= 64 else "gemm_a8w2_mma_kernel<")), _kernel_name(lin, x)
     xq, sx = scale_activations_per_token(x, w_dtype=torch.int8)
     dot = (xq.cpu().to(torch.int64) @ Wt.to(torch.int64).t())  # exact
     assert int(dot.abs().max()) < (1 << 24)

@@ -200,12 +200,14 @@ def test_struct_abi_and_validation():
     (dict(M=4, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=3, c_mode=2), "gemv_a8w4_kernel<tile16,16w>"),
     (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, tuning=(0, 0, 1, 0)), "gemm_a8w4_mma_kernel<32x128>"),
     (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, mt=4), "gemm_a8w4_mma_kernel<32x128>"),  # manual GEMM
-    (dict(M=8, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "gemm_a8w4_mma_kernel<32x128>"),
+    (dict(M=8, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "a8w4_rows_kernel<16x16>"),   # round 4: 5 .. 64 rows, 16-column blocks on the 16-row fp8 MFMA
+    (dict(M=3, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2, tuning=(4, 0, 0, 0)), "a8w4_rows_kernel<16x16>"),
+    (dict(M=100, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "gemm_a8w4_mma_kernel<64x128>"),
     (dict(M=512, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, N=8192, K=8192), "gemm_a8w4_mma_kernel<128x128>"),
-    (dict(M=16, nbits=2, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "gemm_a8w2_mma_kernel<32x128>"),
+    (dict(M=16, nbits=2, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "a8w2_rows_kernel<16x16>"),
     (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=1, c_mode=3, gs=4096), "gemv_a8w4_kernel<tile16,16w>"),  # channel-wise, post-scale
     (dict(M=1, nbits=2, in_dt=4, out_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemv_a8w2_kernel<tile16,16w>"),  # BitNet int8, fp32 scale
-    (dict(M=8, nbits=2, in_dt=4, out_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w2_mma_kernel<32x128>"),
+    (dict(M=8, nbits=2, in_dt=4, out_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "a8w2_rows_kernel<16x16>"),   # BitNet int8: v_mfma_i32_16x16x64_i8
     (dict(M=300, nbits=2, in_dt=4, out_dt=2, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096), "gemm_a8w2_mma_kernel<64x128>"),
     (dict(M=1, in_dt=8, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "generic_matmul_kernel"),   # e5m2 activations: coverage kernel
     # 16-bit activations whose output / channel-scale type differs (BitNet A16W158 with its fp32 scale; fp32 output)
