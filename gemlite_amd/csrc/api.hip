@@ -30,7 +30,7 @@ bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, Laun
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
-bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, bool nv = false);
+bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, int mode = 0);
 bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 const void* mx_generic_kernel_fn();
@@ -268,7 +268,7 @@ static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, cons
         p.group_size = 16;
         p.stride_xm = a.K; p.stride_xk = 1; p.stride_wk = 1;
         p.flags = a.tuning[3];
-        if (plan_gemm_wn_mma_mx(b, p, r.lp, true)) {
+        if (plan_gemm_wn_mma_mx(b, p, r.lp, 1)) {
             r.kind = K_NV_MMA;
             r.wn = p;
             r.nv_x16_bytes = (uint64_t)(((int64_t)a.M * a.K * 2 + 255) & ~(int64_t)255);
@@ -560,6 +560,19 @@ coverage:
             r.lp.block = dim3(1024, 1, 1);
             r.lp.lds_bytes = (size_t)a.K * 2;
             return;
+        }
+        // round 4, more than 64 rows: the 8-wave MFMA tile kernel with the K-contiguous 8-bit geometry (x through LDS, weights converted
+        // in registers); the per-channel pre-scale becomes the epilogue's channel scale.  tuning[0] = 4 keeps the rows kernel.
+        if (a.M > 64 && (a.tuning[0] == 0 || a.tuning[0] == 2) && !(a.W_group_mode == 2 && a.channel_scale_mode != 0)) {
+            WnParams p{};
+            p.x = a.x; p.w = (const uint32_t*)a.w_q; p.scales = a.scales; p.zeros = nullptr;
+            p.epi = make_epilogue(a);
+            if (a.W_group_mode == 2) { p.epi.c_mode = 1; p.epi.scales_w = a.scales; }
+            p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
+            p.group_size = 32;
+            p.stride_xm = a.stride_xm; p.stride_xk = a.stride_xk; p.stride_wk = 1;
+            p.flags = a.tuning[3];
+            if (plan_gemm_wn_mma_mx(a, p, r.lp, 2)) { r.kind = K_TILED_WN; r.wn = p; return; }
         }
         // round 4: 16-column blocks, weights converted in registers, MFMA (tuning[0] = 7 keeps the streaming kernel of rounds 1-3)
         if (a.tuning[0] != 7 && plan_a16w8_rows(a, r.lp)) return;

@@ -13,21 +13,27 @@ const void* mma_lookup_bf16(int kind, int nbits, int mi, int xdt, int xch);
 // tuning[1] = K slices, tuning[2] = tile rows / 32.
 // nv (round 4): NVFP4 weights (e4m3 scale per 16 k) under the fp16 EXPANSION of NVFP4 activations — `a` then describes that expansion
 // (input MXFP16, x [M, K] fp16 in the workspace); any of fp16 / bf16 / fp32 leaves through the untyped epilogue store.
-bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, bool nv) {
-    const bool f16 = a.input_dtype == GEMLITE_DT_MXFP16;
-    if (!f16 && a.input_dtype != GEMLITE_DT_MXBF16) return false;
+bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, int mode) {
+    // mode 0: block-scaled weights (e8m0 per 32 k), 1: NVFP4 weights, 2: plain K-contiguous 8-bit weights of an A16W8 layer (int8 /
+    // fp8 e4m3 / e5m2, no block scale: Geo<KW8I / KW8F / KW8B>; the per-channel scale is the epilogue's, set by the caller)
+    const bool nv = mode == 1, k8 = mode == 2;
+    const bool f16 = k8 ? a.input_dtype == GEMLITE_DT_FP16 : a.input_dtype == GEMLITE_DT_MXFP16;
+    if (!f16 && a.input_dtype != (k8 ? GEMLITE_DT_BF16 : GEMLITE_DT_MXBF16)) return false;
     if (nv && (!f16 || a.W_nbits != 4)) return false;
-    if (!nv && a.output_dtype != (f16 ? GEMLITE_DT_FP16 : GEMLITE_DT_BF16)) return false;  // typed epilogue
-    const int nb = nv ? mma::NVW4 : (a.W_nbits == 8 ? mma::MXW8 : mma::MXW4);
+    if (mode == 0 && a.output_dtype != (f16 ? GEMLITE_DT_FP16 : GEMLITE_DT_BF16)) return false;  // typed epilogue
+    if (k8 && (a.elements_per_sample != 1 || !(a.w_dtype == GEMLITE_DT_INT8 || a.w_dtype == GEMLITE_DT_FP8E4 || a.w_dtype == GEMLITE_DT_FP8E5))) return false;
+    const int nb = k8 ? (a.w_dtype == GEMLITE_DT_INT8 ? mma::KW8I : (a.w_dtype == GEMLITE_DT_FP8E4 ? mma::KW8F : mma::KW8B))
+                      : (nv ? mma::NVW4 : (a.W_nbits == 8 ? mma::MXW8 : mma::MXW4));
     const int sbk = nv ? 16 : 32;  // k per scale byte
-    if (a.group_size != sbk || a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % mma::BN != 0 || a.K % 128 != 0) return false;
+    if ((!k8 && a.group_size != sbk) || a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % mma::BN != 0 || a.K % 128 != 0) return false;
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0 || ((uintptr_t)a.w_q % 16) != 0 || a.stride_wn % 16 != 0) return false;
     if (((uintptr_t)a.out % 8) != 0 || (a.stride_om * 2) % 8 != 0) return false;
     if ((int64_t)a.N * a.stride_wn >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31)) return false;
-    if ((int64_t)(a.K / sbk) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
-    if (nv) {
+    if (!k8 && (int64_t)(a.K / sbk) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    if (nv || k8) {
         const int oal = a.output_dtype == GEMLITE_DT_FP32 ? 16 : 8;  // 4 outputs per (untyped) store
         if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
+        if (k8 && p.epi.c_mode != 0 && p.epi.c_mode != 2 && ((uintptr_t)p.epi.scales_w % 16) != 0) return false;  // 4 channel scales per load
     }
     auto kstep_of = [](int c) { return c >= 4 ? 128 : 256; };
     const int cap = a.M > 128 ? 8 : (a.M > 64 ? 4 : (a.M > 32 ? 2 : 1));
@@ -67,8 +73,8 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     p.splitk = splitk;
     p.rows_per_slice = (int)a.K;  // E = 1: "packed rows" are k
     p.stride_wn_b = a.stride_wn;  // 1-byte elements
-    p.stride_meta_n = a.stride_meta_n;
-    p.stride_meta_g = a.stride_meta_g;
+    p.stride_meta_n = k8 ? 0 : a.stride_meta_n;
+    p.stride_meta_g = k8 ? 0 : a.stride_meta_g;
     p.w_mode = 2;
     p.gs_shift = 5;
     lp.fn = fn;
@@ -76,10 +82,12 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         {"gemm_a16w8_mxfp_kernel<32x128>", "gemm_a16w8_mxfp_kernel<64x128>", "gemm_a16w8_mxfp_kernel<128x128>", "gemm_a16w8_mxfp_kernel<256x128>"},
         {"gemm_a16w4_mxfp_kernel<32x128>", "gemm_a16w4_mxfp_kernel<64x128>", "gemm_a16w4_mxfp_kernel<128x128>", "gemm_a16w4_mxfp_kernel<256x128>"}};
     static const char* nv_names[4] = {"gemm_nvfp4_f16_kernel<32x128>", "gemm_nvfp4_f16_kernel<64x128>", "gemm_nvfp4_f16_kernel<128x128>", "gemm_nvfp4_f16_kernel<256x128>"};
-    lp.name = nv ? nv_names[mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))] : names[nb == mma::MXW8 ? 0 : 1][mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))];
+    static const char* k8_names[4] = {"gemm_a16w8_kernel<32x128>", "gemm_a16w8_kernel<64x128>", "gemm_a16w8_kernel<128x128>", "gemm_a16w8_kernel<256x128>"};
+    if (k8) lp.name = k8_names[mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))];
+    else lp.name = nv ? nv_names[mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))] : names[nb == mma::MXW8 ? 0 : 1][mi == 1 ? 0 : (mi == 2 ? 1 : (mi == 4 ? 2 : 3))];
     lp.grid = dim3((unsigned)tiles, splitk, 1);
     lp.block = dim3(512, 1, 1);
-    const bool w8 = nb == mma::MXW8;
+    const bool w8 = nb == mma::MXW8 || k8;
     const int nst = mi == 8 ? 2 : (mi == 4 ? 3 : (w8 ? 2 : (mi == 2 ? 3 : 4)));  // LDS stages of x (mma_pick_mi)
     const size_t stages = (size_t)nst * bm * ks * 2;
     const size_t xch = (size_t)4 * mi * 4 * 64 * 16;

@@ -1054,6 +1054,43 @@ def test_a16w8_rows_kernel_against_the_oracle_and_the_streaming_kernel(proc, tdt
         assert rel < (2e-3 if tdt == torch.float16 else 8e-3), (proc, M, rel)
 
 
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("proc", ["A16W8_INT8", "A16W8_INT8_post", "A16W8_FP8", "A16W8_FP8e5"])
+def test_a16w8_tile_kernel_above_64_rows(proc, tdt):
+    """8-bit weight-only layers above 64 rows (round 4): the 8-wave MFMA tile kernel with the K-contiguous 8-bit geometries
+    (Geo<KW8I / KW8F / KW8B>: int8 / e4m3 / e5m2 converted in registers at scale 1, the channel scale in the epilogue — pre-scale layers
+    included).  Every tile height, split-K and unsplit, ragged M; against the float64 oracle and the rows kernel (tuning[0] = 4)."""
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    torch.manual_seed(43)
+    out_code = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+    for N, K, Ms in ((1024, 2048, (65, 130, 300)), (256, 4096 + 128, (100,)), (4096, 1024, (513,))):
+        W = (torch.randn(N, K) / 30).to(tdt)
+        W[3, :] *= 6.0
+        if proc == "A16W8_FP8e5":
+            sc = (W.float().abs().amax(dim=1, keepdim=True) / 57344.0).clamp_(min=1e-6)
+            lin = H.A16W8(device=DEV, dtype=tdt).from_weights((W.float() / sc).to(torch.float8_e5m2), scales=sc)
+        else:
+            mk = {"A16W8_INT8": lambda: H.A16W8(device=DEV, dtype=tdt), "A16W8_INT8_post": lambda: H.A16W8(device=DEV, dtype=tdt, post_scale=True),
+                  "A16W8_FP8": lambda: H.A16W8_FP8(device=DEV, dtype=tdt)}[proc]
+            lin = mk().from_weights(W)
+        for M in Ms:
+            x = (torch.randn(M, K, device=DEV) / 10).to(tdt)
+            name = _kernel_name(lin, x)
+            assert name.startswith("gemm_a16w8_kernel<"), (proc, M, name)
+            y = lin(x)
+            y_rows = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, (4, 0, 0, 0))
+            torch.cuda.synchronize()
+            _compare(f"a16w8-tile/{proc}/{str(tdt)[6:]}/{N}x{K}/M{M}", y, _oracle_from_layer(lin, x), out_code, abs_gate=5e-3)
+            rel = float((y.float() - y_rows.float()).abs().mean() / y_rows.float().abs().mean())
+            assert rel < (2e-3 if tdt == torch.float16 else 8e-3), (proc, M, rel)
+            for tun in ((2, 1, 1, 0), (2, 2, 2, 0), (2, 1, 4, 0), (2, 4, 8, 0)):  # (tile kernel, split-K, 32-row units per tile)
+                y_t = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tun)
+                torch.cuda.synchronize()
+                rel = float((y_t.float() - y_rows.float()).abs().mean() / y_rows.float().abs().mean())
+                assert rel < (2e-3 if tdt == torch.float16 else 8e-3), (proc, M, tun, rel)
+
+
 @pytest.mark.parametrize("kind", ["int8", "fp8"])
 def test_a8w8_decode_kernel_against_the_round2_kernels_and_the_oracle(kind):
     """a8w8_decode_kernel (round 4: one wave per column, the weight row requested before anything else; FUSED form quantises x under that

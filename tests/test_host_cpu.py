@@ -190,7 +190,9 @@ def test_struct_abi_and_validation():
     (dict(M=2, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<16x16>"),   # from 2 rows: MFMA, weights converted in registers
     (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "a16w8_rows_kernel<16x16>"),  # fp8 W, bf16 x
     (dict(M=40, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<64x16>"),
-    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<64x16>"),  # 64-row tiles along grid.y
+    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "gemm_a16w8_kernel<64x128>"),  # above 64 rows: the MFMA tile kernel
+    (dict(M=65, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "gemm_a16w8_kernel<64x128>"),
+    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(4, 0, 0, 0)), "a16w8_rows_kernel<64x16>"),  # 64-row tiles along grid.y
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(7, 0, 0, 0)), "kmajor_w8a16_kernel"),  # A/B switch: rounds 1-3
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096 + 16, K=4096 + 16), "kmajor_w8a16_kernel"),    # K % 64 != 0
     (dict(M=1, N=1000), "generic_matmul_kernel"),    # N not a multiple of 64
