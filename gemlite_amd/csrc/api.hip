@@ -30,6 +30,7 @@ bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, Laun
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
+bool plan_gemm_mx_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp, int mode = 0);
 bool plan_mx_gemv(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
@@ -229,6 +230,12 @@ static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, cons
         plan_a16w8_rows(a, r.lp)) { r.kind = K_KMAJOR; return; }
     // decode sizes of what is left (K % 64 != 0 ...): the streaming kernel
     if ((a.tuning[0] == 0 || a.tuning[0] == 5) && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
+    // 65 .. 384 (512) rows (round 4): 64 x 64 tiles, K unsplit; tuning[0] = 6 forces them, 2 keeps the 128-column kernel with its K slices
+    // (profiles/r04/probe_mx_sq.log, `layer(x)` at 4096^2 / 8192^2 / 4096 x 14336 / 14336 x 4096: ahead or within 5 % everywhere up to 384
+    //  rows — 4096^2 M = 256: fp8 27.2 -> 17.4 us, fp4 29.7 -> 13.7; at 512 rows for fp4 x fp4 and for one-round shapes)
+    const bool sq_auto = a.M > 64 && (a.M <= 384 || (a.M <= 512 && ((g.mx_x == MX_FP4 && g.mx_w == MX_FP4) ||
+                                                                     ((a.N / 64) * ((a.M + 63) / 64) <= 512 && a.K <= 4096))));
+    if ((a.tuning[0] == 6 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && sq_auto)) && plan_gemm_mx_sq(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
     // prefill sizes of the same-format pairs: 256 x 256 tiles, both operands through LDS (tuning[0] = 3 forces it at any M)
     if (plan_gemm_mx_tile(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
     if ((a.tuning[0] == 0 || a.tuning[0] == 2) && plan_gemm_mx_mma(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }

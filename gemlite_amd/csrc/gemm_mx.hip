@@ -1376,6 +1376,228 @@ bool plan_gemm_mx_tile(const gemlite_hip_forward_args& a, GenericParams& g, Laun
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: 64 x 64 tiles, K NOT split ("gemm_mx_sq_kernel") — the shape of gemm_a8w8_sq_kernel (gemm_a8w8.hip) for the
+// block-scaled pairs.  Between 65 and ~256 rows the 128-column kernel above needs K slices to fill 256 CUs (4096^2, M = 256:
+// 64 tiles x 4 slices, 22-26 us: prologue + a combine through memory around a 2-us loop); nothing is dequantised here either, so
+// a small tile costs operand traffic only.  8 waves: wave (rb, cb, kh) owns the 32 x 32 block (rb, cb) and half of every
+// 256-k step (two v_mfma_scale_f32_32x32x64_f8f6f4); x and w rows travel as 1-KiB LDS-DMA pieces into NST stages of
+// [64 x rows | 64 w rows] x (256 B fp8 | 128 B fp4), 16-byte slots swizzled like the 256 x 256 kernel's (mxt_slot); the step's
+// block scales ride as four 256-byte pieces (activation scale dwords [K half][row], weight scale bytes [block row][column]);
+// one counted wait + one barrier per step.  The blocks sharing a weight column tile sit on one XCD.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int AF, int BF, int NST, bool BLKX>
+__global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_mx_sq_kernel(const GenericParams p) {
+    using namespace async;
+    constexpr int BM = 64, BN = 64, KSTEP = 256;
+    constexpr int PA = AF == 0 ? KSTEP : KSTEP / 2, PB = BF == 0 ? KSTEP : KSTEP / 2;  // bytes per row and step
+    constexpr int A_BYTES = BM * PA, TILES = A_BYTES + BN * PB;
+    constexpr int SC_A = TILES, SC_B = TILES + 512, STAGE = TILES + 1024;
+    constexpr int PX = A_BYTES / 1024 / 8, PW = BN * PB / 1024 / 8;  // tile pieces per wave and stage (2 or 1 each)
+    constexpr int R = PX + PW + 1;                                     // + one scale piece
+    constexpr int FVA = AF == 0 ? 2 : 1, FVB = BF == 0 ? 2 : 1;       // 16-byte pieces per fragment
+    static_assert(NST >= 2 && (NST - 1) * R <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST][STAGE], later the epilogue tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = (wave >> 1) & 1, cb = wave & 1, kh = wave >> 2;
+    const int col = lane & 31, h = lane >> 5;
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = p.N / BN;
+    int mt, nt;
+    {
+        const int lin = blockIdx.x;
+        if ((ntiles & 7) == 0) {  // the row tiles of one weight column tile on one XCD, back to back in its dispatch order
+            const int xcd = lin & 7, idx = lin >> 3;
+            mt = idx % mtiles;
+            nt = (idx / mtiles) * 8 + xcd;
+        } else {
+            mt = lin % mtiles;
+            nt = lin / mtiles;
+        }
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nsteps = p.K / KSTEP;
+    const int xrow_bytes = AF == 0 ? p.K : p.K / 2, wrow_bytes = BF == 0 ? p.K : p.K / 2;
+    const int blocks_k = p.K / 32;
+    const int m_pad = (p.M + 31) / 32 * 32;
+
+    const srd_t rsX = make_srd(p.x, (uint32_t)((int64_t)(p.M - 1) * p.stride_xm + xrow_bytes));
+    const srd_t rsW = make_srd(p.w, (uint32_t)((int64_t)(p.N - 1) * p.stride_wn + wrow_bytes));
+    const srd_t rsSW = make_srd(p.scales, (uint32_t)((int64_t)(blocks_k - 1) * p.stride_meta_g + p.N));
+    const srd_t rsSA = BLKX ? make_srd(p.sx_blocks, (uint32_t)((int64_t)(m_pad - 1) * p.stride_sx_blk_m + blocks_k)) : rsSW;
+
+    uint32_t xvoff[PX], wvoff[PW];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int byte = (wave * PX + j) * 1024 + lane * 16;
+        const int r = byte / PA, phys = (byte % PA) / 16;
+        const int logical = phys ^ ((r / (256 / PA)) & (PA / 16 - 1));
+        xvoff[j] = m0 + r < p.M ? (uint32_t)((int64_t)(m0 + r) * p.stride_xm + logical * 16) : 0x80000000u;  // rows >= M: zeros
+    }
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int byte = (wave * PW + j) * 1024 + lane * 16;
+        const int r = byte / PB, phys = (byte % PB) / 16;
+        const int logical = phys ^ ((r / (256 / PB)) & (PB / 16 - 1));
+        wvoff[j] = (uint32_t)((int64_t)(n0 + r) * p.stride_wn + logical * 16);
+    }
+    // scale piece sp = wave & 3 (waves 4 .. 7 repeat the requests of waves 0 .. 3: same bytes to the same place — every wave then counts
+    // the same number of requests per stage).  sp 0 / 1: dword sp of the step's 8 activation-scale bytes of rows [m0, +64);
+    // sp 2 / 3: weight-scale block rows [4 (sp - 2), +4) x 64 columns
+    const int sp = wave & 3;
+    const bool s_is_w = sp >= 2;
+    const srd_t rsS = s_is_w ? rsSW : rsSA;
+    const uint32_t s_voff = s_is_w ? (uint32_t)((int64_t)((sp - 2) * 4 + (lane >> 4)) * p.stride_meta_g + n0 + (lane & 15) * 4)
+                                   : (BLKX ? (uint32_t)((int64_t)(m0 + lane) * p.stride_sx_blk_m + sp * 4) : 0u);
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const uint32_t ldsx = lds_base + (uint32_t)(wave * PX) * 1024u;
+    const uint32_t ldsw = lds_base + (uint32_t)A_BYTES + (uint32_t)(wave * PW) * 1024u;
+    const uint32_t ldss = lds_base + (uint32_t)(s_is_w ? SC_B + (sp - 2) * 256 : SC_A + sp * 256);
+    auto request = [&](int stage, int step) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < PX; ++j) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * PA));
+#pragma unroll
+        for (int j = 0; j < PW; ++j) req_lds16(rsW, ldsw + (uint32_t)(stage * STAGE + j * 1024), wvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * PB));
+        const int so = s_is_w ? step * 8 * (int)p.stride_meta_g : (BLKX ? step * 8 : 0);
+        req_lds4(rsS, ldss + (uint32_t)(stage * STAGE), s_voff, (uint32_t)__builtin_amdgcn_readfirstlane(so));
+    };
+    // fragments of slice g (64 k of this wave's K half): fp8 slots {4 g + h, 4 g + 2 + h} of the half's 8, fp4 slot 2 g + h of its 4
+    const int ra = rb * 32 + col, rw = cb * 32 + col;
+    int fa[2][FVA], fb[2][FVB];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int v = 0; v < FVA; ++v) fa[g][v] = mxt_slot<PA>(ra, AF == 0 ? kh * 8 + 4 * g + 2 * v + h : kh * 4 + 2 * g + h);
+#pragma unroll
+        for (int v = 0; v < FVB; ++v) fb[g][v] = A_BYTES + mxt_slot<PB>(rw, BF == 0 ? kh * 8 + 4 * g + 2 * v + h : kh * 4 + 2 * g + h);
+    }
+    const int sa_off = SC_A + kh * 256 + ra * 4;
+    const int sb_off = SC_B + (kh * 4 + h) * 64 + rw;
+    const uint32_t sh_h = 8u * (uint32_t)h;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    auto mk8 = [](u32x4 v0, u32x4 v1) -> v8i {
+        return (v8i){(int)v0[0], (int)v0[1], (int)v0[2], (int)v0[3], (int)v1[0], (int)v1[1], (int)v1[2], (int)v1[3]};
+    };
+    auto wide4 = [](u32x4 f) -> v8i { return (v8i){(int)f[0], (int)f[1], (int)f[2], (int)f[3], 0, 0, 0, 0}; };
+
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) request(st, st < nsteps ? st : nsteps - 1);
+    auto do_step = [&](auto Jc, int step) __attribute__((always_inline)) {
+        constexpr int stage = decltype(Jc)::value, stage_fill = (stage + NST - 1) % NST;
+        wait_vm<(NST - 2) * R>();      // this step's pieces have landed (the later stages' stay in flight)
+        __builtin_amdgcn_s_barrier();  // ... everybody's have, and everybody is done reading the stage refilled next
+        asm volatile("" ::: "memory");
+        request(stage_fill, step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1);  // past the end: repeat the last step (never consumed)
+        const unsigned char* sb = smem + stage * STAGE;
+        v8i av[2], bv[2];
+        uint32_t sa[2], sw[2];
+        const uint32_t sa_dw = BLKX ? *(const uint32_t*)(sb + sa_off) : 0u;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const u32x4 a0 = *(const u32x4*)(sb + fa[g][0]);
+            if constexpr (AF == 0) av[g] = mk8(a0, *(const u32x4*)(sb + fa[g][FVA - 1])); else av[g] = wide4(a0);
+            const u32x4 b0 = *(const u32x4*)(sb + fb[g][0]);
+            if constexpr (BF == 0) bv[g] = mk8(b0, *(const u32x4*)(sb + fb[g][FVB - 1])); else bv[g] = wide4(b0);
+            sa[g] = BLKX ? (sa_dw >> (sh_h + 16u * (uint32_t)g)) : 127u;  // block 2 g + h of the half
+            sw[g] = sb[sb_off + 2 * g * 64];
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[g], bv[g], acc, AF, BF, 0, (int)sa[g], 0, (int)sw[g]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the stage are complete before it reaches the next barrier
+    };
+    auto chain = [&](auto self, auto Jc, int s0) -> void {
+        constexpr int J = decltype(Jc)::value;
+        do_step(std::integral_constant<int, J>{}, s0 + J);
+        if constexpr (J + 1 < NST) {
+            if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
+        }
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += NST) chain(chain, std::integral_constant<int, 0>{}, s0);
+    wait_vm<0>();
+    __syncthreads();
+
+    // ---- epilogue: add the two K halves, transpose through LDS, 4 outputs per store
+    constexpr int C_PITCH = BN + 4;
+    {
+        f32x16* xch = (f32x16*)smem;  // [rb][cb][lane]
+        if (kh == 1) xch[(rb * 2 + cb) * 64 + lane] = acc;
+        __syncthreads();
+        if (kh == 0) acc += xch[(rb * 2 + cb) * 64 + lane];
+        __syncthreads();
+    }
+    float* ct = (float*)smem;  // [64][C_PITCH]
+    if (kh == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            ct[r * C_PITCH + cb * 32 + col] = acc[e];
+        }
+    }
+    __syncthreads();
+    const float post = p.mx_post;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + 512 * i, r = u >> 4, c4 = (u & 15) * 4;
+        const int m = m0 + r;
+        if (m < p.M) {
+            const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
+            store_out4_any(p.epi, v * (f32x4){post, post, post, post}, m, (int64_t)n0 + c4);
+        }
+    }
+}
+
+// 65 .. ~256 rows whose 64 x 64 tiles fill the chip about once (the caller's rule), fp8 x fp8 / fp4 x fp4 / fp8 x fp4; tuning[0] = 6 forces it
+bool plan_gemm_mx_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
+    if (g.mx_scale_e4m3 || g.group_size != 32 || a.M < 1) return false;
+    const bool f8 = g.mx_x == MX_FP8 && g.mx_w == MX_FP8, f4 = g.mx_x == MX_FP4 && g.mx_w == MX_FP4;
+    const bool f84 = g.mx_x == MX_FP8 && g.mx_w == MX_FP4;
+    if (!f8 && !f4 && !f84) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 64 != 0 || a.K % 256 != 0) return false;
+    if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
+    if ((int64_t)a.M * a.stride_xm >= (1ll << 31) || (int64_t)a.N * a.stride_wn >= (1ll << 31)) return false;
+    if ((int64_t)(a.K / 32) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
+    if (!(a.output_dtype == GEMLITE_DT_FP32 || a.output_dtype == GEMLITE_DT_FP16 || a.output_dtype == GEMLITE_DT_BF16)) return false;
+    const int oal = a.output_dtype == GEMLITE_DT_FP32 ? 16 : 8;
+    if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
+    if (a.channel_scale_mode == 4) {
+        if (!g.sx_blocks || g.stride_sx_blk_m % 4 != 0 || ((uintptr_t)g.sx_blocks % 4) != 0) return false;
+        if ((int64_t)((a.M + 31) / 32 * 32) * g.stride_sx_blk_m >= (1ll << 31)) return false;
+    } else if (a.channel_scale_mode != 2 && a.channel_scale_mode != 0) {
+        return false;
+    }
+    if (a.stride_meta_n != 1 || ((uintptr_t)a.scales % 4) != 0 || a.stride_meta_g % 4 != 0) return false;  // 4-byte scale pieces
+    const int64_t tiles = (int64_t)(a.N / 64) * ((a.M + 63) / 64);
+    if (tiles > 0x7FFFFFFF) return false;
+    // one round of tiles: 4 stages in flight per block; more: 2 stages, two co-resident blocks per CU (the A8W8 kernel's measurements);
+    // tuning[2] = 2 / 3 / 4 picks the depth under tuning[0] = 6
+    const int nst = (a.tuning[0] == 6 && (a.tuning[2] == 2 || a.tuning[2] == 3 || a.tuning[2] == 4)) ? a.tuning[2] : (tiles <= 256 ? 4 : 2);
+    const bool bx = a.channel_scale_mode == 4;
+    auto pick = [&](auto af, auto bf) -> mx_kernel_fn_t {
+        constexpr int A = decltype(af)::value, B = decltype(bf)::value;
+        if (bx) return nst == 2 ? gemm_mx_sq_kernel<A, B, 2, true> : (nst == 3 ? gemm_mx_sq_kernel<A, B, 3, true> : gemm_mx_sq_kernel<A, B, 4, true>);
+        return nst == 2 ? gemm_mx_sq_kernel<A, B, 2, false> : (nst == 3 ? gemm_mx_sq_kernel<A, B, 3, false> : gemm_mx_sq_kernel<A, B, 4, false>);
+    };
+    typedef std::integral_constant<int, 0> F8;
+    typedef std::integral_constant<int, 4> F4;
+    mx_kernel_fn_t f = f8 ? pick(F8{}, F8{}) : (f4 ? pick(F4{}, F4{}) : pick(F8{}, F4{}));
+    g.splitk = 1;
+    g.flags = a.tuning[3];
+    lp.fn = (const void*)f;
+    lp.name = f8 ? "gemm_mx_a8w8_sq_kernel<64x64>" : (f4 ? "gemm_mx_a4w4_sq_kernel<64x64>" : "gemm_mx_a8w4_sq_kernel<64x64>");
+    lp.grid = dim3((unsigned)tiles, 1, 1);
+    lp.block = dim3(512, 1, 1);
+    const size_t stage = (size_t)64 * ((f4 ? 128 : 256) + (f8 ? 256 : 128)) + 1024;
+    lp.lds_bytes = (size_t)nst * stage;
+    if (lp.lds_bytes < 64 * 68 * 4) lp.lds_bytes = 64 * 68 * 4;
+    lp.ws_bytes = 0;
+    lp.slab_bytes = 0;
+    return true;
+}
+
 typedef void (*mx_kernel_fn)(const GenericParams);
 template <int AF, int BF>
 static const void* mx_pick(int mi) {

@@ -68,6 +68,7 @@ MAKERS = {
     "A4W4_MXFP_dynamic": lambda: H.A4W4_MXFP_dynamic(device=dev, dtype=tdt).from_linear(linear(), del_orig=True),
     "A4W4_NVFP_dynamic": lambda: H.A4W4_NVFP_dynamic(device=dev, dtype=tdt).from_linear(linear(), del_orig=True),
 }
+MS = tuple(int(v) for v in os.environ.get("GL_MS", "1,16").split(","))  # GL_MS=64,256,2048: the prefill survey
 only = sys.argv[1:]
 for name, mk in MAKERS.items():
     if only and name not in only:
@@ -79,11 +80,14 @@ for name, mk in MAKERS.items():
         continue
     wbytes = sum(t.numel() * t.element_size() for t in (layers[0].W_q, layers[0].scales, layers[0].zeros) if t is not None and t.numel() > 1)
     rec = dict(proc=name, weight_MB=round(wbytes / 1e6, 2))
-    for M in (1, 16):
+    for M in MS:
         x = (torch.randn(M, K, device=dev) / 10).to(tdt)
         us = graph_us(lambda i: layers[i % 24](x), 24)
         rec[f"m{M}_us"] = round(us, 2)
-        rec[f"m{M}_frac_of_8TBs"] = round(wbytes / (us * 1e-6) / 8e12, 3)
+        if M <= 16:
+            rec[f"m{M}_frac_of_8TBs"] = round(wbytes / (us * 1e-6) / 8e12, 3)
+        else:
+            rec[f"m{M}_TFLOPs"] = round(2.0 * M * N * K / (us * 1e-6) / 1e12, 1)
     print(json.dumps(rec), flush=True)
     del layers
     torch.cuda.empty_cache()

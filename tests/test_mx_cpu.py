@@ -148,10 +148,20 @@ def test_c_abi_routes_block_scaled_formats():
         return a
 
     name = lambda a: lib.gemlite_hip_kernel_name(C.byref(a)).decode()  # noqa: E731
-    assert name(args(16, 8, 256, 4, N=8192, K=8192)) == "gemm_mx_a8w8_kernel<128x128>"
-    assert name(args(16, 4, 256, 2, N=8192, K=8192)) == "gemm_mx_a8w4_kernel<128x128>"
-    assert name(args(17, 4, 256, 4, N=8192, K=8192)) == "gemm_mx_a4w4_kernel<128x128>"
-    assert name(args(16, 8, 256, 4)) == "gemm_mx_a8w8_kernel<128x128>"  # the tallest tile that fills the chip with <= K / 1024 slices
+    # round 4: 65 .. 384 rows (512 for fp4 x fp4 and one-round shapes) on 64 x 64 tiles with K unsplit
+    assert name(args(16, 8, 256, 4, N=8192, K=8192)) == "gemm_mx_a8w8_sq_kernel<64x64>"
+    assert name(args(16, 4, 256, 2, N=8192, K=8192)) == "gemm_mx_a8w4_sq_kernel<64x64>"
+    assert name(args(17, 4, 256, 4, N=8192, K=8192)) == "gemm_mx_a4w4_sq_kernel<64x64>"
+    assert name(args(16, 8, 65, 4)) == "gemm_mx_a8w8_sq_kernel<64x64>"
+    assert name(args(16, 8, 512, 4)) == "gemm_mx_a8w8_sq_kernel<64x64>"    # 512 tiles, K <= 4096
+    assert name(args(17, 4, 512, 4, N=8192, K=8192)) == "gemm_mx_a4w4_sq_kernel<64x64>"
+    assert name(args(16, 4, 512, 2, N=8192, K=8192)) == "gemm_mx_a8w4_kernel<128x128>"
+    a = args(16, 8, 256, 4)
+    a.tuning[0] = 2                                                       # A/B switch: the 128-column kernel with K slices
+    assert name(a) == "gemm_mx_a8w8_kernel<128x128>"  # the tallest tile that fills the chip with <= K / 1024 slices
+    a.tuning[0] = 6                                                       # ... and the forced form, at any M
+    a.M = 700
+    assert name(a) == "gemm_mx_a8w8_sq_kernel<64x64>"
     assert name(args(16, 8, 2048, 4, N=8192, K=8192)) == "gemm_mx_a8w8_tile_kernel<256x256>"  # >= 96 tiles of 256 x 256
     assert name(args(16, 8, 512, 4, N=8192, K=8192)) == "gemm_mx_a8w8_kernel<128x128>"        # 64 tiles: the 128-row kernel
     assert name(args(16, 8, 1, 4)) == "mx_rows_a8w8_kernel<16x16>"    # round 4: fp8 / fp4 activations take the few-row MFMA kernel from 1 row
@@ -167,8 +177,10 @@ def test_c_abi_routes_block_scaled_formats():
     a.tuning[0] = 5
     assert name(a) == "mx_gemv_w8_kernel"
     assert name(args(15, 8, 100, 0)) == "gemm_a16w8_mxfp_kernel<64x128>"     # above 64 rows: the tile kernel (bf16 x, bf16 out)
-    assert name(args(17, 4, 300, 4, K=11008)) == "mx_rows_a4w4_kernel<64x16>"   # fp4 activations, K % 512 != 0: no tile kernel -> 64-row tiles of the few-row kernel
-    assert name(args(17, 4, 300, 4, K=4096)) == "gemm_mx_a4w4_kernel<128x128>"
+    assert name(args(17, 4, 300, 4, K=11008)) == "gemm_mx_a4w4_sq_kernel<64x64>"  # fp4 activations, K % 512 != 0 but K % 256 == 0: the 64 x 64 tiles take it (round 4)
+    assert name(args(17, 4, 600, 4, K=11008)) == "mx_rows_a4w4_kernel<64x16>"   # ... above their row range: no tile kernel -> 64-row tiles of the few-row kernel
+    assert name(args(17, 4, 300, 4, K=4096)) == "gemm_mx_a4w4_sq_kernel<64x64>"
+    assert name(args(17, 4, 600, 4, K=4096)) == "gemm_mx_a4w4_kernel<128x128>"
     assert name(args(16, 8, 5, 4)) == "mx_rows_a8w8_kernel<16x16>"       # round 4: 5 .. 64 rows, 16-column blocks
     assert name(args(16, 4, 33, 2)) == "mx_rows_a8w4_kernel<64x16>"
     assert name(args(17, 4, 20, 4)) == "mx_rows_a4w4_kernel<32x16>"

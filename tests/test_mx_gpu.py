@@ -165,6 +165,8 @@ def test_processor_forward_vs_oracle(proc, tdt):
             want = "mx_rows_"  # round 4: 1 .. 64 rows of the fp8 / fp4 activation formats
         if M <= 64 and "NVFP" in proc:
             want = "nvfp4_rows_"  # round 4: both operands expanded to fp16 in registers, two v_mfma_f32_16x16x32_f16 per chunk and 16 rows
+        if M > 64 and "dynamic" in proc and "NVFP" not in proc:
+            want = EXPECT[proc].replace("_kernel", "_sq_kernel")  # round 4: 65 .. 384 rows on 64 x 64 tiles, K unsplit
         if M <= 64 and proc.startswith("A16"):
             want = "a16w8_mxfp_rows_kernel" if "W8" in proc else "a16w4_mxfp_rows_kernel"  # round 4: the weight-only layers on the A16W8 rows kernel
         assert name.startswith(want), (proc, M, name)
@@ -350,18 +352,24 @@ def test_nvfp4_few_row_kernel_against_the_oracle_and_the_tile_kernel():
 
 def test_fp4_activations_with_k_not_a_multiple_of_512_leave_the_coverage_kernel():
     """The fp4 x fp4 tile kernels step 512 k; K = 11008 (Llama down_proj) is 21.5 such steps and ran on the coverage kernel in rounds 2-3
-    (4.5 ms at 4096 x 11008).  Round 4: any M on 64-row tiles of the few-row kernel (grid.y), 128-k chunks."""
+    (4.5 ms at 4096 x 11008).  Round 4: any M on 64-row tiles of the few-row kernel (grid.y), 128-k chunks; 65 .. 512 rows on the 64 x 64
+    tile kernel (256-k steps: K = 1280 and 11008 are whole numbers of them), K % 256 != 0 still on the few-row kernel."""
     tdt = torch.bfloat16
     N, K = 256, 1280
     lin = _linear(N, K, tdt, seed=21)
     bias = lin.bias.data.float().cpu().numpy().astype(np.float64)
     layer = PROCS["A4W4_MXFP_dynamic"](tdt).from_linear(lin, del_orig=False)
     g = torch.Generator().manual_seed(17)
-    for M in (7, 64, 65, 100, 300):
+    for M in (7, 64, 65, 100, 300, 600):
         x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
         name = _kernel_name(layer, x)
-        assert name.startswith("mx_rows_a4w4_kernel"), name
+        assert name.startswith("gemm_mx_a4w4_sq_kernel" if 64 < M <= 512 else "mx_rows_a4w4_kernel"), name
         _check(f"a4w4 K=1280 M={M} {name}", layer(x), _oracle(layer, x) + bias, tdt)
+    lin2 = _linear(N, K + 128, tdt, seed=22)
+    layer2 = PROCS["A4W4_MXFP_dynamic"](tdt).from_linear(lin2, del_orig=False)
+    x = (torch.randn(100, K + 128, generator=g) / 4).to(tdt).to(DEV)
+    assert _kernel_name(layer2, x).startswith("mx_rows_a4w4_kernel"), _kernel_name(layer2, x)
+    _check("a4w4 K=1408 M=100", layer2(x), _oracle(layer2, x) + lin2.bias.data.float().cpu().numpy().astype(np.float64), tdt)
 
 
 @pytest.mark.parametrize("M", [1, 4, 16])
@@ -415,6 +423,42 @@ def test_prefill_tile_kernel_vs_oracle(proc, kname, tdt):
             _check(f"{proc} {tdt} M={M} 8-wave kernel", layer(x), ref, tdt)
         finally:
             C.TUNING_OVERRIDE = None
+
+
+@pytest.mark.parametrize("proc,kname", [("A8W8_MXFP_dynamic", "gemm_mx_a8w8_sq_kernel"), ("A4W4_MXFP_dynamic", "gemm_mx_a4w4_sq_kernel"),
+                                        ("A8W8_MXFP_dynamic_post", "gemm_mx_a8w8_sq_kernel"), ("A8W4_MXFP_dynamic", "gemm_mx_a8w4_sq_kernel"),
+                                        ("A8W4_MXFP_dynamic_post", "gemm_mx_a8w4_sq_kernel")])
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
+def test_unsplit_64x64_tile_kernel_vs_oracle(proc, kname, tdt):
+    """gemm_mx_sq_kernel (round 4): 64 x 64 tiles, K unsplit, both operands and the block scales through LDS — the default between 65 and
+    ~256 rows where its tiles fill the chip about once; forced (tuning[0] = 6) on ragged M at every stage depth, K = 256 (one step,
+    shorter than the pipeline) and a K that is an odd number of steps; against the oracle and the 128-column kernel (tuning[0] = 2)."""
+    g = torch.Generator().manual_seed(17)
+    for N, K, Ms in ((512, 2048 + 256, (300, 65, 33)), (192, 256, (100,)), (1024, 1024, (256,))):
+        lin = _linear(N, K, tdt, seed=23)
+        bias = lin.bias.data.clone()
+        layer = PROCS[proc](tdt).from_linear(lin, del_orig=False)
+        for M in Ms:
+            x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
+            ref = _oracle(layer, x) + bias.float().cpu().numpy().astype(np.float64)
+            if M > 64:
+                assert _kernel_name(layer, x).startswith(kname), (M, _kernel_name(layer, x))  # the default here
+            for tuning in ((6, 0, 0, 0), (6, 0, 2, 0), (6, 0, 3, 0), (6, 0, 4, 0)):
+                try:
+                    C.TUNING_OVERRIDE = tuning
+                    name = _kernel_name(layer, x, tuning)
+                    assert name.startswith(kname), (M, tuning, name)
+                    y = layer(x)
+                finally:
+                    C.TUNING_OVERRIDE = None
+                _check(f"{proc} {tdt} {N}x{K} M={M} {tuning} {name}", y, ref, tdt)
+            if K % (512 if "A4" in proc else 256) == 0:
+                try:  # and the 128-column kernel gives the same answer
+                    C.TUNING_OVERRIDE = (2, 0, 0, 0)
+                    assert "sq_kernel" not in _kernel_name(layer, x, (2, 0, 0, 0))
+                    _check(f"{proc} {tdt} M={M} 8-wave kernel", layer(x), ref, tdt)
+                finally:
+                    C.TUNING_OVERRIDE = None
 
 
 def test_prefill_tile_kernel_is_the_default_when_the_tiles_fill_the_chip():
