@@ -385,13 +385,15 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
                                 mt == GEMLITE_MATMUL_GEMV_SPLITK || (mt == GEMLITE_MATMUL_AUTO && a.M <= 1));
         LaunchPlan lp{};
         if (p.gs_shift < 0) goto coverage;  // group size not a power of two
-        // 5 .. 64 rows of 8-bit activations x packed weights (round 4): 16-column blocks on the 16-row fp8 / int8 MFMA (tuning[0] = 4: from 2 rows)
+        // 2 .. 64 rows of 8-bit activations x packed weights (round 4): 16-column blocks on the 16-row fp8 / int8 MFMA.  (From 2 rows, not 5:
+        // the streaming GEMV below re-reads the weights per row pair — 4096^2 M = 4 `layer(x)` 14.1 vs 9.5 us, 2-bit 14336 x 4096 M = 3 74.7 vs
+        // 16.0, profiles/r04/probe_a8wn_fewrows.log.)  tuning[0] = 4 forces it at one row, 7 keeps the GEMV up to 4 rows.
         if (x8 && (want_gemv || mt == GEMLITE_MATMUL_AUTO) && a.tuning[1] == 0 && a.tuning[2] == 0 &&
-            (a.tuning[0] == 4 || (a.tuning[0] == 0 && a.M >= 5)) && plan_a8wn_rows(a, p, lp)) {
+            (a.tuning[0] == 4 || (a.tuning[0] == 0 && a.M >= 2)) && plan_a8wn_rows(a, p, lp)) {
             r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
         }
         // decode sizes of 8-bit activations x packed weights (A8Wn fp8 dynamic, BitNet int8): per-weight cast to the activation type
-        if (x8 && a.M <= 4 && (want_gemv || mt == GEMLITE_MATMUL_AUTO) && a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 &&
+        if (x8 && a.M <= 4 && (want_gemv || mt == GEMLITE_MATMUL_AUTO) && (a.tuning[0] == 0 || a.tuning[0] == 7) && a.tuning[1] == 0 && a.tuning[2] == 0 &&
             plan_gemv_a8wn(a, p, lp)) {
             r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
         }

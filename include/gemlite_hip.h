@@ -199,8 +199,14 @@ typedef struct gemlite_hip_forward_args {
      *                              [3] & 32768: test switch of the in-launch activation quantisation (no producer block runs)
      *   block-scaled (MX / NVFP4)  [0] 1 = coverage kernel, 2 = the 8-wave scaled-MFMA tile kernels at any M, 3 = the 256 x 256 tile
      *                              kernel at any M, 4 = the few-row kernel (default for 1..64 rows of fp8 / fp4 activations) past
-     *                              its x re-read budget, 5 = the streaming kernel of rounds 2-3 (M <= 4)
+     *                              its x re-read budget, 5 = the streaming kernel of rounds 2-3 (M <= 4), 6 = the unsplit 64 x 64
+     *                              tiles of round 4 at any M (default for 65..384 rows, to 512 for fp4 x fp4 and one-round
+     *                              shapes; [2] = 2/3/4 LDS stages)
      *                              [1] K slices   [2] tile rows / 32   (NVFP4: [0] = 1 coverage kernel, else the fp16 tile kernel)
+     *   8-bit x packed (A8Wn, BitNet int8)   [0] 4 = the 16-column few-row kernel also at one row (default for 2..64 rows),
+     *                              7 = the streaming GEMV of rounds 2-3 up to 4 rows
+     *   unpacked 8-bit under 16-bit x (A16W8)   [0] 4 = the 16-column rows kernel at any M (default for 2..64 rows; above: the 8-wave
+     *                              tile kernel, [1] K slices, [2] tile rows / 32), 7 = the streaming kernel of rounds 1-3
      *   [3] & 4: development timeline stamps (needs a workspace)   [3] & 8: XCD-aware (tile, K slice) map (opt-in).
      *   A value that does not apply to the shape makes the planner fall through to its own choice or to another family;
      *   it never produces a wrong result. */

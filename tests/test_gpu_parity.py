@@ -1324,14 +1324,15 @@ def test_a8wn_fp8_activations_on_the_mfma_kernel(nbits, tdt):
                 # the reference's GEMM_SPLITK family; ONE row = its GEMV family, whose dot product keeps the dequantised weight in the
                 # metadata type (gemv_revsplitK_kernels.py:331-332) — round 4, pinned by the reference's own M = 1 output on the
                 # MI355X (tests/golden/fullsize_ref_r4.npz, a8w4_fp8dyn_m1)
-                y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1)
+                # (2 .. 4 rows: the default is the rows kernel since round 4 — tuning[0] = 7 keeps this one)
+                y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1, (7, 0, 0, 0) if M > 1 else (0, 0, 0, 0))
                 torch.cuda.synchronize()
                 y_or1 = y_or if M > 1 else O.forward_packed(
                     xq, lin.W_q.data.cpu().numpy(), O.to_f64(lin.scales.data), z, W_nbits=nbits, group_size=lin.group_size,
                     W_group_mode=lin.W_group_mode, channel_scale_mode=lin.channel_scale_mode, scales_x=sx, weight_cast_code=out_code)
                 _compare(f"a8wn/w{nbits}/{str(tdt)[6:]}/g{gs}/post{int(post)}/M{M}/gemv", y, y_or1, out_code, abs_gate=None)
-            if 2 <= M <= 64:  # round 4: the rows kernel (default from 5 rows, forced below): per-weight cast to e4m3 like the tile kernel
-                tun = (0, 0, 0, 0) if M >= 5 else (4, 0, 0, 0)
+            if 2 <= M <= 64:  # round 4: the rows kernel (the default from 2 rows): per-weight cast to e4m3 like the tile kernel
+                tun = (0, 0, 0, 0)
                 a = gemlite_amd.core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
                 a.matmul_type, a.M, a.x, a.out, a.scales_x = -1, M, 0x1000, 0x1000, 0x1000
                 a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = K, 1, N, 1
@@ -1373,8 +1374,8 @@ def test_bitnet_int8_activations_on_the_int8_mfma_are_exact(M):
     x = (torch.randn(M, K) / 10).half().to(DEV)
     y = lin(x)
     torch.cuda.synchronize()
-    # (round 4: 5 .. 64 rows on a8wn_rows_kernel — v_mfma_i32_16x16x64_i8 — the 8-wave tile kernel above)
-    assert _kernel_name(lin, x).startswith("gemv_a8w2_kernel<" if M <= 4 else ("a8w2_rows_kernel<" if M <= 64 else "gemm_a8w2_mma_kernel<")), _kernel_name(lin, x)
+    # (round 4: 2 .. 64 rows on a8wn_rows_kernel — v_mfma_i32_16x16x64_i8 — the 8-wave tile kernel above)
+    assert _kernel_name(lin, x).startswith("gemv_a8w2_kernel<" if M <= 1 else ("a8w2_rows_kernel<" if M <= 64 else "gemm_a8w2_mma_kernel<")), _kernel_name(lin, x)
     xq, sx = scale_activations_per_token(x, w_dtype=torch.int8)
     dot = (xq.cpu().to(torch.int64) @ Wt.to(torch.int64).t())  # exact
     assert int(dot.abs().max()) < (1 << 24)

@@ -199,7 +199,8 @@ def test_struct_abi_and_validation():
     (dict(M=1, in_dt=4, w_mode=1, c_mode=1, out_dt=0), "generic_matmul_kernel"),  # int8 x W4 with tensor zeros, fp32 out
     # 8-bit activations x packed weights (A8Wn fp8 dynamic, BitNet int8: helper.py:502-615, 1006-1062): fp8 / int8 MFMA
     (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "gemv_a8w4_kernel<tile16,16w>"),   # decode: per-weight cast, no K split
-    (dict(M=4, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=3, c_mode=2), "gemv_a8w4_kernel<tile16,16w>"),
+    (dict(M=4, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=3, c_mode=2), "a8w4_rows_kernel<16x16>"),   # round 4: from 2 rows (the GEMV re-reads the weights per row pair)
+    (dict(M=4, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=3, c_mode=2, tuning=(7, 0, 0, 0)), "gemv_a8w4_kernel<tile16,16w>"),  # A/B switch
     (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, tuning=(0, 0, 1, 0)), "gemm_a8w4_mma_kernel<32x128>"),
     (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, mt=4), "gemm_a8w4_mma_kernel<32x128>"),  # manual GEMM
     (dict(M=8, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "a8w4_rows_kernel<16x16>"),   # round 4: 5 .. 64 rows, 16-column blocks on the 16-row fp8 MFMA
