@@ -225,17 +225,23 @@ static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, cons
     if ((a.tuning[0] == 4 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0)) && plan_mx_rows(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
     // 16-bit activations x block-scaled weights, 1 .. 64 rows (round 4): the A16W8 rows kernel with the scaled converters — while every
     // block's re-read of x (M K 2 bytes x N / 16 blocks) stays in budget.  tuning[0] = 4 forces it, 5 / 2 keep the streaming / tile kernels
-    if ((a.input_dtype == GEMLITE_DT_MXFP16 || a.input_dtype == GEMLITE_DT_MXBF16) && a.M <= 64 &&
-        (a.tuning[0] == 4 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && (a.M <= 16 || (int64_t)a.M * a.K * 2 * (a.N / 16) <= (176ll << 20)))) &&
+    // (round 4, profiles/r04/probe_rows_vs_tiles*.log: against the tile kernel the crossover sits at M N K ~ 570 M for 4096^2-sized layers
+    //  — M = 34; M = 64: 19.0 vs 13.0 us — and ~ 250 M for the larger ones: 8192^2 and 14336 x 4096 from 4 rows, M = 16: 25.4 vs 17.7)
+    const bool mx16 = a.input_dtype == GEMLITE_DT_MXFP16 || a.input_dtype == GEMLITE_DT_MXBF16;
+    const bool a16_over = mx16 && a.M >= 2 && a.M <= 64 && a.N % 128 == 0 && a.K % 128 == 0 &&
+                          (int64_t)a.M * a.N * a.K > ((int64_t)a.N * a.K <= (32ll << 20) ? 570000000ll : 250000000ll);
+    if (mx16 && a.M <= 64 && (a.tuning[0] == 4 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && !a16_over)) &&
         plan_a16w8_rows(a, r.lp)) { r.kind = K_KMAJOR; return; }
-    // decode sizes of what is left (K % 64 != 0 ...): the streaming kernel
-    if ((a.tuning[0] == 0 || a.tuning[0] == 5) && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
     // 65 .. 384 (512) rows (round 4): 64 x 64 tiles, K unsplit; tuning[0] = 6 forces them, 2 keeps the 128-column kernel with its K slices
     // (profiles/r04/probe_mx_sq.log, `layer(x)` at 4096^2 / 8192^2 / 4096 x 14336 / 14336 x 4096: ahead or within 5 % everywhere up to 384
     //  rows — 4096^2 M = 256: fp8 27.2 -> 17.4 us, fp4 29.7 -> 13.7; at 512 rows for fp4 x fp4 and for one-round shapes)
-    const bool sq_auto = a.M > 64 && (a.M <= 384 || (a.M <= 512 && ((g.mx_x == MX_FP4 && g.mx_w == MX_FP4) ||
-                                                                     ((a.N / 64) * ((a.M + 63) / 64) <= 512 && a.K <= 4096))));
+    // Up to 64 rows they take what the few-row kernel's budget refuses (plan_mx_rows): fp4 x fp4 anywhere, fp8 activations from 128 column tiles.
+    const bool sq_few = a.M >= 2 && a.M <= 64 && ((g.mx_x == MX_FP4 && g.mx_w == MX_FP4) || a.N / 64 >= 128);
+    const bool sq_auto = sq_few || (a.M > 64 && (a.M <= 384 || (a.M <= 512 && ((g.mx_x == MX_FP4 && g.mx_w == MX_FP4) ||
+                                                                                ((a.N / 64) * ((a.M + 63) / 64) <= 512 && a.K <= 4096)))));
     if ((a.tuning[0] == 6 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && sq_auto)) && plan_gemm_mx_sq(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
+    // decode sizes of what is left (K % 64 != 0 ...): the streaming kernel
+    if ((a.tuning[0] == 5 || (a.tuning[0] == 0 && !a16_over)) && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
     // prefill sizes of the same-format pairs: 256 x 256 tiles, both operands through LDS (tuning[0] = 3 forces it at any M)
     if (plan_gemm_mx_tile(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
     if ((a.tuning[0] == 0 || a.tuning[0] == 2) && plan_gemm_mx_mma(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
@@ -295,8 +301,10 @@ static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, cons
 // more than 64 rows and at most one round of tiles over the CUs (4096^2 int8: M = 65 .. 256 17.0 .. 21.7 -> 11.2 .. 13.6 us, 8192^2 M = 128
 // 28.4 -> 24.2), or up to two rounds of a short K with two blocks per CU (4096^2 M = 384 / 512: 31.5 / 23.9 -> 19.3 / 21.5 us; at
 // K = 8192 two rounds lose: 8192^2 M = 256 39.4 vs 34.4)
+// Up to 64 rows (one row tile) they take what the rows kernel's budget refuses from 128 column tiles (plan_a8w8_rows).
 static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
-    if (a.M <= 64 || a.N % 64 != 0) return false;
+    if (a.N % 64 != 0) return false;
+    if (a.M <= 64) return a.M >= 2 && a.N / 64 >= 128 && a.N / 64 <= 512;
     const int64_t tiles = (a.N / 64) * ((a.M + 63) / 64);
     return tiles <= 256 || (tiles <= 512 && a.K <= 4096);
 }
@@ -572,7 +580,10 @@ coverage:
         }
         // round 4, more than 64 rows: the 8-wave MFMA tile kernel with the K-contiguous 8-bit geometry (x through LDS, weights converted
         // in registers); the per-channel pre-scale becomes the epilogue's channel scale.  tuning[0] = 4 keeps the rows kernel.
-        if (a.M > 64 && (a.tuning[0] == 0 || a.tuning[0] == 2) && !(a.W_group_mode == 2 && a.channel_scale_mode != 0)) {
+        // (rows vs tile, profiles/r04/probe_rows_vs_tiles*.log: the crossover sits at M N K ~ 850 M — 4096^2: M = 52, 8192^2: 13 (M = 64 there:
+        //  67.6 vs 29.1 us), 14336 x 4096: 12, 4096 x 14336: 19)
+        if ((a.tuning[0] == 2 || ((a.M > 64 || (a.M >= 2 && (int64_t)a.M * a.N * a.K > 850000000ll)) && a.tuning[0] == 0)) &&
+            !(a.W_group_mode == 2 && a.channel_scale_mode != 0)) {
             WnParams p{};
             p.x = a.x; p.w = (const uint32_t*)a.w_q; p.scales = a.scales; p.zeros = nullptr;
             p.epi = make_epilogue(a);

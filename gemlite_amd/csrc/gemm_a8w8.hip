@@ -1069,6 +1069,11 @@ bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq) 
     // 8-wave tiles (4096^2: 7.5 / 8.8 / 13.4 us at M = 17 / 32 / 64 against 16.9 / 17.4 / 18.3; 8192^2 M = 17: 21.3 vs 24.7), beyond
     // they lose (8192^2 M = 32: 28.1 vs 24.9; M = 64: 43.9 vs 27.7) — profiles/r03/probe_a8w8_rows_mt.log.  tuning[0] = 4 forces them.
     if (mt > 1 && a.tuning[0] != 4 && (int64_t)a.M * a.K * (a.N / 16) > (88ll << 20)) return false;
+    // round 4 (profiles/r04/probe_rows_vs_tiles*.log): against the unsplit 64 x 64 tiles, which fill the chip from N / 64 >= 128 column
+    // tiles even with one row tile, the crossover sits at M N K ~ 800 M (8192^2: M = 12), and at ~ 250 M from 192 column tiles
+    // (14336 x 4096: M = 4; M = 16: 24.4 vs 19.1 us, M = 64: 30.8 vs 21.9)
+    if (a.M >= 2 && a.tuning[0] != 4 && !fq && a.N % 64 == 0 && a.K % 256 == 0 && a.N / 64 >= 128 &&
+        (int64_t)a.M * a.N * a.K > (a.N / 64 >= 192 ? 250000000ll : 800000000ll)) return false;
     auto pick = [&](auto dt) -> const void* {
         constexpr int DT = decltype(dt)::value;
         if (fq) return mt == 1 ? (const void*)a8w8_rows_kernel<DT, 1, true> : (mt == 2 ? (const void*)a8w8_rows_kernel<DT, 2, true> : (const void*)a8w8_rows_kernel<DT, 4, true>);

@@ -606,6 +606,14 @@ bool plan_mx_rows(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPla
     const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
     const int64_t xrow = g.mx_x == MX_FP8 ? a.K : a.K / 2;
     if (mt > 1 && a.tuning[0] != 4 && !any_m && (int64_t)a.M * xrow * (a.N / 16) > (88ll << 20)) return false;  // every block re-reads its rows of x from L2
+    // round 4 (profiles/r04/probe_rows_vs_tiles*.log), against the unsplit 64 x 64 tiles (K % 256 == 0, N % 64 == 0): fp4 x fp4 — ahead only
+    // up to ~22 rows with fewer than 128 column tiles (4096^2 M = 40: 14.8 vs 12.7 us; 4096 x 14336: 33.6 vs 24.4) and up to 2 rows from 128
+    // (8192^2 M = 4: 18.6 vs 16.2; 14336 x 4096 M = 40: 36.5 vs 14.5); fp8 activations — M N K <= 1.1 G from 128 column tiles (8192^2:
+    // M = 16), <= 200 M from 192 (14336 x 4096: M = 3)
+    if (a.M >= 2 && a.tuning[0] != 4 && !any_m && !fq && a.N % 64 == 0 && a.K % 256 == 0) {
+        const int64_t ct = a.N / 64, mnk = (int64_t)a.M * a.N * a.K;
+        if (g.mx_x == MX_FP4 ? (ct >= 128 ? a.M > 2 : a.M > 22) : (ct >= 192 ? mnk > 200000000ll : (ct >= 128 && mnk > 1100000000ll))) return false;
+    }
     typedef void (*fn_t)(const GenericParams);
     fn_t fn = nullptr;
     auto pick = [&](auto xf, auto wf) -> fn_t {
@@ -787,6 +795,9 @@ bool plan_nvfp4_rows(const gemlite_hip_forward_args& a, GenericParams& g, Launch
     if ((int64_t)(a.K / 16) * a.stride_meta_g + (int64_t)a.N * a.stride_meta_n >= (1ll << 31)) return false;
     const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
     if (mt > 1 && a.tuning[0] != 4 && (int64_t)a.M * (a.K / 2) * (a.N / 16) > (88ll << 20)) return false;
+    // round 4 (profiles/r04/probe_rows_vs_tiles*.log): against the fp16 tile kernel the crossover sits at M N K ~ 600 M (4096^2: M = 36 of the
+    // measured 44, 8192^2: 9, 14336 x 4096: 10 — M = 48 there: 60.6 vs 24.7 us)
+    if (a.M >= 2 && a.tuning[0] != 4 && !fq && a.N % 128 == 0 && a.K % 128 == 0 && (int64_t)a.M * a.N * a.K > 600000000ll) return false;
     typedef void (*fn_t)(const GenericParams);
     fn_t fn = fq ? nvfp4_rows_kernel<1, true> : (mt == 1 ? nvfp4_rows_kernel<1, false> : (mt == 2 ? nvfp4_rows_kernel<2, false> : nvfp4_rows_kernel<4, false>));
     lp.fn = (const void*)fn;

@@ -165,13 +165,15 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         narrow_v = a.tuning[2] - 32;
         narrow_sk = a.tuning[1] > 0 ? a.tuning[1] : 1;
     } else if (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384) && x16 && (nbits == 4 || nbits == 2) &&
-               a.M > 64 && a.N % 64 == 0 && a.K % 256 == 0) {
+               a.M > 32 && a.N % 64 == 0 && a.K % 256 == 0) {  // (33 .. 64 rows: the same two rules hold — 14336 x 4096 M = 48 18.9 -> 17.2 us, 8192^2 20.8 -> 19.9)
         const int64_t t64 = (int64_t)(a.N / 64) * ((a.M + 63) / 64);
         const int64_t x_bytes = (int64_t)(a.N / 64) * ((a.M + 63) / 64 * 64) * a.K * 2;
-        if (t64 >= 192 && t64 <= 256 && x_bytes <= (160ll << 20)) {
+        // (one row tile, M <= 64: unsplit already from 140 column tiles — 8960 x 1536 M = 64 13.3 -> 9.9 us, 11008 x 4096 18.0 -> 16.5;
+        //  profiles/r04/probe_mma_narrow_m40_m64.log)
+        if (t64 >= (a.M <= 64 ? 140 : 192) && t64 <= 256 && x_bytes <= (160ll << 20)) {
             narrow_v = 0;
             narrow_sk = 1;
-        } else if (t64 >= 96 && t64 <= 128 && a.K / 256 >= 8) {
+        } else if (t64 >= 96 && t64 <= 128 && a.K / 256 >= 8 && (a.M > 64 || a.K <= 8192)) {  // (one row tile: measured up to K = 8192)
             narrow_v = 0;
             narrow_sk = 2;
         }

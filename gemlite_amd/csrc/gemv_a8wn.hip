@@ -491,6 +491,9 @@ bool plan_a8wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& 
     if (((int64_t)(a.K / (p.group_size > 0 ? p.group_size : a.K)) * p.stride_meta_g + a.N) * 2 >= (1ll << 31)) return false;
     const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
     if (mt > 1 && a.tuning[0] != 4 && (int64_t)a.M * a.K * (a.N / 16) > (88ll << 20)) return false;
+    // round 4 (profiles/r04/probe_rows_vs_tiles*.log): against the 32- / 64-row tiles of the 8-wave kernel the crossover sits at
+    // M N K ~ 600 M (4096^2: M = 36; 8192^2: 8 — M = 16 there: 27.5 vs 22.0 us; 4096 x 14336: 11)
+    if (a.M >= 2 && a.tuning[0] != 4 && a.N % 128 == 0 && a.K % 256 == 0 && (int64_t)a.M * a.N * a.K > 600000000ll) return false;
     typedef void (*fn_t)(const WnParams);
     fn_t fn = nullptr;
     auto pick = [&](auto tag, auto nb, auto xd) -> fn_t {

@@ -110,7 +110,8 @@ def test_struct_abi_and_validation():
     (dict(M=24, gs=64), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32
     (dict(M=4, gs=32), "gemm_wn_stream_kernel"),
     (dict(M=48), "gemm_w4_mma_kernel<32x128>"),       # from 33 rows: the 8-wave MFMA kernel; 4096^2: 32-row tiles x 4 slices (15.8 us vs 16.4)
-    (dict(M=48, N=11008, K=4096), "gemm_w4_mma_kernel<64x128>"),
+    (dict(M=48, N=11008, K=4096), "gemm_w4_mma_kernel<64x64>"),   # round 4: one row tile, 172 column tiles: unsplit 64 x 64 tiles (18.0 -> 16.5 us)
+    (dict(M=48, N=11008, K=4096, tuning=(0, 0, 0, 16384)), "gemm_w4_mma_kernel<64x128>"),
     (dict(M=8, N=11008, K=4096), "gemm_wn_direct_kernel<tile64>"),   # wide N: 64-column tiles, K not split
     (dict(M=48, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK at 33..64 rows: LDS-staged streaming kernel
     (dict(M=48, nbits=2), "gemm_w2_mma_kernel<64x128>"),   # every bit width has the tiled MFMA kernel
@@ -168,12 +169,15 @@ def test_struct_abi_and_validation():
     (dict(M=2, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),
     (dict(M=17, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<32x16>"),  # round 3: 2 / 4 row tiles while the x re-reads stay < 88 MB
     (dict(M=32, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<32x16>"),
-    (dict(M=17, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<32x16>"),
-    (dict(M=32, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # ... then the 8-wave MFMA kernel
+    (dict(M=8, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),
+    (dict(M=17, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),  # round 4: M N K > 800 M with >= 128 column tiles: the unsplit 64 x 64 tiles
+    (dict(M=32, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),
+    (dict(M=32, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_mma_kernel<32x128>"),  # (round 3: the 8-wave MFMA kernel)
+    (dict(M=40, N=4096, K=14336, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # 64 column tiles, long K: past the rows budget the 8-wave kernel
     (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 1, 0)), "gemm_a8w8_mma_kernel<32x128>"),
     (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<64x16>"),
     (dict(M=64, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<64x16>"),
-    (dict(M=64, N=8192, K=8192, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),   # <= 64 rows: weights straight from memory
+    (dict(M=64, N=8192, K=8192, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # round 4 (39.5 -> 30.0 us)
     (dict(M=65, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # round 4: unsplit 64 x 64 tiles while they fit
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),  # one round of CUs (config 4: 21.7 -> 13.6 us) ...
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_lds_kernel<128x128>"),   # (tuning[0] = 6: the round-3 tile, both operands through LDS)

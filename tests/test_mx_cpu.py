@@ -171,7 +171,17 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(a) == "mx_gemv_w8_kernel"
     assert name(args(16, 8, 1, 4, K=4096 + 32)) == "mx_gemv_w8_kernel"   # K % 128 != 0
     assert name(args(14, 8, 1, 0)) == "a16w8_mxfp_rows_kernel<16x16>"    # round 4: 16-bit activations x MX weights, 1 .. 64 rows: the A16W8 rows kernel
-    assert name(args(15, 4, 40, 0)) == "a16w4_mxfp_rows_kernel<64x16>"
+    assert name(args(15, 4, 40, 0)) == "gemm_a16w4_mxfp_kernel<64x128>"   # round 4: rows only while M N K <= 570 M (250 M for layers > 32 M weights)
+    assert name(args(15, 4, 30, 0)) == "a16w4_mxfp_rows_kernel<32x16>"
+    assert name(args(15, 4, 8, 0, N=8192, K=8192)) == "gemm_a16w4_mxfp_kernel<32x128>"
+    assert name(args(15, 4, 3, 0, N=8192, K=8192)) == "a16w4_mxfp_rows_kernel<16x16>"
+    assert name(args(17, 4, 22, 4)) == "mx_rows_a4w4_kernel<32x16>"           # fp4 x fp4: rows up to 22 rows below 128 column tiles, 2 rows from there
+    assert name(args(17, 4, 23, 4)) == "gemm_mx_a4w4_sq_kernel<64x64>"
+    assert name(args(17, 4, 3, 4, N=8192, K=8192)) == "gemm_mx_a4w4_sq_kernel<64x64>"
+    assert name(args(17, 4, 2, 4, N=8192, K=8192)) == "mx_rows_a4w4_kernel<16x16>"
+    assert name(args(16, 8, 16, 4, N=8192, K=8192)) == "mx_rows_a8w8_kernel<16x16>"   # fp8 activations: M N K <= 1.1 G from 128 column tiles
+    assert name(args(16, 8, 17, 4, N=8192, K=8192)) == "gemm_mx_a8w8_sq_kernel<64x64>"
+    assert name(args(18, 4, 30, 4, group=16)) == "nvfp4_rows_kernel<32x16>"     # NVFP4: rows while M N K <= 600 M
     assert name(args(14, 8, 1, 0, K=4096 + 32)) == "mx_gemv_w8_kernel"   # K % 64 != 0: the streaming kernel
     a = args(14, 8, 1, 0)
     a.tuning[0] = 5
@@ -184,16 +194,16 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(args(16, 8, 5, 4)) == "mx_rows_a8w8_kernel<16x16>"       # round 4: 5 .. 64 rows, 16-column blocks
     assert name(args(16, 4, 33, 2)) == "mx_rows_a8w4_kernel<64x16>"
     assert name(args(17, 4, 20, 4)) == "mx_rows_a4w4_kernel<32x16>"
-    assert name(args(16, 8, 64, 4, N=16384, K=16384)) == "gemm_mx_a8w8_kernel<64x128>"  # past the x re-read budget: the tile kernel
+    assert name(args(16, 8, 64, 4, N=16384, K=16384)) == "gemm_mx_a8w8_sq_kernel<64x64>"  # past the x re-read budget: the tile kernel
     a = args(16, 8, 1, 4)
     a.tuning[0] = 2                                                       # A/B switch: MFMA kernel at decode sizes
     assert name(a) == "gemm_mx_a8w8_kernel<32x128>"
-    assert name(args(17, 4, 48, 4, N=16384)) == "gemm_mx_a4w4_kernel<64x128>"   # 48 x 2 KB x 1024 blocks of x re-reads: over the budget
-    assert name(args(17, 4, 40, 4, N=16384)) == "mx_rows_a4w4_kernel<64x16>"
+    assert name(args(17, 4, 48, 4, N=16384)) == "gemm_mx_a4w4_sq_kernel<64x64>"   # 48 x 2 KB x 1024 blocks of x re-reads: over the budget
+    assert name(args(17, 4, 40, 4, N=16384)) == "gemm_mx_a4w4_sq_kernel<64x64>"
     # NVFP4: no scaled-MFMA form takes e4m3 block-16 scales; both operands are exact in fp16, so the fp16 tile kernel runs it (round 4:
     # x expanded by a kernel in front, the weights in the K loop; workspace = tickets + slabs + M K fp16 + M floats)
     assert name(args(18, 4, 8, 4, group=16)) == "nvfp4_rows_kernel<16x16>"   # 1 .. 64 rows: both operands expanded in registers
-    assert name(args(18, 4, 40, 4, group=16)) == "nvfp4_rows_kernel<64x16>"
+    assert name(args(18, 4, 40, 4, group=16)) == "gemm_nvfp4_f16_kernel<64x128>"
     assert name(args(18, 4, 256, 4, group=16)) == "gemm_nvfp4_f16_kernel<64x128>"
     a = args(18, 4, 8, 4, group=16)
     a.tuning[0] = 2                                                       # A/B switch: the tile kernel at any M

@@ -165,7 +165,7 @@ def test_processor_forward_vs_oracle(proc, tdt):
             want = "mx_rows_"  # round 4: 1 .. 64 rows of the fp8 / fp4 activation formats
         if M <= 64 and "NVFP" in proc:
             want = "nvfp4_rows_"  # round 4: both operands expanded to fp16 in registers, two v_mfma_f32_16x16x32_f16 per chunk and 16 rows
-        if M > 64 and "dynamic" in proc and "NVFP" not in proc:
+        if (M > 64 or (M > 22 and proc == "A4W4_MXFP_dynamic")) and "dynamic" in proc and "NVFP" not in proc:
             want = EXPECT[proc].replace("_kernel", "_sq_kernel")  # round 4: 65 .. 384 rows on 64 x 64 tiles, K unsplit
         if M <= 64 and proc.startswith("A16"):
             want = "a16w8_mxfp_rows_kernel" if "W8" in proc else "a16w4_mxfp_rows_kernel"  # round 4: the weight-only layers on the A16W8 rows kernel
@@ -363,7 +363,7 @@ def test_fp4_activations_with_k_not_a_multiple_of_512_leave_the_coverage_kernel(
     for M in (7, 64, 65, 100, 300, 600):
         x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
         name = _kernel_name(layer, x)
-        assert name.startswith("gemm_mx_a4w4_sq_kernel" if 64 < M <= 512 else "mx_rows_a4w4_kernel"), name
+        assert name.startswith("gemm_mx_a4w4_sq_kernel" if 22 < M <= 512 else "mx_rows_a4w4_kernel"), name
         _check(f"a4w4 K=1280 M={M} {name}", layer(x), _oracle(layer, x) + bias, tdt)
     lin2 = _linear(N, K + 128, tdt, seed=22)
     layer2 = PROCS["A4W4_MXFP_dynamic"](tdt).from_linear(lin2, del_orig=False)
