@@ -31,10 +31,12 @@ def lin(N, K):
 PROCS = {  # name -> (maker(N, K), {tag: tuning})
     "A16W4_HQQ_INT": (lambda N, K: H.A16W4_HQQ_INT(device=dev, dtype=tdt).from_weights(*hqq(N, K, 4), W_nbits=4, group_size=128),
                       {"narrow64": (0, 0, 32, 0), "narrow64x2": (0, 2, 32, 0), "mma64": (0, 0, 2, 0)}),
-    "A16W8_INT8": (lambda N, K: H.A16W8(device=dev, dtype=tdt).from_weights(lin(N, K).weight.data), {"tile": (2, 0, 0, 0)}),
+    "A16W8_INT8": (lambda N, K: H.A16W8(device=dev, dtype=tdt).from_weights(lin(N, K).weight.data), {"tile": (2, 0, 0, 0), "rows": (4, 0, 0, 0), "r3": (7, 0, 0, 0)}),
+    "A16W8_FP8": (lambda N, K: H.A16W8_FP8(device=dev, dtype=tdt).from_weights(lin(N, K).weight.data), {"tile": (2, 0, 0, 0), "rows": (4, 0, 0, 0), "r3": (7, 0, 0, 0)}),
     "A8W8_int8_dynamic": (lambda N, K: H.A8W8_int8_dynamic(device=dev, dtype=tdt).from_weights(lin(N, K).weight.data), {"sq": (5, 0, 0, 0)}),
     "A8W4_HQQ_INT_dynamic": (lambda N, K: H.A8W4_HQQ_INT_dynamic(device=dev, dtype=tdt).from_weights(*hqq(N, K, 4)), {"mma64": (0, 0, 2, 0), "mma32": (0, 0, 1, 0)}),
-    "A16W4_MXFP": (lambda N, K: H.A16W4_MXFP(device=dev, dtype=tdt).from_linear(lin(N, K), del_orig=True), {"tile": (2, 0, 0, 0)}),
+    "A16W4_MXFP": (lambda N, K: H.A16W4_MXFP(device=dev, dtype=tdt).from_linear(lin(N, K), del_orig=True), {"tile": (2, 0, 0, 0), "rows": (4, 0, 0, 0), "gemv": (5, 0, 0, 0)}),
+    "A16W8_MXFP": (lambda N, K: H.A16W8_MXFP(device=dev, dtype=tdt).from_linear(lin(N, K), del_orig=True), {"tile": (2, 0, 0, 0), "rows": (4, 0, 0, 0), "gemv": (5, 0, 0, 0)}),
     "A8W8_MXFP_dynamic": (lambda N, K: H.A8W8_MXFP_dynamic(device=dev, dtype=tdt).from_linear(lin(N, K), del_orig=True), {"sq": (6, 0, 0, 0)}),
     "A4W4_MXFP_dynamic": (lambda N, K: H.A4W4_MXFP_dynamic(device=dev, dtype=tdt).from_linear(lin(N, K), del_orig=True), {"sq": (6, 0, 0, 0)}),
     "A4W4_NVFP_dynamic": (lambda N, K: H.A4W4_NVFP_dynamic(device=dev, dtype=tdt).from_linear(lin(N, K), del_orig=True), {"tile": (2, 0, 0, 0)}),
