@@ -22,6 +22,8 @@ secondary figure only (`event_us`; an EMPTY kernel reads ~4 us through them: `ev
                     region) AND `*_layer_e2e`: layer(x) with the dynamic activation quantisation inside the timed region (round 4).
   roofline_cfg5   — BASELINE configs[4]: A16W2 g128 and FP8 x FP8 16384^2 at M = 1 / 256 (+ `*_layer_e2e` for FP8).
   roofline_m1_bf16, rotation_ab — the bf16 twin of the headline; the headline step over 32 (286 MB) vs 64 (572 MB) distinct layers.
+  roofline_mx_fewrows, roofline_mx_m256 — block-scaled formats (MXFP8 / MXFP4 / NVFP4) at 4096^2: M = 16 (few-row kernels) and M = 256
+                    (unsplit 64 x 64 scaled-MFMA tiles, round 4), matmul alone and `*_layer_e2e` with the activation quantiser inside.
   roofline_prefill_m2048 — 8192^2 at M=2048 (bf16), the large-M end of the MFMA kernel family.
   roofline_trend_m1 — the same GEMV family at 8192^2 and 16384^2 (fraction of HBM peak grows with size).
   sustained       — >= 6 s of back-to-back replays of the headline step (an outside sampler sees the GPU busy).
@@ -90,6 +92,7 @@ WORKLOADS = {
     "mx_a8w4_8192_m2048": (8192, 8192, 4, 32, 2048, "mxa8", 8, "mfma"),
     "mx_a4w4_4096_m1": (4096, 4096, 4, 32, 1, "mxa4", 32, "hbm"),
     "mx_a4w4_8192_m256": (8192, 8192, 4, 32, 256, "mxa4", 8, "mfma"),
+    "mx_a4w4_4096_m256": (4096, 4096, 4, 32, 256, "mxa4", 32, "mfma"),
     "mx_a4w4_8192_m2048": (8192, 8192, 4, 32, 2048, "mxa4", 8, "mfma"),
     # round 4: decode-batch sizes of the block-scaled formats (few-row scaled-MFMA kernel) and NVFP4 (fp16 MFMA tile kernel)
     "mx_a8w8_4096_m16": (4096, 4096, 8, 32, 16, "mxa8", 32, "hbm"),
@@ -541,6 +544,9 @@ def main():
             # pre-quantised x and layer(x) with the activation quantiser
             line["roofline_mx_fewrows"] = {w: block(w) for w in ("mx_a8w8_4096_m16", "mx_a4w4_4096_m16", "nvfp4_4096_m16", "nvfp4_4096_m256")}
             line["roofline_mx_fewrows"].update({w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a4w4_4096_m16", "nvfp4_4096_m16")})
+            # round 4: the unsplit 64 x 64 block-scaled tiles (gemm_mx_sq_kernel) at M = 256, matmul alone and the layer with its quantiser
+            line["roofline_mx_m256"] = {w: block(w) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")}
+            line["roofline_mx_m256"].update({w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")})
             line["roofline_prefill_m2048"] = block("a16w4_8192_m2048", 4)
             line["roofline_trend_m1"] = {"8192": block("a16w4_8192_m1"), "16384": block("a16w4_16384_m1")}
         except Exception as e:
