@@ -7,6 +7,23 @@ namespace gl {
 const void* mma_lookup_f16(int kind, int nbits, int mi, int xdt, int xch);
 const void* mma_lookup_bf16(int kind, int nbits, int mi, int xdt, int xch);
 
+// When the narrow 64 x 64 tiles (KH = 4, 256-k steps) are the default: 0 = never, 1 = K unsplit, 2 = two K slices.  From sweeps over 20 LLM
+// layer shapes x M = 40 .. 256 for 4-bit words under 16-bit activations (profiles/r04/probe_mma_narrow_llm_shapes.log, ..._m40_m64.log) and
+// over six other geometries x four layer sizes (probe_narrow_geos.log: the same windows hold, 0.71 .. 0.97 of the 128-column time where
+// they fire).  t64 = 64 x 64 tiles of the problem; every column tile re-reads its rows of x from L2, x_bytes in total:
+//   * 192 <= t64 <= 256 (one row tile, M <= 64: from 140) and x_bytes <= 160 MB: K UNSPLIT (4096^2 M = 256: 19.8 -> 16.8 us; beyond 160 MB
+//     the L2 -> LDS path is the limit: 4096 x 11008 M = 256, 344 MB, 33.3 -> 36.5; below 192 tiles too many CUs idle);
+//   * 96 <= t64 <= 128 (one row tile with K <= 8192: from 64): TWO K slices (<= 256 blocks: one round; 4096^2 M = 128: 15.4 -> 13.7);
+//   * the 128-row narrow tiles never beat the 128-column choice by more than 1 %: forced variants only.
+static int narrow_auto(int64_t M, int64_t N, int64_t K, int es) {
+    if (M <= 32 || N % 64 != 0 || K % 256 != 0) return 0;
+    const int64_t t64 = (N / 64) * ((M + 63) / 64);
+    const int64_t x_bytes = (N / 64) * ((M + 63) / 64 * 64) * K * es;
+    if (t64 >= (M <= 64 ? 140 : 192) && t64 <= 256 && x_bytes <= (160ll << 20)) return 1;
+    if (t64 >= (M <= 64 ? 64 : 96) && t64 <= 128 && K / 256 >= 8 && (M > 64 || K <= 8192)) return 2;
+    return 0;
+}
+
 // 16-bit activations x block-scaled weights (layer formats MXFP16 / MXBF16: A16W8_MXFP, A16W4_MXFP): the same kernel with the
 // K-contiguous weight geometry (Geo<MXW8 / MXW4>) — the weights are converted by v_cvt_scalef32_pk_* with their block scale, 4
 // VALU per fragment instead of 23.  `p` arrives with x / w / scales / epilogue / M / N / K / strides filled in by the caller.
@@ -25,7 +42,7 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     const int nb = k8 ? (a.w_dtype == GEMLITE_DT_INT8 ? mma::KW8I : (a.w_dtype == GEMLITE_DT_FP8E4 ? mma::KW8F : mma::KW8B))
                       : (nv ? mma::NVW4 : (a.W_nbits == 8 ? mma::MXW8 : mma::MXW4));
     const int sbk = nv ? 16 : 32;  // k per scale byte
-    if ((!k8 && a.group_size != sbk) || a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % mma::BN != 0 || a.K % 128 != 0) return false;
+    if ((!k8 && a.group_size != sbk) || a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 64 != 0 || a.K % 128 != 0) return false;  // (128 columns: checked behind the narrow tiles)
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0 || ((uintptr_t)a.w_q % 16) != 0 || a.stride_wn % 16 != 0) return false;
     if (((uintptr_t)a.out % 8) != 0 || (a.stride_om * 2) % 8 != 0) return false;
     if ((int64_t)a.N * a.stride_wn >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31)) return false;
@@ -35,6 +52,37 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
         if (k8 && p.epi.c_mode != 0 && p.epi.c_mode != 2 && ((uintptr_t)p.epi.scales_w % 16) != 0) return false;  // 4 channel scales per load
     }
+    const int nauto = (a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384)) ? narrow_auto(a.M, a.N, a.K, 2) : 0;
+    if (a.tuning[2] == 32 || nauto) {  // narrow tiles (64 x 64, 256-k steps, KH = 4; round 4, late): tuning[2] = 32 forces them, [1] = K slices
+        if (a.N % 64 != 0 || a.K % 256 != 0) return false;
+        const int units = (int)(a.K / 256), splitk = a.tuning[2] == 32 ? (a.tuning[1] > 0 ? a.tuning[1] : 1) : nauto;
+        if (splitk > units) return false;
+        const int64_t tiles = (int64_t)(a.N / 64) * ((a.M + 63) / 64);
+        if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
+        const void* fn = f16 ? mma_lookup_f16(6, nb, 0, 0, 0) : mma_lookup_bf16(6, nb, 0, 0, 0);
+        if (!fn) return false;
+        p.splitk = splitk;
+        p.rows_per_slice = (int)a.K;
+        p.stride_wn_b = a.stride_wn;
+        p.stride_meta_n = k8 ? 0 : a.stride_meta_n;
+        p.stride_meta_g = k8 ? 0 : a.stride_meta_g;
+        p.w_mode = 2;
+        p.gs_shift = 5;
+        p.combine = 0;
+        lp.fn = fn;
+        lp.name = k8 ? "gemm_a16w8_kernel<64x64>" : (nv ? "gemm_nvfp4_f16_kernel<64x64>" : (nb == mma::MXW8 ? "gemm_a16w8_mxfp_kernel<64x64>" : "gemm_a16w4_mxfp_kernel<64x64>"));
+        lp.grid = dim3((unsigned)tiles, splitk, 1);
+        lp.block = dim3(512, 1, 1);
+        const size_t stages = (size_t)((nb == mma::MXW8 || k8) ? 2 : 3) * 64 * 256 * 2;
+        const size_t xch = (size_t)3 * 2 * 2 * 4 * 64 * 16;  // K-part exchange: [kh - 1][cg][mi][e4][lane] float4
+        const size_t c_b = (size_t)64 * (64 + 4) * 4 + 16;
+        lp.lds_bytes = stages > xch ? stages : xch;
+        if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
+        lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * 64 * 64 * 4 : 0;
+        lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
+        return true;
+    }
+    if (a.N % mma::BN != 0) return false;
     auto kstep_of = [](int c) { return c >= 4 ? 128 : 256; };
     const int cap = a.M > 128 ? 8 : (a.M > 64 ? 4 : (a.M > 32 ? 2 : 1));
     // cheap conversion: the tallest tile that still gives >= 128 tiles (else >= 64, else the tallest M fills), then the
@@ -151,37 +199,21 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     int mi = 0, splitk = 0;
     // narrow tiles (32 MI x 64, KH = 4; round 4): tuning[2] = 32 + variant forces them (variants: gemm_wn_mma_kernel.inc, mma_pick_narrow);
     // tuning[3] & 16384 keeps the round-3 choice (A/B runs)
-    // Automatic, from a sweep of 20 LLM layer shapes x M = 128 / 192 / 256 x {64 x 64, 64 x 64 x 2 slices, 128 x 64, 128 x 64 x 2} against
-    // the round-3 choice (profiles/r04/probe_mma_narrow_llm_shapes.log).  t64 = 64 x 64 tiles of the problem; every column tile re-reads
-    // its rows of x from L2, x_bytes = (N / 64) * M * K * 2 in total:
-    //   * 192 <= t64 <= 256 and x_bytes <= 160 MB: K UNSPLIT — all ten such cells win, 0.78 .. 0.89 of the round-3 time (4096^2 M = 256:
-    //     19.8 -> 16.8 us; 8192 x 2048 M = 128: 14.7 -> 11.9); beyond 160 MB the L2 -> LDS path is the limit and K slices win again
-    //     (4096 x 11008 M = 256: 344 MB, 33.3 -> 36.5), below 192 tiles too many CUs idle (5120^2 M = 128: 160 tiles, 18.4 -> 19.3);
-    //   * 96 <= t64 <= 128: TWO K slices (<= 256 blocks: one round) — all eight such cells win, 0.85 .. 0.97 (4096^2 M = 128: 15.4 -> 13.7,
-    //     4096 x 11008 M = 128: 28.4 -> 24.2); with 144 tiles two slices make two rounds (3072 x 8192 M = 192: 22.2 -> 32.9);
-    //   * the 128-row narrow tiles never beat the round-3 choice by more than 1 % in the sweep: forced variants only.
+    // Automatic: narrow_auto() above (4- / 2-bit words under 16-bit or 8-bit activations)
     int narrow_v = -1, narrow_sk = 0;
     if (a.tuning[2] >= 32 && a.tuning[2] <= 35) {
         narrow_v = a.tuning[2] - 32;
         narrow_sk = a.tuning[1] > 0 ? a.tuning[1] : 1;
-    } else if (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384) && x16 && (nbits == 4 || nbits == 2) &&
-               a.M > 32 && a.N % 64 == 0 && a.K % 256 == 0) {  // (33 .. 64 rows: the same two rules hold — 14336 x 4096 M = 48 18.9 -> 17.2 us, 8192^2 20.8 -> 19.9)
-        const int64_t t64 = (int64_t)(a.N / 64) * ((a.M + 63) / 64);
-        const int64_t x_bytes = (int64_t)(a.N / 64) * ((a.M + 63) / 64 * 64) * a.K * 2;
-        // (one row tile, M <= 64: unsplit already from 140 column tiles — 8960 x 1536 M = 64 13.3 -> 9.9 us, 11008 x 4096 18.0 -> 16.5;
-        //  profiles/r04/probe_mma_narrow_m40_m64.log)
-        if (t64 >= (a.M <= 64 ? 140 : 192) && t64 <= 256 && x_bytes <= (160ll << 20)) {
+    } else if (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384) && (nbits == 4 || nbits == 2)) {
+        if (const int na = narrow_auto(a.M, a.N, a.K, es)) {
             narrow_v = 0;
-            narrow_sk = 1;
-        } else if (t64 >= 96 && t64 <= 128 && a.K / 256 >= 8 && (a.M > 64 || a.K <= 8192)) {  // (one row tile: measured up to K = 8192)
-            narrow_v = 0;
-            narrow_sk = 2;
+            narrow_sk = na;
         }
     }
     if (narrow_v >= 0) {
         static const int V_MI[4] = {2, 2, 4, 4}, V_KS[4] = {256, 512, 256, 256}, V_NST[4] = {3, 2, 2, 2};
         const int v = narrow_v, vmi = V_MI[v], ks = V_KS[v], bm = 32 * vmi;
-        if (!x16 || (nbits != 4 && nbits != 2) || a.N % 64 != 0 || a.K % ks != 0) return false;
+        if ((!x16 && v != 0) || (nbits != 4 && nbits != 2) || a.N % 64 != 0 || a.K % ks != 0) return false;  // (8-bit activations: variant 0 only)
         const int rows = (int)(a.K / e), units = (int)(a.K / ks);
         const int splitk = narrow_sk;
         if (splitk > units) return false;
@@ -190,17 +222,17 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         const int64_t tiles = (int64_t)(a.N / 64) * ((a.M + bm - 1) / bm);
         if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
         const bool f16 = tag_dt == GEMLITE_DT_FP16;
-        const void* fn = f16 ? mma_lookup_f16(6, nbits, v, 0, 0) : mma_lookup_bf16(6, nbits, v, 0, 0);
+        const void* fn = f16 ? mma_lookup_f16(6, nbits, v, xdt, 0) : mma_lookup_bf16(6, nbits, v, xdt, 0);
         if (!fn) return false;
         p.splitk = splitk;
         p.rows_per_slice = rows;
         p.combine = 0;
         lp.fn = fn;
         static const char* nn[2][2] = {{"gemm_w4_mma_kernel<64x64>", "gemm_w4_mma_kernel<128x64>"}, {"gemm_w2_mma_kernel<64x64>", "gemm_w2_mma_kernel<128x64>"}};
-        lp.name = nn[nbits == 4 ? 0 : 1][vmi == 2 ? 0 : 1];
+        lp.name = xdt ? (nbits == 4 ? "gemm_a8w4_mma_kernel<64x64>" : "gemm_a8w2_mma_kernel<64x64>") : nn[nbits == 4 ? 0 : 1][vmi == 2 ? 0 : 1];
         lp.grid = dim3((unsigned)tiles, splitk, 1);
         lp.block = dim3(512, 1, 1);
-        const size_t stages = (size_t)V_NST[v] * bm * ks * 2;
+        const size_t stages = (size_t)V_NST[v] * bm * ks * (x16 ? 2 : 1);
         const size_t xch = (size_t)3 * 2 * vmi * 4 * 64 * 16;  // K-part exchange: [kh - 1][cg][mi][e4][lane] float4
         const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * (64 + 4) * 4 + 16;
         lp.lds_bytes = stages > xch ? stages : xch;

@@ -181,7 +181,8 @@ typedef struct gemlite_hip_forward_args {
      *                              fallback for K = 64 * odd)
      *                              [1] K slices (any count <= K steps; slices may be uneven)
      *                              [2] tile rows / 32: 1/2/4/8 (8-wave kernel, 128-column tiles); 20 / 24 = 128 / 256 rows x 256
-     *                              columns (4- and 2-bit, 16-bit activations); 32 .. 35 = the narrow 64-COLUMN tiles of round 4
+     *                              columns (4- and 2-bit, 16-bit activations); 32 .. 35 = the narrow 64-COLUMN tiles of round 4 (32 also
+     *                              for 8-bit activations, block-scaled / NVFP4 / K-contiguous 8-bit weights)
      *                              (32: 64 x 64, 256-k steps — the default where they fill the chip without K slices, e.g.
      *                              4096^2 at M = 256; 33: 64 x 64, 512-k steps; 34 / 35: 128 x 64); with [0] = 2: 4 = one-step-ahead,
      *                              8 = 256 rows (both only in a library built with `make AB=1`)

@@ -41,24 +41,30 @@ PROCS = {  # name -> (maker(N, K), {tag: tuning})
     "A4W4_MXFP_dynamic": (lambda N, K: H.A4W4_MXFP_dynamic(device=dev, dtype=tdt).from_linear(lin(N, K), del_orig=True), {"sq": (6, 0, 0, 0)}),
     "A4W4_NVFP_dynamic": (lambda N, K: H.A4W4_NVFP_dynamic(device=dev, dtype=tdt).from_linear(lin(N, K), del_orig=True), {"tile": (2, 0, 0, 0)}),
 }
-only = sys.argv[1:]
-for N, K in ((4096, 4096), (8192, 8192), (4096, 14336), (14336, 4096)):
-    nl = max(2, min(16, (400 << 20) // (N * K)))
-    for proc, (mk, alts) in PROCS.items():
-        if only and proc not in only:
-            continue
-        layers = [mk(N, K) for _ in range(nl)]
-        for M in MS:
-            x = (torch.randn(M, K, device=dev) / 4).to(tdt)
-            rec = dict(proc=proc, N=N, K=K, M=M)
-            for tag, tun in [("default", None)] + list(alts.items()):
-                C.TUNING_OVERRIDE = tun
-                try:
-                    rec[tag] = round(graph_us(lambda i: layers[i % nl](x), nl, min_seconds=0.06), 2)
-                except Exception as e:
-                    rec[tag] = type(e).__name__
-                finally:
-                    C.TUNING_OVERRIDE = None
-            print(json.dumps(rec), flush=True)
-        del layers
-        torch.cuda.empty_cache()
+
+def main():
+    only = sys.argv[1:]
+    for N, K in ((4096, 4096), (8192, 8192), (4096, 14336), (14336, 4096)):
+        nl = max(2, min(16, (400 << 20) // (N * K)))
+        for proc, (mk, alts) in PROCS.items():
+            if only and proc not in only:
+                continue
+            layers = [mk(N, K) for _ in range(nl)]
+            for M in MS:
+                x = (torch.randn(M, K, device=dev) / 4).to(tdt)
+                rec = dict(proc=proc, N=N, K=K, M=M)
+                for tag, tun in [("default", None)] + list(alts.items()):
+                    C.TUNING_OVERRIDE = tun
+                    try:
+                        rec[tag] = round(graph_us(lambda i: layers[i % nl](x), nl, min_seconds=0.06), 2)
+                    except Exception as e:
+                        rec[tag] = type(e).__name__
+                    finally:
+                        C.TUNING_OVERRIDE = None
+                print(json.dumps(rec), flush=True)
+            del layers
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -1084,11 +1084,52 @@ def test_a16w8_tile_kernel_above_64_rows(proc, tdt):
             _compare(f"a16w8-tile/{proc}/{str(tdt)[6:]}/{N}x{K}/M{M}", y, _oracle_from_layer(lin, x), out_code, abs_gate=5e-3)
             rel = float((y.float() - y_rows.float()).abs().mean() / y_rows.float().abs().mean())
             assert rel < (2e-3 if tdt == torch.float16 else 8e-3), (proc, M, rel)
-            for tun in ((2, 1, 1, 0), (2, 2, 2, 0), (2, 1, 4, 0), (2, 4, 8, 0)):  # (tile kernel, split-K, 32-row units per tile)
+            for tun in ((2, 1, 1, 0), (2, 2, 2, 0), (2, 1, 4, 0), (2, 4, 8, 0), (2, 1, 32, 0), (2, 2, 32, 0)):  # (tile kernel, split-K, 32-row units per tile; 32 = the narrow 64 x 64 tiles)
+                if tun[2] == 32 and K % 256 != 0:
+                    continue
+                assert ("<64x64>" in _kernel_name(lin, x, tuning=tun)) == (tun[2] == 32), tun
                 y_t = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tun)
                 torch.cuda.synchronize()
                 rel = float((y_t.float() - y_rows.float()).abs().mean() / y_rows.float().abs().mean())
                 assert rel < (2e-3 if tdt == torch.float16 else 8e-3), (proc, M, tun, rel)
+
+
+@pytest.mark.parametrize("proc", ["A8W4", "A8W2", "A8W158"])
+def test_narrow_tiles_with_8bit_activations(proc):
+    """The narrow 64 x 64 tiles (KH = 4) of the 8-wave kernel for fp8 / int8 activations x packed words (round 4, late; forced with
+    tuning[2] = 32, K slices in tuning[1]): against the 128-column tiles of the same kernel — BitNet int8 bit for bit (exact int32
+    accumulation), fp8 within the fp32 summation-order tolerance — and, through them, against everything those are pinned to."""
+    from gemlite_amd import core
+    H = gemlite_amd.helper
+    torch.manual_seed(5)
+    N, K = 512, 2048 + 256
+    if proc == "A8W158":
+        lin = H.A8W158_INT_dynamic(device=DEV).from_weights(torch.randint(-1, 2, (N, K)).half(), torch.tensor(0.02))
+    else:
+        nb = 4 if proc == "A8W4" else 2
+        W_q = torch.randint(0, 2 ** nb, (N, K), dtype=torch.int32).to(torch.uint8).to(DEV)
+        s = (torch.rand(N * K // 128, 1, device=DEV) * 0.01 + 0.001).half()
+        z = (torch.rand(N * K // 128, 1, device=DEV) * (2 ** nb - 1)).half()
+        lin = (H.A8W4_HQQ_INT_dynamic if nb == 4 else H.A8W2_HQQ_INT_dynamic)(device=DEV, dtype=torch.float16).from_weights(W_q, s, z)
+    for M in (65, 200):
+        x = (torch.randn(M, K) / 4).half().to(DEV)
+        try:
+            core.TUNING_OVERRIDE = (0, 0, 2, 0)  # 64 x 128 tiles
+            assert "x128>" in _kernel_name(lin, x, tuning=(0, 0, 2, 0))
+            y0 = lin(x)
+            for tun in ((0, 1, 32, 0), (0, 3, 32, 0)):
+                core.TUNING_OVERRIDE = tun
+                name = _kernel_name(lin, x, tuning=tun)
+                assert name == ("gemm_a8w4_mma_kernel<64x64>" if proc == "A8W4" else "gemm_a8w2_mma_kernel<64x64>"), (tun, name)
+                y = lin(x)
+                torch.cuda.synchronize()
+                if proc == "A8W158":
+                    assert torch.equal(y, y0), (M, tun)
+                else:
+                    rel = float((y.float() - y0.float()).abs().mean() / y0.float().abs().mean())
+                    assert rel < 2e-3, (proc, M, tun, rel)
+        finally:
+            core.TUNING_OVERRIDE = None
 
 
 @pytest.mark.parametrize("kind", ["int8", "fp8"])

@@ -109,12 +109,12 @@ def test_struct_abi_and_validation():
     (dict(M=8, gs=64), "gemm_wn_direct_kernel<tile32>"),   # group size 64: registers-only kernel up to 16 rows
     (dict(M=24, gs=64), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32
     (dict(M=4, gs=32), "gemm_wn_stream_kernel"),
-    (dict(M=48), "gemm_w4_mma_kernel<32x128>"),       # from 33 rows: the 8-wave MFMA kernel; 4096^2: 32-row tiles x 4 slices (15.8 us vs 16.4)
+    (dict(M=48), "gemm_w4_mma_kernel<64x64>"),       # from 33 rows: the 8-wave MFMA kernel; 4096^2: 32-row tiles x 4 slices (15.8 us vs 16.4)  [round 4, late: narrow 64 x 64 tiles]
     (dict(M=48, N=11008, K=4096), "gemm_w4_mma_kernel<64x64>"),   # round 4: one row tile, 172 column tiles: unsplit 64 x 64 tiles (18.0 -> 16.5 us)
     (dict(M=48, N=11008, K=4096, tuning=(0, 0, 0, 16384)), "gemm_w4_mma_kernel<64x128>"),
     (dict(M=8, N=11008, K=4096), "gemm_wn_direct_kernel<tile64>"),   # wide N: 64-column tiles, K not split
     (dict(M=48, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK at 33..64 rows: LDS-staged streaming kernel
-    (dict(M=48, nbits=2), "gemm_w2_mma_kernel<64x128>"),   # every bit width has the tiled MFMA kernel
+    (dict(M=48, nbits=2), "gemm_w2_mma_kernel<64x64>"),   # every bit width has the tiled MFMA kernel  [round 4, late: narrow 64 x 64 tiles]
     (dict(M=48, nbits=1), "gemm_w1_mma_kernel<64x128>"),
     (dict(M=200, nbits=8), "gemm_w8_mma_kernel<64x128>"),   # tallest tile with >= 128 tiles: at most two K slices
     (dict(M=48, tuning=(1, 0, 0, 0)), "gemm_wn_stream_kernel"),          # tuning[0] = 1: LDS-staged streaming kernel
@@ -195,7 +195,7 @@ def test_struct_abi_and_validation():
     (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "a16w8_rows_kernel<16x16>"),  # fp8 W, bf16 x
     (dict(M=40, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<64x16>"),
     (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "gemm_a16w8_kernel<64x128>"),  # above 64 rows: the MFMA tile kernel
-    (dict(M=65, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "gemm_a16w8_kernel<64x128>"),
+    (dict(M=65, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "gemm_a16w8_kernel<64x64>"),  # round 4, late: narrow 64 x 64 tiles where narrow_auto() fires
     (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(4, 0, 0, 0)), "a16w8_rows_kernel<64x16>"),  # 64-row tiles along grid.y
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(7, 0, 0, 0)), "kmajor_w8a16_kernel"),  # A/B switch: rounds 1-3
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096 + 16, K=4096 + 16), "kmajor_w8a16_kernel"),    # K % 64 != 0
@@ -209,7 +209,10 @@ def test_struct_abi_and_validation():
     (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, mt=4), "gemm_a8w4_mma_kernel<32x128>"),  # manual GEMM
     (dict(M=8, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "a8w4_rows_kernel<16x16>"),   # round 4: 5 .. 64 rows, 16-column blocks on the 16-row fp8 MFMA
     (dict(M=3, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2, tuning=(4, 0, 0, 0)), "a8w4_rows_kernel<16x16>"),
-    (dict(M=100, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "gemm_a8w4_mma_kernel<64x128>"),
+    (dict(M=100, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "gemm_a8w4_mma_kernel<64x64>"),  # round 4, late: narrow 64 x 64 tiles where narrow_auto() fires
+    (dict(M=100, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2, tuning=(0, 0, 32, 0)), "gemm_a8w4_mma_kernel<64x64>"),   # round 4, late: narrow tiles for 8-bit activations (forced)
+    (dict(M=300, nbits=2, in_dt=4, out_dt=2, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3, gs=4096, tuning=(0, 2, 32, 0)), "gemm_a8w2_mma_kernel<64x64>"),
+    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(0, 0, 32, 0)), "gemm_a16w8_kernel<64x64>"),
     (dict(M=512, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2, N=8192, K=8192), "gemm_a8w4_mma_kernel<128x128>"),
     (dict(M=16, nbits=2, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "a8w2_rows_kernel<16x16>"),
     (dict(M=1, in_dt=3, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=1, c_mode=3, gs=4096), "gemv_a8w4_kernel<tile16,16w>"),  # channel-wise, post-scale
@@ -220,8 +223,8 @@ def test_struct_abi_and_validation():
     # 16-bit activations whose output / channel-scale type differs (BitNet A16W158 with its fp32 scale; fp32 output)
     (dict(M=1, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemv_w2_mfma_kernel<tile16>"),   # round 4: fp32 post-scale in the GEMV epilogue
     (dict(M=8, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_wn_direct_kernel<tile32,8w>"),  # ... and in the few-row kernels
-    (dict(M=64, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_w2_mma_kernel<64x128>"),
-    (dict(M=64, in_dt=1, out_dt=0), "gemm_w4_mma_kernel<32x128>"),
+    (dict(M=64, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_w2_mma_kernel<64x64>"),  # round 4, late: narrow 64 x 64 tiles where narrow_auto() fires
+    (dict(M=64, in_dt=1, out_dt=0), "gemm_w4_mma_kernel<64x64>"),  # round 4, late: narrow 64 x 64 tiles where narrow_auto() fires
 ])
 def test_kernel_selection(kw, kernel):
     lib = _hip.load()

@@ -171,7 +171,7 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(a) == "mx_gemv_w8_kernel"
     assert name(args(16, 8, 1, 4, K=4096 + 32)) == "mx_gemv_w8_kernel"   # K % 128 != 0
     assert name(args(14, 8, 1, 0)) == "a16w8_mxfp_rows_kernel<16x16>"    # round 4: 16-bit activations x MX weights, 1 .. 64 rows: the A16W8 rows kernel
-    assert name(args(15, 4, 40, 0)) == "gemm_a16w4_mxfp_kernel<64x128>"   # round 4: rows only while M N K <= 570 M (250 M for layers > 32 M weights)
+    assert name(args(15, 4, 40, 0)) == "gemm_a16w4_mxfp_kernel<64x64>"   # round 4: rows only while M N K <= 570 M (250 M for layers > 32 M weights)
     assert name(args(15, 4, 30, 0)) == "a16w4_mxfp_rows_kernel<32x16>"
     assert name(args(15, 4, 8, 0, N=8192, K=8192)) == "gemm_a16w4_mxfp_kernel<32x128>"
     assert name(args(15, 4, 3, 0, N=8192, K=8192)) == "a16w4_mxfp_rows_kernel<16x16>"
@@ -186,7 +186,7 @@ def test_c_abi_routes_block_scaled_formats():
     a = args(14, 8, 1, 0)
     a.tuning[0] = 5
     assert name(a) == "mx_gemv_w8_kernel"
-    assert name(args(15, 8, 100, 0)) == "gemm_a16w8_mxfp_kernel<64x128>"     # above 64 rows: the tile kernel (bf16 x, bf16 out)
+    assert name(args(15, 8, 100, 0)) == "gemm_a16w8_mxfp_kernel<64x64>"     # above 64 rows: the tile kernel (bf16 x, bf16 out)
     assert name(args(17, 4, 300, 4, K=11008)) == "gemm_mx_a4w4_sq_kernel<64x64>"  # fp4 activations, K % 512 != 0 but K % 256 == 0: the 64 x 64 tiles take it (round 4)
     assert name(args(17, 4, 600, 4, K=11008)) == "mx_rows_a4w4_kernel<64x16>"   # ... above their row range: no tile kernel -> 64-row tiles of the few-row kernel
     assert name(args(17, 4, 300, 4, K=4096)) == "gemm_mx_a4w4_sq_kernel<64x64>"
@@ -203,8 +203,17 @@ def test_c_abi_routes_block_scaled_formats():
     # NVFP4: no scaled-MFMA form takes e4m3 block-16 scales; both operands are exact in fp16, so the fp16 tile kernel runs it (round 4:
     # x expanded by a kernel in front, the weights in the K loop; workspace = tickets + slabs + M K fp16 + M floats)
     assert name(args(18, 4, 8, 4, group=16)) == "nvfp4_rows_kernel<16x16>"   # 1 .. 64 rows: both operands expanded in registers
-    assert name(args(18, 4, 40, 4, group=16)) == "gemm_nvfp4_f16_kernel<64x128>"
-    assert name(args(18, 4, 256, 4, group=16)) == "gemm_nvfp4_f16_kernel<64x128>"
+    assert name(args(18, 4, 40, 4, group=16)) == "gemm_nvfp4_f16_kernel<64x64>"
+    assert name(args(18, 4, 256, 4, group=16)) == "gemm_nvfp4_f16_kernel<64x64>"
+    a = args(18, 4, 256, 4, group=16)
+    a.tuning[2] = 32                                                      # round 4, late: the narrow 64 x 64 tiles (forced)
+    assert name(a) == "gemm_nvfp4_f16_kernel<64x64>"
+    a = args(15, 4, 100, 0)
+    a.tuning[2] = 32
+    assert name(a) == "gemm_a16w4_mxfp_kernel<64x64>"
+    a = args(15, 8, 100, 0)
+    a.tuning[1], a.tuning[2] = 2, 32
+    assert name(a) == "gemm_a16w8_mxfp_kernel<64x64>"
     a = args(18, 4, 8, 4, group=16)
     a.tuning[0] = 2                                                       # A/B switch: the tile kernel at any M
     assert name(a) == "gemm_nvfp4_f16_kernel<32x128>"

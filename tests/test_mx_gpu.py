@@ -214,10 +214,13 @@ def test_mfma_kernel_tiles_slices_and_coverage_agree(proc):
         tunings = [(0, 1, 1, 0), (0, 1, 2, 0), (0, 1, 4, 0), (0, 2, 1, 0), (0, 4, 2, 0), (0, 3, 4, 0), (0, 8, 1, 0), (1, 0, 0, 0)]
         if proc.startswith("A16") or "NVFP" in proc:
             tunings += [(0, 1, 8, 0), (0, 5, 8, 0)]  # 256-row tiles exist on the 16-bit-activation kernel only (NVFP4 runs on it: both operands expanded to fp16)
+        if proc.startswith("A16") or "NVFP" in proc:
+            tunings += [(0, 1, 32, 0), (0, 3, 32, 0)]  # round 4, late: the narrow 64 x 64 tiles (KH = 4) of the same template, unsplit and with K slices
         for tuning in tunings:
             C.TUNING_OVERRIDE = tuning
             name = _kernel_name(layer, x, tuning)
             assert name.startswith("mx_generic_kernel" if tuning[0] == 1 else EXPECT[proc]), (tuning, name)
+            assert ("<64x64>" in name) == (tuning[2] == 32), (tuning, name)
             y = layer(x)
             _check(f"{proc} tuning={tuning} {name}", y, ref, tdt)
             outs[tuning] = y.float().cpu()
