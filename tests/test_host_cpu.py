@@ -260,6 +260,40 @@ def test_planner_choices_on_llm_shapes():
     assert not moved, moved[:10]
 
 
+FEW_ROW_KERNELS = ("_rows_kernel", "gemv_", "gemm_wn_direct", "gemm_wn_stream", "_decode", "kmajor")
+
+
+@pytest.mark.parametrize("fam", ["a16w8", "a8w8", "a8w4", "bitnet_int8", "a16w4"])
+def test_few_row_to_tile_hand_over_is_monotone(fam):
+    """Round 4, late: every few-row kernel has an M N K budget against its tile kernel.  Walking M upwards on the four layer sizes
+    of the sweep, the plan must hand over ONCE — after a tile kernel was chosen no larger M may fall back to a few-row kernel — nothing
+    may reach the coverage kernel, and from 65 rows no few-row kernel may be left."""
+    lib = _hip.load()
+    kw = {"a16w8": dict(nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2),
+          "a8w8": dict(nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1),
+          "a8w4": dict(in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2),
+          "bitnet_int8": dict(nbits=2, in_dt=4, out_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=3),
+          "a16w4": dict()}[fam]
+    for N, K in ((4096, 4096), (8192, 8192), (4096, 14336), (14336, 4096)):
+        kk = dict(kw)
+        if fam in ("a16w8", "a8w8", "bitnet_int8"):
+            kk["gs"] = K
+        tiled_at = None
+        for M in list(range(1, 66)) + [96, 128, 256, 512]:
+            a = _args(M=M, N=N, K=K, **kk)
+            if kk.get("c_mode", 0) in (2, 3):
+                a.scales_x = 0x1000
+            assert lib.gemlite_hip_query(C.byref(a)) == 0
+            name = lib.gemlite_hip_kernel_name(C.byref(a)).decode()
+            assert "generic" not in name, (fam, N, K, M, name)
+            few = any(t in name for t in FEW_ROW_KERNELS)
+            if not few and tiled_at is None:
+                tiled_at = M
+            if tiled_at is not None:
+                assert not few, (fam, N, K, M, name, "tile kernel since M = %d" % tiled_at)
+        assert tiled_at is not None and tiled_at <= 65, (fam, N, K, tiled_at)
+
+
 def test_workspace_sizing_cfgA():
     lib = _hip.load()
     a = _args(M=1)

@@ -119,6 +119,47 @@ def test_block_scaled_layers_refuse_cpu_tensors():
         layer(torch.randn(2, 256, dtype=torch.bfloat16))
 
 
+@pytest.mark.parametrize("fam", ["mxfp8", "mxfp8_w4", "mxfp4", "a16_mxw8", "a16_mxw4", "nvfp4"])
+def test_block_scaled_few_row_to_tile_hand_over_is_monotone(fam):
+    """Round 4, late: walking M upwards on the four layer sizes of the sweep, every block-scaled family hands over ONCE from
+    its few-row kernel to a tile kernel, never reaches the coverage kernel, and has left the few-row kernels by 65 rows."""
+    import ctypes as C
+    from gemlite_amd import _hip
+    lib = _hip.load()
+    buf = (C.c_uint8 * 64)()
+    ptr = C.addressof(buf) // 16 * 16 + 16
+    in_dt, nbits, c_mode, group = {"mxfp8": (16, 8, 4, 32), "mxfp8_w4": (16, 4, 2, 32), "mxfp4": (17, 4, 4, 32), "a16_mxw8": (15, 8, 0, 32),
+                                   "a16_mxw4": (14, 4, 0, 32), "nvfp4": (18, 4, 4, 16)}[fam]
+    for N, K in ((4096, 4096), (8192, 8192), (4096, 14336), (14336, 4096)):
+        tiled_at = None
+        for M in list(range(1, 66)) + [96, 128, 256, 512]:
+            a = _hip.ForwardArgs()
+            a.struct_size = C.sizeof(_hip.ForwardArgs)
+            a.matmul_type = -1
+            a.x = a.w_q = a.scales = a.out = a.scales_x = ptr
+            a.M, a.N, a.K = M, N, K
+            a.W_nbits, a.group_size, a.unpack_mask = nbits, group, 2 ** nbits - 1
+            a.elements_per_sample = 1 if nbits == 8 else 2
+            a.w_pack_bits = 0 if nbits == 8 else 8
+            a.w_dtype = 3 if nbits == 8 else 5
+            a.input_dtype, a.output_dtype, a.meta_dtype = in_dt, (1 if in_dt in (14, 18) else 2), 5
+            a.channel_scale_mode, a.W_group_mode = c_mode, 0
+            a.stride_xm, a.stride_xk = (K // 2 if in_dt in (17, 18) else K), 1
+            a.stride_wk, a.stride_wn = 1, (K if nbits == 8 else K // 2)
+            a.stride_om, a.stride_on = N, 1
+            a.stride_meta_g, a.stride_meta_n = N, 1
+            a.stride_sx_m = K // group
+            assert lib.gemlite_hip_query(C.byref(a)) == 0, (fam, N, K, M)
+            name = lib.gemlite_hip_kernel_name(C.byref(a)).decode()
+            assert "generic" not in name, (fam, N, K, M, name)
+            few = "_rows_" in name or "gemv" in name
+            if not few and tiled_at is None:
+                tiled_at = M
+            if tiled_at is not None:
+                assert not few, (fam, N, K, M, name, "tile kernel since M = %d" % tiled_at)
+        assert tiled_at is not None and tiled_at <= 65, (fam, N, K, tiled_at)
+
+
 def test_c_abi_routes_block_scaled_formats():
     """gemlite_hip_kernel_name never launches: which kernel each format pair resolves to (K-contiguous layout of pack())."""
     import ctypes as C
