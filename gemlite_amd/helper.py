@@ -496,10 +496,13 @@ def warmup(processor=None, shapes=(), batch_sizes=None, group_size: int = 64, dt
 # tuning[] candidates per kernel family of libgemlite_hip (include/gemlite_hip.h: tuning[0..3]); (0,0,0,0) = planner
 _TUNING_CANDIDATES = {
     "gemv": [(0, 0, 0, 0), (2, 1, 4, 0), (2, 1, 8, 0), (2, 1, 16, 0), (3, 1, 0, 0), (3, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 4, 0, 0)],
+    # (round 4: 4 = the 16-column rows kernels of the 8-bit families, 2 = their tile kernels, 5 = unsplit 64 x 64 A8W8 tiles, 7 = the
+    #  streaming kernels of rounds 1-3; candidates a family does not know fall through to its planner or are refused, never mis-run)
     "few_rows": [(0, 0, 0, 0), (1, 1, 0, 0), (2, 1, 0, 0), (2, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 4, 0, 0), (0, 0, 1, 0),
-                 (3, 0, 0, 0), (3, 0, 1, 0), (3, 0, 2, 0)],
-    # 8-wave MFMA kernel: tuning[1] = K slices, tuning[2] = tile rows / 32
-    "tiled": [(0, 0, 0, 0)] + [(0, sk, mi, 0) for mi in (1, 2, 4, 8) for sk in (1, 2, 3, 4, 6, 8)],
+                 (3, 0, 0, 0), (3, 0, 1, 0), (3, 0, 2, 0), (4, 0, 0, 0), (2, 0, 0, 0), (5, 0, 0, 0), (7, 0, 0, 0)],
+    # 8-wave MFMA kernel: tuning[1] = K slices, tuning[2] = tile rows / 32 (32 / 34: the narrow 64-column tiles of round 4)
+    "tiled": [(0, 0, 0, 0)] + [(0, sk, mi, 0) for mi in (1, 2, 4, 8) for sk in (1, 2, 3, 4, 6, 8)] +
+             [(0, 1, 32, 0), (0, 2, 32, 0), (0, 1, 34, 0), (0, 2, 34, 0), (4, 0, 0, 0), (5, 0, 0, 0), (5, 0, 2, 0), (6, 0, 0, 0)],
 }
 
 
