@@ -503,6 +503,10 @@ _TUNING_CANDIDATES = {
     # 8-wave MFMA kernel: tuning[1] = K slices, tuning[2] = tile rows / 32 (32 / 34: the narrow 64-column tiles of round 4)
     "tiled": [(0, 0, 0, 0)] + [(0, sk, mi, 0) for mi in (1, 2, 4, 8) for sk in (1, 2, 3, 4, 6, 8)] +
              [(0, 1, 32, 0), (0, 2, 32, 0), (0, 1, 34, 0), (0, 2, 34, 0), (4, 0, 0, 0), (5, 0, 0, 0), (5, 0, 2, 0), (6, 0, 0, 0)],
+    # block-scaled layers, 2 <= M (include/gemlite_hip.h): [0] 2 = 8-wave tile kernels, 3 = 256 x 256 tiles, 4 = few-row kernel,
+    # 6 = unsplit 64 x 64 tiles ([2] = stages); [1] K slices, [2] tile rows / 32 or 32 = narrow tiles (16-bit activations, NVFP4)
+    "mx": [(0, 0, 0, 0), (2, 0, 0, 0), (3, 0, 0, 0), (4, 0, 0, 0), (6, 0, 0, 0), (6, 0, 2, 0), (6, 0, 4, 0), (0, 1, 32, 0), (0, 2, 32, 0)] +
+          [(0, sk, mi, 0) for mi in (1, 2, 4) for sk in (1, 2, 4)],
 }
 
 
@@ -519,22 +523,37 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
     from ._hip import GemliteHipError
     from .bench_utils import kernel_device_us
 
-    if _core.is_mx_dtype(layer.input_dtype.value):
-        # the block-scaled kernels have no tuning candidates yet (their planner takes tuning[1] / [2] only), and their entries live
-        # under the `mx` config families: say so instead of filing a result where lookup_tuning() never looks
-        raise NotImplementedError("autotune_layer: block-scaled (MXFP / NVFP4) layers are not tunable yet")
+    mx = bool(_core.is_mx_dtype(layer.input_dtype.value))
     dev = layer.W_q.device
-    in_t = _core.DTYPE_TO_TORCH[layer.input_dtype.value if not layer.scaled_activations else layer.output_dtype.value]
+    in_t = _core.DTYPE_TO_TORCH[layer.output_dtype.value if (mx or layer.scaled_activations) else layer.input_dtype.value]
     meta = layer.get_meta_args()
     out = {}
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev) if cold else None
     for M in batch_sizes:
         x = (torch.randn(M, layer.in_features, device=dev) / 10).to(in_t)
         scales_x = None
-        if layer.scaled_activations:
+        if mx:
+            # block-scaled layers (round 4): entries are filed under the `mx` families lookup_tuning() reads.  One row of a dynamic layer is
+            # quantised INSIDE the few-row kernel, which a table entry would switch off: not tuned
+            code, c_mode = layer.input_dtype.value, layer.channel_scale_mode
+            if bool(meta[0]):
+                if M == 1:
+                    continue
+                from . import quant_utils as _q
+                if code == _core.DType.MXFP8.value and c_mode == 4:
+                    x, scales_x = _q.scale_activations_mxfp8(x, w_dtype=torch.float8_e4m3fn)
+                elif code == _core.DType.MXFP8.value and c_mode == 2:
+                    x, scales_x = _q.scale_activations_per_token(x, w_dtype=torch.float8_e4m3fn)
+                elif code == _core.DType.MXFP4.value and c_mode == 4:
+                    x, scales_x = _q.scale_activations_mxfp4(x)
+                elif code == _core.DType.NVFP4.value and c_mode == 4:
+                    x, scales_x = _q.scale_activations_nvfp4(x)
+                else:
+                    raise NotImplementedError(f"autotune_layer: no activation quantiser for {layer.input_dtype} with channel_scale_mode {c_mode}")
+        elif layer.scaled_activations:
             from .quant_utils import scale_activations_per_token
             x, scales_x = scale_activations_per_token(x, w_dtype=_core.DTYPE_TO_TORCH[layer.input_dtype.value])
-        fam = "gemv" if M == 1 else ("few_rows" if M <= 32 else "tiled")
+        fam = "mx" if mx else ("gemv" if M == 1 else ("few_rows" if M <= 32 else "tiled"))
         best, default_us, timed = None, None, {}
         for cand in (candidates or _TUNING_CANDIDATES[fam]):
             try:  # device time of the kernel itself (per-launch HIP events), not host-bound wall time
@@ -556,7 +575,7 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
             continue
         a = _core._static_args(layer.W_q, layer.scales, layer.zeros, meta)
         key = _core.config_key(M, a.N, a.K, a.group_size, a.elements_per_sample, a.type_id)
-        family = _core.config_family(-1, M, layer.W_nbits)
+        family = _core.config_family(-1, M, layer.W_nbits, mx)
         entry = {"tuning": list(best[0]), "us": round(best[1], 3)}
         _core.GEMLITE_HIP_CONFIG_CACHE.setdefault(family, {})[key] = entry
         out[M] = dict(entry, default_us=None if default_us is None else round(default_us, 3), candidates=timed)

@@ -476,6 +476,31 @@ def test_prefill_tile_kernel_is_the_default_when_the_tiles_fill_the_chip():
     assert _kernel_name(layer, x[:1024]).startswith("gemm_mx_a4w4_kernel")  # 64 tiles: the 128-row kernel
 
 
+@pytest.mark.parametrize("proc", ["A4W4_MXFP_dynamic", "A8W8_MXFP_dynamic_post", "A16W4_MXFP", "A4W4_NVFP_dynamic"])
+def test_autotune_layer_on_block_scaled_layers(proc):
+    """helper.autotune_layer() on block-scaled layers (round 4, late): the candidates of include/gemlite_hip.h's block-scaled row are timed,
+    the winner is filed under the `mx` family lookup_tuning() reads, and the tuned layer still matches the oracle.  One row of a dynamic
+    layer is not tuned (it is quantised inside the few-row kernel)."""
+    tdt = torch.float16 if "NVFP" in proc else torch.bfloat16
+    N, K = 1024, 2048
+    lin = _linear(N, K, tdt, seed=41)
+    lin.bias = None
+    layer = PROCS[proc](tdt).from_linear(lin, del_orig=False)
+    C.GemLiteLinear.reset_config()
+    try:
+        res = H.autotune_layer(layer, batch_sizes=(1, 8, 200), iters=5)
+        assert set(res) == ({1, 8, 200} if proc.startswith("A16") else {8, 200}), res.keys()
+        assert all(len(v["tuning"]) == 4 and v["us"] > 0 and len(v["candidates"]) >= 3 for v in res.values())
+        g = torch.Generator().manual_seed(9)
+        for M in res:
+            x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
+            a = C._static_args(layer.W_q, layer.scales, layer.zeros, layer.get_meta_args())
+            assert C.lookup_tuning(-1, M, a) == tuple(res[M]["tuning"]), (M, res[M])
+            _check(f"{proc} autotuned M={M} {res[M]['tuning']}", layer(x), _oracle(layer, x), tdt)
+    finally:
+        C.GemLiteLinear.reset_config()
+
+
 def test_mx_layer_state_dict_round_trip_and_functional_op():
     tdt = torch.bfloat16
     lin = _linear(256, 512, tdt, seed=9)
