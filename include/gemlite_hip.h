@@ -191,8 +191,8 @@ typedef struct gemlite_hip_forward_args {
      *                              & 16384 = never the narrow tiles (the round-3 choice, A/B runs)
      *   unpacked 8-bit (A8W8)      [0] 1 = streaming (one wave per column), 2 = the 4-wave MFMA kernel of round 1 (the planner's
      *                              fallback for K % 256 != 0), 4 = the 16-column few-row kernel (default for 2..64 rows while
-     *                              M K N / 16 <= 88 MiB) at any M <= 64 and at M = 1, 5 = the unsplit 64 x 64 tiles of round 4
-     *                              (default from 65 rows where they fill the chip once or twice; [2] = 2/3/4 LDS stages),
+     *                              M K N / 16 <= 88 MiB and, from 128 column tiles of 64, M N K <= 800 M) at any M <= 64 and at M = 1, 5 = the unsplit 64 x 64 tiles of round 4
+     *                              (default from 65 rows where they fill the chip once or twice, and from 2 rows past the few-row budget; [2] = 2/3/4 LDS stages),
      *                              6 = the round-3 kernels instead; M = 1: 7 = the round-2 streaming kernels instead of
      *                              a8w8_decode_kernel, 8 = a8w8_decode_kernel also for fp8 with N > 4096
      *                              [1] K slices   [2] tile rows / 32 (forces the 8-wave kernels at any M)
