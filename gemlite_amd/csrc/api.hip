@@ -289,6 +289,14 @@ static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, cons
             return;
         }
     }
+    // past their budgets but no tile kernel took the shape (an alignment the tile kernels need ...): the few-row kernels after all,
+    // before the coverage kernel
+    if (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0) {
+        gemlite_hip_forward_args f = a;
+        f.tuning[0] = 4;
+        if (a16_over && plan_a16w8_rows(f, r.lp)) { r.kind = K_KMAJOR; return; }
+        if (a.input_dtype == GEMLITE_DT_NVFP4 && plan_nvfp4_rows(f, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }
+    }
     if (a.M > 65535) { r.status = GEMLITE_ERR_BAD_SHAPE; return; }
     r.kind = K_GENERIC;
     r.lp.fn = mx_generic_kernel_fn();
@@ -401,7 +409,8 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
             r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
         }
         // decode sizes of 8-bit activations x packed weights (A8Wn fp8 dynamic, BitNet int8): per-weight cast to the activation type
-        if (x8 && a.M <= 4 && (want_gemv || mt == GEMLITE_MATMUL_AUTO) && (a.tuning[0] == 0 || a.tuning[0] == 7) && a.tuning[1] == 0 && a.tuning[2] == 0 &&
+        // (one row by default; 2 .. 4 rows only as the A/B switch tuning[0] = 7: past the rows kernel's budget the tile kernel is the faster one)
+        if (x8 && a.M <= (a.tuning[0] == 7 ? 4 : 1) && (want_gemv || mt == GEMLITE_MATMUL_AUTO) && (a.tuning[0] == 0 || a.tuning[0] == 7) && a.tuning[1] == 0 && a.tuning[2] == 0 &&
             plan_gemv_a8wn(a, p, lp)) {
             r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
         }

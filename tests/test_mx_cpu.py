@@ -223,6 +223,12 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(args(16, 8, 16, 4, N=8192, K=8192)) == "mx_rows_a8w8_kernel<16x16>"   # fp8 activations: M N K <= 1.1 G from 128 column tiles
     assert name(args(16, 8, 17, 4, N=8192, K=8192)) == "gemm_mx_a8w8_sq_kernel<64x64>"
     assert name(args(18, 4, 30, 4, group=16)) == "nvfp4_rows_kernel<32x16>"     # NVFP4: rows while M N K <= 600 M
+    a = args(18, 4, 48, 4, group=16)
+    a.out = ptr + 2                                                        # an output the tile kernels cannot store to (2-byte aligned): past the
+    assert name(a) == "nvfp4_rows_kernel<64x16>"                           # budget the few-row kernel still takes it — not the coverage kernel
+    a = args(14, 4, 48, 0)
+    a.output_dtype, a.out = 1, ptr + 2
+    assert name(a) == "a16w4_mxfp_rows_kernel<64x16>"
     assert name(args(14, 8, 1, 0, K=4096 + 32)) == "mx_gemv_w8_kernel"   # K % 64 != 0: the streaming kernel
     a = args(14, 8, 1, 0)
     a.tuning[0] = 5
