@@ -1,0 +1,49 @@
+"""Regenerate the "Round-N summary" section of profiles/README.md from an official bench line + the rocprofv3 kernel stats of the same
+command.   python scripts/make_profiles_summary.py profiles/r04/official [--boxes "1975 / 1957 ... GB/s (4.52 / ... µs)"]"""
+import csv, json, os, re, sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+off = sys.argv[1]
+boxes = sys.argv[sys.argv.index("--boxes") + 1] if "--boxes" in sys.argv else None
+d = json.load(open(os.path.join(root, off, "bench_default.json")))
+r = d["roofline"]
+avg = calls = mn = None
+for row in csv.DictReader(open(os.path.join(root, off, "rocprof_bench_kernel_stats.csv"))):
+    if "gemv_w4_decode3_kernel<gl::half_tag, true>" in row["Name"]:
+        avg, calls, mn = float(row["AverageNs"]) / 1000, int(row["Calls"]), float(row["MinNs"]) / 1000
+cb = d["cpu_baseline"]
+head = (f"**value {d['value']:.0f} GB/s** (4096² M = 1 fp16, 64 cold layers = 572 MB per step, {d['ms_per_step'] * 1000:.1f} µs per step); `roofline`: "
+        f"`{r['kernel']}` **{r['kernel_us']:.3f} µs** per launch (the timed region itself) = **{r['frac']:.4f}** of 8 TB/s; an empty kernel in the same graph "
+        f"{r['empty_launch_us']:.2f} µs → the kernel's own part {r['kernel_us_minus_empty_launch']:.2f} µs; `rotation_ab`: 32 layers "
+        f"{d['rotation_ab']['layers32_286MB_us']:.2f} µs vs 64 layers {d['rotation_ab']['layers64_572MB_us']:.2f} µs; sustained 6 s: "
+        f"{d['sustained']['us_per_launch']:.2f} µs; eager host cost {d['eager']['host_us_per_call']:.2f} µs per `layer(x)`; CPU baseline (port, {cb['cores']} threads) "
+        f"{cb['value']:.3f} GB/s.  rocprofv3 (`rocprof_bench_kernel_stats.csv`): `gemv_w4_decode3_kernel<half,true>` avg {avg:.2f} µs over {calls} calls "
+        f"(min {mn:.2f}; the average includes the eager passes and the 32-layer rotation block)." + (f"  The same command on the other boxes of the session: {boxes}." if boxes else ""))
+rows = []
+
+
+def add(block, key, b):
+    tr, mu = b.get("traffic"), b.get("mfma_util")
+    rows.append(f"| `{block}`{(' / ' + key) if key else ''} | `{b['kernel']}` | {b['kernel_us']:.2f} | {b['achieved']:.0f} {b.get('unit', 'GB/s')} | {b['frac']:.3f} | "
+                f"{('%.1f MB' % (tr / 1e6)) if tr else '—'} | "
+                f"{('%.2f @ %.2f GHz, %.1f VALU/MFMA' % (mu['mfma_busy'], mu['effective_clock_ghz'], mu['valu_per_mfma'])) if mu else '—'} |")
+
+
+add("roofline", "", r)
+for blk in ("roofline_m256", "roofline_cfg4", "roofline_cfg5", "roofline_mx_fewrows", "roofline_mx_m256"):
+    for k, b in d.get(blk, {}).items():
+        add(blk, k, b)
+for blk in ("roofline_m1_bf16", "roofline_prefill_m2048"):
+    if blk in d:
+        add(blk, "", d[blk])
+for k, b in d.get("roofline_trend_m1", {}).items():
+    add("roofline_trend_m1", k, b)
+table = ("| block | kernel | µs per launch | algorithmic rate | fraction of peak | HBM traffic (PMC) | MFMA busy @ clock |\n|---|---|---|---|---|---|---|\n" + "\n".join(rows))
+p = os.path.join(root, "profiles", "README.md")
+s = open(p).read()
+title = re.search(r"### Round-\d+ summary \(`[^`]*`\)", s).group(0)
+i = s.index(title)
+m = re.search(r"\n##+ ", s[i + 10:])
+end = i + 10 + m.start() if m else len(s)
+open(p, "w").write(s[:i] + title + "\n\n" + head + "\n\n" + table + "\n" + s[end:])
+print(head[:200])
