@@ -10,23 +10,26 @@ The step is captured once as a hipGraph (the launch-bound regime the reference i
 graphs, config.py:17) and replayed; `value` is whole-job algorithmic GB/s over all ranks.
 
 The JSON line carries BOTH halves of BASELINE.json's metric ("... at M=1 and M=256") and all five BASELINE configs, measured in this
-process.  Every block uses ONE clock: wall time of a replayed hipGraph that holds >= 32 back-to-back launches of the workload over
+process.  Round 5: EVERY block below lives INSIDE the `roofline` object in compact form ({kernel, kernel_us, achieved, unit, frac,
+traffic, mfma_util}) — the driver's parsed record keeps `roofline` whole and only the NAMES of other top-level keys, so the M = 256
+half of the metric (`roofline.m256`) is now driver-retained evidence.  `--full-out PATH` writes the verbose blocks to a file.  Every block uses ONE clock: wall time of a replayed hipGraph that holds >= 32 back-to-back launches of the workload over
 rotating (cache-cold) layers, divided by the launches — the same quantity as the timed region of `value`, and the one that
 reproduces from `rocprofv3 --kernel-trace --stats` of this command (profiles/r03/official/: the kernel's average duration agrees
 within a few percent; the graph's dependent-launch boundary, ~1.5 us, is inside it).  Per-launch HIP events are reported as a
 secondary figure only (`event_us`; an EMPTY kernel reads ~4 us through them: `event_clock_floor_us`).
   roofline        — M=1 (the `value` workload): algorithmic bytes per launch / time per launch of the TIMED REGION.
-  roofline_m256   — cfgA (4096^2) and cfgB (8192^2, BASELINE configs[2]) at M=256 in bf16: TFLOP/s against the dense bf16 MFMA peak;
+  roofline.m256   — cfgA (4096^2) and cfgB (8192^2, BASELINE configs[2]) at M=256 in bf16: TFLOP/s against the dense bf16 MFMA peak;
                     `mfma_util` = matrix-pipe busy share from the committed SQ counter passes (profiles/mfma_util.json), or null.
-  roofline_cfg4   — BASELINE configs[3]: A8W8 int8 4096^2 at M = 1 / 16 / 256: the matmul alone (x pre-quantised outside the timed
+  roofline.cfg4   — BASELINE configs[3]: A8W8 int8 4096^2 at M = 1 / 16 / 256: the matmul alone (x pre-quantised outside the timed
                     region) AND `*_layer_e2e`: layer(x) with the dynamic activation quantisation inside the timed region (round 4).
-  roofline_cfg5   — BASELINE configs[4]: A16W2 g128 and FP8 x FP8 16384^2 at M = 1 / 256 (+ `*_layer_e2e` for FP8).
-  roofline_m1_bf16, rotation_ab — the bf16 twin of the headline; the headline step over 32 (286 MB) vs 64 (572 MB) distinct layers.
-  roofline_mx_fewrows, roofline_mx_m256 — block-scaled formats (MXFP8 / MXFP4 / NVFP4) at 4096^2: M = 16 (few-row kernels) and M = 256
+  roofline.cfg5   — BASELINE configs[4]: A16W2 g128 and FP8 x FP8 16384^2 at M = 1 / 256 (+ `*_layer_e2e` for FP8).
+  roofline.m1_bf16, roofline.rotation_ab — the bf16 twin of the headline; the headline step over 32 (286 MB) vs 64 (572 MB) distinct layers.
+  roofline.mx_fewrows, roofline.mx_m256 — block-scaled formats (MXFP8 / MXFP4 / NVFP4) at 4096^2: M = 16 (few-row kernels) and M = 256
                     (unsplit 64 x 64 scaled-MFMA tiles, round 4), matmul alone and `*_layer_e2e` with the activation quantiser inside.
-  roofline_prefill_m2048 — 8192^2 at M=2048 (bf16), the large-M end of the MFMA kernel family.
-  roofline_trend_m1 — the same GEMV family at 8192^2 and 16384^2 (fraction of HBM peak grows with size).
-  sustained       — >= 6 s of back-to-back replays of the headline step (an outside sampler sees the GPU busy).
+  roofline.prefill_m2048 — 8192^2 at M=2048 (bf16), the large-M end of the MFMA kernel family.
+  roofline.trend_m1 — the same GEMV family at 8192^2 and 16384^2 (fraction of HBM peak grows with size).
+  roofline.fewrows — A16W4 4096^2 at M = 16 / 32 / 64 in fp16 (decode-batch sizes; round 5: the 16-column MFMA rows kernel).
+  roofline.sustained — >= 6 s of back-to-back replays of the headline step (an outside sampler sees the GPU busy).
   cpu_baseline    — oracle/torch_cpu_path.py (a port of the reference's test oracle: unpack -> dequant -> matmul in
                     torch CPU ops; thread count swept, best reported, plus the matmul-only variant), rank 0, N=1 only.
 
@@ -58,6 +61,8 @@ WORKLOADS = {
     "a16w4_4096_m1_bf16": (4096, 4096, 4, 128, 1, "bf16", 64, "hbm"),
     "a16w4_4096_m8": (4096, 4096, 4, 128, 8, "fp16", 32, "hbm"),
     "a16w4_4096_m16": (4096, 4096, 4, 128, 16, "fp16", 32, "hbm"),
+    "a16w4_4096_m32": (4096, 4096, 4, 128, 32, "fp16", 32, "hbm"),
+    "a16w4_4096_m64": (4096, 4096, 4, 128, 64, "fp16", 32, "hbm"),
     "a16w4_4096_m256": (4096, 4096, 4, 128, 256, "bf16", 64, "mfma"),
     "a16w4_4096_m256_fp16": (4096, 4096, 4, 128, 256, "fp16", 32, "mfma"),
     "a16w4_8192_m256": (8192, 8192, 4, 128, 256, "bf16", 16, "mfma"),
@@ -428,6 +433,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="profiler runs: short blocks (0.03 s each), sustained leg 0.2 s")
     ap.add_argument("--kernel-samples", type=int, default=256, help="launches timed individually for roofline")
+    ap.add_argument("--full-out", default="", help="also write the verbose per-block records (clock strings, event timings, byte counts) to this file")
     ap.add_argument("--tuning", default="", help="development: comma-separated tuning[] override, e.g. 4,8")
     ap.add_argument("--matmul-type", default="", help="development: force a kernel family (forward_manual)")
     args = ap.parse_args()
@@ -486,7 +492,7 @@ def main():
         roof["mfma_util"] = _committed("mfma_util.json", name)
     roof["traffic"] = _traffic(name)
 
-    metric = ("HBM GB/s (algorithmic bytes) vs roofline at M=1 [value], TFLOP/s vs bf16 MFMA roofline at M=256 [roofline_m256]; "
+    metric = ("HBM GB/s (algorithmic bytes) vs roofline at M=1 [value], TFLOP/s vs bf16 MFMA roofline at M=256 [roofline.m256]; "
               "A16W4 gs=128 4096x4096" if name == "a16w4_4096_m1" else f"{unit} {name}")
     line = {
         "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -501,56 +507,78 @@ def main():
     }
 
     extras = name == "a16w4_4096_m1" and not args.single and not args.tuning and not args.matmul_type
+    full = {}  # verbose blocks (--full-out); the printed line carries their compact form inside `roofline`
     if extras:
-        try:
-            h_us, e_us = main_run.eager_us_per_call()
-            line["eager"] = {"host_us_per_call": round(h_us, 3), "us_per_call_incl_device": round(e_us, 3), "calls": 2000,
-                             "what": "layer(x) eager, no graph: Python + ctypes + gemlite_hip_forward per call"}
-            # >= 6 s of back-to-back replays of the headline step
-            us, nl, el = main_run.chained_us_per_launch(min_seconds=0.2 if args.quick else 6.0, min_steps=50)
-            line["sustained"] = {"seconds": round(el, 3), "launches": nl, "value": round(main_run.bytes / 1e9 / (us * 1e-6), 3),
-                                 "unit": "GB/s", "us_per_launch": round(us, 3)}
+        def compact(b):
+            c = {k: b[k] for k in ("kernel", "kernel_us", "achieved", "unit", "frac") if k in b}
+            c["traffic"] = b.get("traffic")
+            if b.get("bound") == "mfma":
+                c["mfma_util"] = b.get("mfma_util")
+            return c
 
-            def block(wname, nl=None, samples=0, e2e=False):
-                r = Runner(wname, device, lib, layers=nl, use_graph=not args.no_graph, e2e=e2e)
-                out = r.roofline(0 if args.quick else samples, min_seconds=0.03 if args.quick else 0.25)
-                if e2e:
-                    out["what"] = ("layer(x) on fp16 x, dynamic per-token quantisation included: " +
-                                   ("ONE fused launch" if r.M == 1 else "quantiser launch + matmul launch; kernel_us is the time of the pair"))
-                out["traffic"] = _traffic(wname)
-                if out["bound"] == "mfma":
-                    out["mfma_util"] = _committed("mfma_util.json", wname)
-                del r
-                torch.cuda.empty_cache()
-                return out
-            # the M=256 half of the headline metric, same process, bf16
-            line["roofline_m256"] = {"cfgA_4096": block("a16w4_4096_m256", samples=64), "cfgB_8192": block("a16w4_8192_m256", samples=32)}
-            # SURVEY §8(d) config 2 is "fp16 + bf16": the bf16 twin of the headline
-            line["roofline_m1_bf16"] = block("a16w4_4096_m1_bf16")
+        def block(wname, nl=None, samples=0, e2e=False):
+            r = Runner(wname, device, lib, layers=nl, use_graph=not args.no_graph, e2e=e2e)
+            out = r.roofline(0 if args.quick else samples, min_seconds=0.03 if args.quick else 0.25)
+            if e2e:
+                out["what"] = ("layer(x) on fp16 x, dynamic per-token quantisation included: " +
+                               ("ONE fused launch" if r.M == 1 else "quantiser launch + matmul launch; kernel_us is the time of the pair"))
+            out["traffic"] = _traffic(wname)
+            if out["bound"] == "mfma":
+                out["mfma_util"] = _committed("mfma_util.json", wname)
+            del r
+            torch.cuda.empty_cache()
+            return out
+
+        def group(key, blocks):
+            """blocks: {label: verbose block}.  The compact form goes INSIDE `roofline` (the key the driver keeps whole)."""
+            full[key] = blocks
+            roof[key] = {k: compact(v) for k, v in blocks.items()}
+
+        # every group is independent: one failing block must not take the M = 256 half of the metric with it
+        def guarded(key, fn):
+            try:
+                group(key, fn())
+            except Exception as e:
+                roof[key] = {"error": f"{type(e).__name__}: {e}"[:160]}
+                print(f"[bench] block {key} failed: {type(e).__name__}: {e}", file=sys.stderr)
+
+        # the M=256 half of the headline metric, same process, bf16 — FIRST, right behind the headline
+        guarded("m256", lambda: {"cfgA_4096": block("a16w4_4096_m256", samples=64), "cfgB_8192": block("a16w4_8192_m256", samples=32)})
+        # SURVEY §8(d) config 2 is "fp16 + bf16": the bf16 twin of the headline
+        guarded("m1_bf16", lambda: {"a16w4_4096_m1_bf16": block("a16w4_4096_m1_bf16")})
+        # decode-batch sizes of the headline layer (row a9: 2 <= M <= 64), layer(x) in fp16
+        guarded("fewrows", lambda: {f"a16w4_4096_m{m}": block(f"a16w4_4096_m{m}") for m in (16, 32, 64)})
+        # BASELINE configs[3]: A8W8 int8 channel-wise 4096^2, M in {1, 16, 256}: the matmul alone on a pre-quantised x, and
+        # (`*_layer_e2e`) layer(x) as the product runs it, dynamic activation quantisation included
+        guarded("cfg4", lambda: {**{f"a8w8_int8_4096_m{m}": block(f"a8w8_4096_m{m}") for m in (1, 16, 256)},
+                                 **{f"a8w8_int8_4096_m{m}_layer_e2e": block(f"a8w8_4096_m{m}", e2e=True) for m in (1, 16, 256)}})
+        # BASELINE configs[4]: A16W2 g128 and FP8 x FP8, 16384^2, M in {1, 256}
+        guarded("cfg5", lambda: {"a16w2_16384_m1": block("a16w2_16384_m1"), "a16w2_16384_m256": block("a16w2_16384_m256"),
+                                 "fp8_16384_m1": block("fp8_16384_m1"), "fp8_16384_m256": block("fp8_16384_m256"),
+                                 "fp8_16384_m1_layer_e2e": block("fp8_16384_m1", e2e=True),
+                                 "fp8_16384_m256_layer_e2e": block("fp8_16384_m256", e2e=True)})
+        # the large-M end of the same kernel family (north star: "tiled GEMM for large-M prefill") and the GEMV family on larger layers
+        guarded("prefill_m2048", lambda: {"a16w4_8192_m2048": block("a16w4_8192_m2048", 4)})
+        guarded("trend_m1", lambda: {"8192": block("a16w4_8192_m1"), "16384": block("a16w4_16384_m1")})
+        # block-scaled formats at decode-batch sizes (few-row scaled-MFMA kernel; NVFP4 on the fp16 tile kernel) and at M = 256 (unsplit
+        # 64 x 64 scaled-MFMA tiles): matmul on pre-quantised x and layer(x) with the activation quantiser
+        guarded("mx_fewrows", lambda: {**{w: block(w) for w in ("mx_a8w8_4096_m16", "mx_a4w4_4096_m16", "nvfp4_4096_m16", "nvfp4_4096_m256")},
+                                       **{w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a4w4_4096_m16", "nvfp4_4096_m16")}})
+        guarded("mx_m256", lambda: {**{w: block(w) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")},
+                                    **{w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")}})
+        try:
             # the rotation size does not carry the headline: the same step over 32 layers (286 MB, rounds 1-3) and 64 (572 MB)
             r32 = block("a16w4_4096_m1", 32)
-            line["rotation_ab"] = {"layers32_286MB_us": r32["kernel_us"], "layers64_572MB_us": roof["kernel_us"]}
-            # BASELINE configs[3]: A8W8 int8 channel-wise 4096^2, M in {1, 16, 256}: the matmul alone on a pre-quantised x, and
-            # (`*_layer_e2e`, round 4) layer(x) as the product runs it, dynamic activation quantisation included
-            line["roofline_cfg4"] = {f"a8w8_int8_4096_m{m}": block(f"a8w8_4096_m{m}") for m in (1, 16, 256)}
-            line["roofline_cfg4"].update({f"a8w8_int8_4096_m{m}_layer_e2e": block(f"a8w8_4096_m{m}", e2e=True) for m in (1, 16, 256)})
-            # BASELINE configs[4]: A16W2 g128 and FP8 x FP8, 16384^2, M in {1, 256}
-            line["roofline_cfg5"] = {"a16w2_16384_m1": block("a16w2_16384_m1"), "a16w2_16384_m256": block("a16w2_16384_m256"),
-                                     "fp8_16384_m1": block("fp8_16384_m1"), "fp8_16384_m256": block("fp8_16384_m256"),
-                                     "fp8_16384_m1_layer_e2e": block("fp8_16384_m1", e2e=True),
-                                     "fp8_16384_m256_layer_e2e": block("fp8_16384_m256", e2e=True)}
-            # the large-M end of the same kernel family (north star: "tiled GEMM for large-M prefill"), same clock
-            # round 4: block-scaled formats at decode-batch sizes (few-row scaled-MFMA kernel; NVFP4 on the fp16 tile kernel), matmul on
-            # pre-quantised x and layer(x) with the activation quantiser
-            line["roofline_mx_fewrows"] = {w: block(w) for w in ("mx_a8w8_4096_m16", "mx_a4w4_4096_m16", "nvfp4_4096_m16", "nvfp4_4096_m256")}
-            line["roofline_mx_fewrows"].update({w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a4w4_4096_m16", "nvfp4_4096_m16")})
-            # round 4: the unsplit 64 x 64 block-scaled tiles (gemm_mx_sq_kernel) at M = 256, matmul alone and the layer with its quantiser
-            line["roofline_mx_m256"] = {w: block(w) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")}
-            line["roofline_mx_m256"].update({w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")})
-            line["roofline_prefill_m2048"] = block("a16w4_8192_m2048", 4)
-            line["roofline_trend_m1"] = {"8192": block("a16w4_8192_m1"), "16384": block("a16w4_16384_m1")}
+            roof["rotation_ab"] = {"layers32_286MB_us": r32["kernel_us"], "layers64_572MB_us": roof["kernel_us"]}
+            h_us, e_us = main_run.eager_us_per_call()
+            roof["eager"] = {"host_us_per_call": round(h_us, 3), "us_per_call_incl_device": round(e_us, 3)}
+            full["eager"] = dict(roof["eager"], calls=2000, what="layer(x) eager, no graph: Python + ctypes + gemlite_hip_forward per call")
+            # >= 6 s of back-to-back replays of the headline step
+            us, nl, el = main_run.chained_us_per_launch(min_seconds=0.2 if args.quick else 6.0, min_steps=50)
+            roof["sustained"] = {"seconds": round(el, 3), "value": round(main_run.bytes / 1e9 / (us * 1e-6), 3), "us_per_launch": round(us, 3)}
+            full["sustained"] = dict(roof["sustained"], launches=nl, unit="GB/s")
         except Exception as e:
-            print(f"[bench] extra blocks failed: {type(e).__name__}: {e}", file=sys.stderr)
+            print(f"[bench] eager / sustained legs failed: {type(e).__name__}: {e}", file=sys.stderr)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.torch_cpu_path import time_cpu_baseline
@@ -560,12 +588,15 @@ def main():
         mm = r["matmul_only_sec"]
         line["cpu_baseline"] = {
             "value": round(cpu_val, 5), "unit": unit, "cores": r["threads"], "kind": "port",
-            "sample": f"{r['calls']} calls of unpack+dequant+matmul (torch CPU, fp32) on one {N}x{K} layer, M={M}, "
-                      f"{sec * 1e3:.2f} ms/call with the best of the swept thread counts (host has {r['host_cpus']} CPUs)",
+            "sample": f"{r['calls']} calls unpack+dequant+matmul torch-CPU fp32, one {N}x{K} layer M={M}, {sec * 1e3:.1f} ms/call",
+            "host_cpus": r["host_cpus"],
             "thread_sweep_ms": {str(k): round(v * 1e3, 2) for k, v in r["sweep"].items()},
             "matmul_only": {"ms_per_call": round(mm * 1e3, 3), "threads": r["matmul_only_threads"],
                             "note": "x @ W.T on the pre-dequantised fp32 W (64 MiB read per call)"}}
     if rank == 0:
+        if args.full_out:
+            with open(args.full_out, "w") as f:
+                json.dump({"line": line, "blocks": full}, f, indent=1)
         print(json.dumps(line), flush=True)
     rgroup.close()
 

@@ -15,8 +15,8 @@ cb = d["cpu_baseline"]
 head = (f"**value {d['value']:.0f} GB/s** (4096² M = 1 fp16, 64 cold layers = 572 MB per step, {d['ms_per_step'] * 1000:.1f} µs per step); `roofline`: "
         f"`{r['kernel']}` **{r['kernel_us']:.3f} µs** per launch (the timed region itself) = **{r['frac']:.4f}** of 8 TB/s; an empty kernel in the same graph "
         f"{r['empty_launch_us']:.2f} µs → the kernel's own part {r['kernel_us_minus_empty_launch']:.2f} µs; `rotation_ab`: 32 layers "
-        f"{d['rotation_ab']['layers32_286MB_us']:.2f} µs vs 64 layers {d['rotation_ab']['layers64_572MB_us']:.2f} µs; sustained 6 s: "
-        f"{d['sustained']['us_per_launch']:.2f} µs; eager host cost {d['eager']['host_us_per_call']:.2f} µs per `layer(x)`; CPU baseline (port, {cb['cores']} threads) "
+        f"{(r.get('rotation_ab') or d.get('rotation_ab'))['layers32_286MB_us']:.2f} µs vs 64 layers {(r.get('rotation_ab') or d.get('rotation_ab'))['layers64_572MB_us']:.2f} µs; sustained 6 s: "
+        f"{(r.get('sustained') or d.get('sustained'))['us_per_launch']:.2f} µs; eager host cost {(r.get('eager') or d.get('eager'))['host_us_per_call']:.2f} µs per `layer(x)`; CPU baseline (port, {cb['cores']} threads) "
         f"{cb['value']:.3f} GB/s.  rocprofv3 (`rocprof_bench_kernel_stats.csv`): `gemv_w4_decode3_kernel<half,true>` avg {avg:.2f} µs over {calls} calls "
         f"(min {mn:.2f}; the average includes the eager passes and the 32-layer rotation block)." + (f"  The same command on the other boxes of the session: {boxes}." if boxes else ""))
 rows = []
@@ -30,14 +30,14 @@ def add(block, key, b):
 
 
 add("roofline", "", r)
-for blk in ("roofline_m256", "roofline_cfg4", "roofline_cfg5", "roofline_mx_fewrows", "roofline_mx_m256"):
-    for k, b in d.get(blk, {}).items():
-        add(blk, k, b)
-for blk in ("roofline_m1_bf16", "roofline_prefill_m2048"):
-    if blk in d:
-        add(blk, "", d[blk])
-for k, b in d.get("roofline_trend_m1", {}).items():
-    add("roofline_trend_m1", k, b)
+# round 5: the blocks live INSIDE `roofline` ({group: {label: compact block}}); rounds 1-4 had them as top-level `roofline_<group>` keys
+for grp in ("m256", "m1_bf16", "fewrows", "cfg4", "cfg5", "prefill_m2048", "trend_m1", "mx_fewrows", "mx_m256"):
+    blocks = r.get(grp) if isinstance(r.get(grp), dict) else d.get("roofline_" + grp, {})
+    if isinstance(blocks, dict) and "kernel" in blocks:  # (old layout: a single block)
+        blocks = {"": blocks}
+    for k, b in (blocks or {}).items():
+        if isinstance(b, dict) and "kernel" in b:
+            add("roofline." + grp, k, b)
 table = ("| block | kernel | µs per launch | algorithmic rate | fraction of peak | HBM traffic (PMC) | MFMA busy @ clock |\n|---|---|---|---|---|---|---|\n" + "\n".join(rows))
 p = os.path.join(root, "profiles", "README.md")
 s = open(p).read()
