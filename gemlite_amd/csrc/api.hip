@@ -22,6 +22,7 @@ bool plan_gemv_a8wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& 
 bool plan_a8wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_stream(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_direct(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
+bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq = false);
@@ -317,6 +318,11 @@ static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
     return tiles <= 256 || (tiles <= 512 && a.K <= 4096);
 }
 
+// gemm_wn_rows.hip defaults (round 5; refined by profiles/r05/probe_rows5*.log): from how many rows, and up to how many bytes of x
+// re-read per launch, the 16-column rows kernel is the default for A16W4
+static int rows5_min_m() { return 5; }
+static int64_t rows5_budget_bytes() { return 144ll << 20; }
+
 static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
     r.status = validate(&a);
     if (r.status != GEMLITE_OK) return;
@@ -413,6 +419,23 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         if (x8 && a.M <= (a.tuning[0] == 7 ? 4 : 1) && (want_gemv || mt == GEMLITE_MATMUL_AUTO) && (a.tuning[0] == 0 || a.tuning[0] == 7) && a.tuning[1] == 0 && a.tuning[2] == 0 &&
             plan_gemv_a8wn(a, p, lp)) {
             r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
+        }
+        // round 5: 2 .. 64 rows of 16-bit activations x 4-bit words on the decode-shaped MFMA rows kernel (gemm_wn_rows.hip): 16-column
+        // blocks, K unsplit, weights requested first, x fragments straight from L2.  Every block re-reads all of x (M K 2 bytes through the
+        // CU's 64 B/clk address path), so the default stops at a budget on that traffic; groups of 32 and N % 64 != 0 — which no other
+        // specialised kernel takes at M >= 2 — always come here (any M: 64-row blocks along grid.y).  tuning[0] = 9 forces the kernel,
+        // tuning[3] & 65536 keeps the round-4 choice (A/B runs).
+        if (x16 && a.W_nbits == 4 && (mt == GEMLITE_MATMUL_AUTO || mt == GEMLITE_MATMUL_GEMM_SPLITK || (mt == GEMLITE_MATMUL_GEMM && a.tuning[0] == 9)) &&
+            !(a.tuning[3] & 65536) && (a.tuning[0] == 9 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && a.M >= 2))) {
+            const bool only_here = p.gs_shift == 5 || a.N % 64 != 0;  // nothing but the coverage kernel behind this one
+            const int64_t mpad = (a.M + 15) / 16 * 16;
+            const int64_t x_reread = (a.N / 16) * mpad * a.K * 2;      // bytes of x through the address paths of the launch
+            const bool in_budget = a.M >= rows5_min_m() && a.M <= 64 && x_reread <= rows5_budget_bytes();
+            if (a.tuning[0] == 9 || only_here || in_budget) {
+                WnParams pr = p;
+                LaunchPlan lr{};
+                if (plan_gemm_wn_rows(a, pr, lr)) { r.kind = K_STREAM_WN; r.wn = pr; r.lp = lr; return; }
+            }
         }
         // Decode on the matrix core (gemv_mfma.hip, round 3) where it measured faster than the dot-product family
         // (profiles/r03/probe_gemv3_*.log, us per launch in a replayed graph):
@@ -794,6 +817,12 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
             void* dargs[] = {(void*)&d.w, (void*)&d.x, (void*)&d.s, (void*)&d.z, (void*)&d.out, (void*)&d.sw4, (void*)&d.mstride2,
                              (void*)&d.nch_total, (void*)&d.modes, (void*)&d.counters};
             return launch(r.lp.fn, r.lp.grid, r.lp.block, dargs, 0, st);
+        }
+        if (r.lp.arg_kind == 2) {  // gemm_wn_rows.hip
+            Rows5Args& d = r.lp.r5;
+            void* dargs[] = {(void*)&d.w, (void*)&d.x, (void*)&d.s, (void*)&d.z, (void*)&d.out, (void*)&d.sw4, (void*)&d.mstride2,
+                             (void*)&d.nch_total, (void*)&d.modes, (void*)&d.M, (void*)&d.sxm2, (void*)&d.som};
+            return launch(r.lp.fn, r.lp.grid, r.lp.block, dargs, r.lp.lds_bytes, st);
         }
         void* kargs[] = {(void*)&r.wn};
         return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);

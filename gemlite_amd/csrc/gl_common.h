@@ -452,6 +452,17 @@ struct Decode3Args {
     unsigned* counters;
 };
 
+// scalar kernel arguments of gemm_w4_rows_kernel (gemm_wn_rows.hip): the same 14 preloaded dwords, then M and the row strides
+struct Rows5Args {
+    const char *w, *x, *s, *z;
+    uint16_t* out;
+    uint32_t sw4, mstride2;
+    int nch_total;
+    uint32_t modes;
+    int M;
+    uint32_t sxm2, som;
+};
+
 struct LaunchPlan {
     const void* fn;
     const char* name;
@@ -459,8 +470,9 @@ struct LaunchPlan {
     size_t lds_bytes;
     uint64_t ws_bytes;    // total workspace needed (COUNTER_BYTES + slab_bytes when K is split, else 0)
     uint64_t slab_bytes;
-    int arg_kind;         // 0: the kernel takes its parameter struct by value | 1: the scalar arguments of `d3`
+    int arg_kind;         // 0: the kernel takes its parameter struct by value | 1: the scalar arguments of `d3` | 2: those of `r5`
     Decode3Args d3;
+    Rows5Args r5;
 };
 
 }  // namespace gl

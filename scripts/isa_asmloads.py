@@ -18,7 +18,7 @@ import tempfile
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import isa_loops as L
 
-FAMILIES = ("gemm_wn_mma_kernel",)
+FAMILIES = ("gemm_wn_mma_kernel", "gemm_w4_rows_kernel")
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
 

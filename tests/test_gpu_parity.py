@@ -1559,3 +1559,97 @@ def test_small_magnitude_fp16_activations_on_the_decode_kernels(amp):
         rel = float(np.abs(y.float().cpu().numpy().astype(np.float64) - y_or).mean() / np.abs(y_or).mean())
         print(f"small-x amp={amp} {name}: rel={rel:.3e}")
         assert rel < bound, (amp, name, rel, bound)
+
+
+# ------------------------------------------------------------------------------------------------ round 5: the decode-shaped rows kernel
+ROWS5 = (9, 0, 0, 0)  # tuning[0] = 9 forces gemm_w4_rows_kernel
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("gs", [128, 64, 32, 512, 2048])
+def test_rows5_kernel_row_tiles_and_group_sizes(gs, tdt):
+    """gemm_w4_rows_kernel (gemm_wn_rows.hip): every row-tile count (16 .. 64 rows), ragged M, 64-row blocks along grid.y, groups of
+    32 / 64 / 128 / 512 / K (one metadata row), 8- and 16-wave blocks, K of 8 chunks (half of the 16 waves idle) — against the oracle."""
+    from gemlite_amd.core import _hip_matmul
+    N, K = 1024, 2048
+    lin = _make_layer(N, K, 4, gs, tdt, seed=50 + gs % 7, scales_kind="group" if gs < K else "channel")
+    for M in (2, 5, 16, 17, 31, 33, 48, 49, 64, 100):
+        x = torch.from_numpy(O.gen_x(M, K, seed=M + 11).astype(np.float32)).to(tdt).to(DEV)
+        y_or = _oracle_from_layer(lin, x)
+        for tuning in (ROWS5, (9, 0, 8, 0)):
+            name = _kernel_name(lin, x, 3, tuning)
+            if tuning[2] == 8 and not name.startswith("gemm_w4_rows_kernel"):
+                continue  # 8 waves is the only form of this (rows, group) pair: covered by the default
+            assert name.startswith("gemm_w4_rows_kernel<"), (name, M, gs, tuning)
+            y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 3, tuning)
+            torch.cuda.synchronize()
+            _compare(f"rows5/g{gs}/{str(tdt)[6:]}/M{M}/{tuning}", y, y_or, lin.output_dtype.value, extra=dict(kernel=name))
+
+
+@pytest.mark.parametrize("zeros_kind,fma,scales_kind", [("tensor", False, "group"), ("none", True, "group"),
+                                                         ("int", True, "group"), ("int", True, "channel"),
+                                                         ("tensor", True, "channel"), ("none", True, "channel")])
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_rows5_kernel_all_modes(zeros_kind, fma, scales_kind, tdt):
+    from gemlite_amd.core import _hip_matmul
+    lin = _make_layer(2048, 4096, 4, 128 if scales_kind == "group" else 4096, tdt, seed=5, zeros_kind=zeros_kind, fma=fma,
+                      scales_kind=scales_kind)
+    for M in (6, 24, 56):
+        x = torch.from_numpy(O.gen_x(M, 4096, seed=M).astype(np.float32)).to(tdt).to(DEV)
+        assert _kernel_name(lin, x, -1, ROWS5).startswith("gemm_w4_rows_kernel<"), _kernel_name(lin, x, -1, ROWS5)
+        y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, ROWS5)
+        torch.cuda.synchronize()
+        _compare(f"rows5-modes/{zeros_kind}-{fma}-{scales_kind}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x), lin.output_dtype.value)
+
+
+@pytest.mark.parametrize("N,K,gs", [(4096, 4096, 128), (1040, 2816, 128), (512, 256, 128), (2064, 11008, 64), (1024, 8192, 32)])
+def test_rows5_kernel_shapes_strides_and_defaults(N, K, gs):
+    """Shapes: the headline layer, N % 64 != 0 with K = 11 chunks, a single chunk (15 of 16 waves idle), K = 11008 (43 chunks), two chunks
+    per wave; a strided x (rows of a wider buffer); the kernel agrees with the round-4 kernels within both tolerances; and what the planner
+    does by default: the rows kernel inside its budget, for groups of 32 and for N % 64 != 0 at any M >= 2."""
+    from gemlite_amd.core import _hip_matmul
+    tdt = torch.float16
+    lin = _make_layer(N, K, 4, gs, tdt, seed=N % 13)
+    for M in (8, 32, 64):
+        wide = torch.from_numpy(O.gen_x(M, K + 64, seed=M + 5).astype(np.float32)).to(tdt).to(DEV)
+        for x in (wide[:, :K].contiguous(), wide[:, 32:32 + K]):  # contiguous / row stride K + 64, 64-byte offset
+            name = _kernel_name(lin, x, -1, ROWS5)
+            assert name.startswith("gemm_w4_rows_kernel<"), name
+            y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, ROWS5)
+            torch.cuda.synchronize()
+            _compare(f"rows5-shapes/{N}x{K}g{gs}/M{M}/{'c' if x.is_contiguous() else 's'}", y, _oracle_from_layer(lin, x), 1, extra=dict(kernel=name))
+        y4 = _hip_matmul(x.contiguous(), lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, (0, 0, 0, 65536))  # the round-4 choice
+        torch.cuda.synchronize()
+        _compare(f"rows5-vs-r4/{N}x{K}g{gs}/M{M}", y, y4.float().cpu().numpy(), 1)
+    x = torch.from_numpy(O.gen_x(16, K, seed=1).astype(np.float32)).to(tdt).to(DEV)
+    if gs == 32 or N % 64 != 0:
+        for M in (2, 16, 200):
+            xm = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
+            assert _kernel_name(lin, xm).startswith("gemm_w4_rows_kernel<"), (M, _kernel_name(lin, xm))
+            y = lin(xm)
+            torch.cuda.synchronize()
+            _compare(f"rows5-only-here/{N}x{K}g{gs}/M{M}", y, _oracle_from_layer(lin, xm), 1)
+    assert not _kernel_name(lin, x, -1, (0, 0, 0, 65536)).startswith("gemm_w4_rows_kernel")
+
+
+def test_rows5_kernel_is_deterministic_graph_capturable_and_linear():
+    from gemlite_amd.core import _hip_matmul
+    lin = _make_layer(4096, 4096, 4, 128, torch.float16, seed=3)
+    x = torch.from_numpy(O.gen_x(32, 4096, seed=2).astype(np.float32)).half().to(DEV)
+    f = lambda v: _hip_matmul(v, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, ROWS5)
+    y0 = f(x)
+    for _ in range(3):
+        assert torch.equal(f(x), y0)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        f(x)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            yg = f(x)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, y0)
+    assert torch.count_nonzero(f(torch.zeros_like(x))) == 0
+    y2 = f(x * 2)
+    assert torch.allclose(y2.float(), 2 * y0.float(), rtol=2e-3, atol=2e-3)

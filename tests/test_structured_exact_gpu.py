@@ -118,6 +118,14 @@ WN_FAMILIES = [
     ("direct32_8w", 3, 16, (2, 1, 8, 0), "gemm_wn_direct_kernel<tile32,8w>"),
     ("direct64_8w_sk2", 3, 13, (4, 2, 8, 0), "gemm_wn_direct_kernel<tile64,8w>"),
     ("stream", 3, 8, (0, 0, 1, 0), "gemm_wn_stream_kernel"),
+    # round 5: the decode-shaped rows kernel (gemm_wn_rows.hip): every row-tile count, 8 waves, 64-row blocks along grid.y
+    ("rows5_m13", 3, 13, (9, 0, 0, 0), "gemm_w4_rows_kernel<16x16>"),
+    ("rows5_m13_8w", 3, 13, (9, 0, 8, 0), "gemm_w4_rows_kernel<16x16>"),
+    ("rows5_m32", 3, 32, (9, 0, 0, 0), "gemm_w4_rows_kernel<32x16>"),
+    ("rows5_m32_8w", -1, 32, (9, 0, 8, 0), "gemm_w4_rows_kernel<32x16>"),
+    ("rows5_m40", 3, 40, (9, 0, 0, 0), "gemm_w4_rows_kernel<48x16>"),
+    ("rows5_m64", -1, 64, (9, 0, 0, 0), "gemm_w4_rows_kernel<64x16>"),
+    ("rows5_m150_gridy", -1, 150, (9, 0, 0, 0), "gemm_w4_rows_kernel<64x16>"),
     ("mma32", 4, 29, (0, 1, 1, 0), "gemm_w{b}_mma_kernel<32x128>"),
     ("mma64_sk3", 4, 64, (0, 3, 2, 0), "gemm_w{b}_mma_kernel<64x128>"),
     ("mma64_xch2", 4, 64, (0, 2, 2, 2048), "gemm_w{b}_mma_kernel<64x128>"),
@@ -162,6 +170,8 @@ def test_packed_weight_families_one_hot_times_position_coded_is_exact(nbits, fma
         must |= {"gemv_mfma16", "gemv_mfma32", "mma64_xch2", "mma128_xch4", "mma_wide256"}
         if K == 2048:
             must |= {"direct16", "direct32", "direct64_sk2", "direct32_8w", "direct64_8w_sk2", "stream"}
+    if nbits == 4:
+        must |= {"rows5_m13", "rows5_m13_8w", "rows5_m32", "rows5_m32_8w", "rows5_m40", "rows5_m64", "rows5_m150_gridy"}
     assert must <= set(ran), (sorted(must - set(ran)), ran)
 
 
