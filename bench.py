@@ -529,7 +529,7 @@ def main():
             torch.cuda.empty_cache()
             return out
 
-        def group(key, blocks):
+        def add_group(key, blocks):
             """blocks: {label: verbose block}.  The compact form goes INSIDE `roofline` (the key the driver keeps whole)."""
             full[key] = blocks
             roof[key] = {k: compact(v) for k, v in blocks.items()}
@@ -537,7 +537,7 @@ def main():
         # every group is independent: one failing block must not take the M = 256 half of the metric with it
         def guarded(key, fn):
             try:
-                group(key, fn())
+                add_group(key, fn())
             except Exception as e:
                 roof[key] = {"error": f"{type(e).__name__}: {e}"[:160]}
                 print(f"[bench] block {key} failed: {type(e).__name__}: {e}", file=sys.stderr)

@@ -177,7 +177,6 @@ FUSE_ACT_QUANT_M1 = True  # decode of dynamically quantised layers: activation q
 # memory round trips (row load, write-through drain, flag, poll, first read of the quantised rows: 1-2 us each), a launch boundary
 # plus the 2.3-us quantiser is ~4 us — layer(x) measured 3.3-7 us SLOWER fused (profiles/r04/probe_fused_quant_v*.log).
 FUSE_ACT_QUANT_ROWS = False
-_NO_FUSED_QUANT = set()  # (N, K, weight code, x dtype, M, device) the library answered GEMLITE_ERR_NO_FUSED_QUANT for
 TUNING_OVERRIDE = None  # development hook: 4 ints forwarded as gemlite_hip_forward_args.tuning (0 = library default)
 
 # Per-layer launch templates.  A template is the IMMUTABLE byte image of a gemlite_hip_forward_args whose static
@@ -274,18 +273,10 @@ def lookup_tuning(matmul_type: int, M: int, a) -> Optional[tuple]:
     return tuple(v & m for v, m in zip(t, _TUNING_MASK))
 
 
-def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x: Optional[Tensor], meta_args,
-                matmul_type: int, tuning=None, fused_quant_optional: bool = False) -> Optional[Tensor]:
-    """out[M, N] = epilogue(x[M, K] @ dequant(W_q)) — the seam the reference fills with
-    GEMLITE_TRITON_MAPPING[...].forward (core.py:184-190).  ONE C call per launch: the library plans, carves the
-    caller's per-stream workspace and launches; only if that workspace turns out too small is it regrown."""
-    lib = _hip.load()
-    _hip.require_gpu_tensor(x, "x")
-    _hip.require_gpu_tensor(W_q, "W_q")
-    if not _AUTOLOAD_DONE:
-        autoload_default_config(x.device.index or 0)
-    if x.device != W_q.device:
-        raise _hip.GemliteHipError(f"x is on {x.device}, the packed weight on {W_q.device}")
+def _call_args(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x: Optional[Tensor], meta_args, matmul_type: int,
+               tuning, raw_x: bool, out_ptr: int, out_strides) -> "_hip.ForwardArgs":
+    """The gemlite_hip_forward_args of ONE call: the layer's template + the per-call fields.  Shared by the launch (_hip_matmul) and by
+    the planning query in front of it (_library_quantises_inside): both see exactly the same request."""
     a = _static_args(W_q, scales, zeros, meta_args)
     M, K = x.shape
     mx = is_mx_dtype(meta_args[5])
@@ -293,10 +284,9 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
         K *= 2  # e2m1 codes, two per byte
     if K != a.K:
         raise ValueError(f"x has {K} input features, the packed weight expects {a.K}")
-    out = torch.empty((M, a.N), dtype=DTYPE_TO_TORCH[a.output_dtype], device=x.device)
     a.matmul_type = matmul_type
-    a.x, a.out, a.M = x.data_ptr(), out.data_ptr(), M
-    raw_mx = (mx and fused_quant_optional and scales_x is None and x.dtype in (torch.float16, torch.bfloat16) and
+    a.x, a.out, a.M = x.data_ptr(), out_ptr, M
+    raw_mx = (mx and raw_x and scales_x is None and x.dtype in (torch.float16, torch.bfloat16) and
               meta_args[5] in (DType.MXFP8.value, DType.MXFP4.value, DType.NVFP4.value))
     if raw_mx:  # one unquantised row of a block-scaled dynamic layer: the kernel quantises it (the layer's format rides in type_id)
         a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
@@ -307,7 +297,7 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
     else:
         a.input_dtype = TORCH_TO_DTYPE[x.dtype].value
     a.stride_xm, a.stride_xk = x.stride(0), x.stride(1)
-    a.stride_om, a.stride_on = out.stride(0), out.stride(1)
+    a.stride_om, a.stride_on = out_strides
     if scales_x is not None:
         a.scales_x, a.stride_sx_m = scales_x.data_ptr(), scales_x.stride(0)
     if tuning is None:
@@ -317,6 +307,26 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
     if tuning is not None:
         for i in range(4):
             a.tuning[i] = int(tuning[i])
+    return a
+
+
+def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x: Optional[Tensor], meta_args,
+                matmul_type: int, tuning=None, raw_x: bool = False) -> Tensor:
+    """out[M, N] = epilogue(x[M, K] @ dequant(W_q)) — the seam the reference fills with
+    GEMLITE_TRITON_MAPPING[...].forward (core.py:184-190).  ONE C call per launch: the library plans, carves the
+    caller's per-stream workspace and launches; only if that workspace turns out too small is it regrown.
+    raw_x: x holds the UNQUANTISED 16-bit rows of a dynamically quantised layer and the kernel quantises them itself (the caller
+    asked _library_quantises_inside first)."""
+    lib = _hip.load()
+    _hip.require_gpu_tensor(x, "x")
+    _hip.require_gpu_tensor(W_q, "W_q")
+    if not _AUTOLOAD_DONE:
+        autoload_default_config(x.device.index or 0)
+    if x.device != W_q.device:
+        raise _hip.GemliteHipError(f"x is on {x.device}, the packed weight on {W_q.device}")
+    M = x.shape[0]
+    out = torch.empty((M, W_q.shape[1]), dtype=DTYPE_TO_TORCH[TORCH_TO_DTYPE[DTYPE_TO_TORCH[meta_args[6]]].value], device=x.device)
+    a = _call_args(x, W_q, scales, zeros, scales_x, meta_args, matmul_type, tuning, raw_x, out.data_ptr(), (out.stride(0), out.stride(1)))
     with _hip.on_device(x.device):  # launches go to the tensor's device, not the thread's current one
         stream = _hip.current_stream_handle(x.device)
         ws = _hip.workspace(x.device, stream, 0)
@@ -327,8 +337,6 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
             ws = _hip.workspace(x.device, stream, need)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             rc = lib.gemlite_hip_forward(_hip.C.byref(a), stream)
-    if rc == _hip.ERR_NO_FUSED_QUANT and fused_quant_optional:
-        return None  # no kernel quantises these rows in-launch: the caller quantises x and calls again (two launches)
     if rc != 0:
         _hip.raise_for_status(rc, "gemlite_hip_forward")
     # a shape that only the coverage kernel takes is correct but orders of magnitude slower: say so, once per shape
@@ -344,6 +352,39 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
     return out
 
 
+# ---- in-launch activation quantisation: ONE source of truth ------------------------------------------------------------
+# Whether a kernel takes the UNQUANTISED 16-bit rows of a dynamically quantised layer (per-token int8 / fp8, or block-scaled MXFP8 /
+# MXFP4 / NVFP4) is decided in ONE place — resolve() in csrc/api.hip — and asked through gemlite_hip_query, which plans and never
+# launches, on exactly the arguments the launch would carry (_call_args).  Rounds 3-4 kept three hand-written copies of the library's
+# preconditions here (alignment, K % 16, K <= 65536, packed / unpacked, one row / several) plus a memo of refusals under a key that
+# left out what a refusal depends on.  The answer is cached per everything it depends on: the layer (meta ints, shapes,
+# strides, 16-byte alignment of its tensors), M, the activation type and alignment, the device, and the tuning-table epoch (a table
+# entry for the shape rides in the query's tuning[] like in the launch's).
+_FUSED_QUANT_ANSWERS: dict = {}
+_NO_FUSED_QUANT = _FUSED_QUANT_ANSWERS  # (name kept for the tests / scripts that clear it)
+
+
+def _library_quantises_inside(x2: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, meta_args, matmul_type: int) -> bool:
+    if matmul_type >= 0 or TUNING_OVERRIDE is not None or x2.dtype not in (torch.float16, torch.bfloat16) or not x2.is_cuda:
+        return False  # a forced family / a development override keeps the two-launch form
+    M = x2.shape[0]
+    if not (FUSE_ACT_QUANT_M1 if M == 1 else FUSE_ACT_QUANT_ROWS):
+        return False
+    key = (tuple(meta_args), tuple(W_q.shape), W_q.stride(), W_q.dtype, W_q.data_ptr() & 15, scales.data_ptr() & 15, zeros.data_ptr() & 15,
+           tuple(scales.shape), tuple(zeros.shape), M, x2.dtype, x2.stride(), x2.data_ptr() & 15, x2.device.index, _CACHE_EPOCH[0])
+    ans = _FUSED_QUANT_ANSWERS.get(key)
+    if ans is None:
+        if not _AUTOLOAD_DONE:
+            autoload_default_config(x2.device.index or 0)
+            key = key[:-1] + (_CACHE_EPOCH[0],)
+        a = _call_args(x2, W_q, scales, zeros, None, meta_args, matmul_type, None, True, 0x1000, (W_q.shape[1], 1))
+        ans = _hip.load().gemlite_hip_query(_hip.C.byref(a)) == 0
+        if len(_FUSED_QUANT_ANSWERS) >= 4096:
+            _FUSED_QUANT_ANSWERS.clear()
+        _FUSED_QUANT_ANSWERS[key] = ans
+    return ans
+
+
 _COVERAGE_CHECKED = set()
 
 
@@ -357,81 +398,32 @@ def _forward_impl(x: Tensor, bias: Optional[Tensor], tensor_args: List[Tensor], 
     out_shape = x.shape[:-1] + (out_features,)
     in_code = meta_args[5]
     scales_x = None
-    if bool(meta_args[0]) and is_mx_dtype(in_code):
-        # block-scaled activations (core.py:165-175): microscales (channel_scale_mode 4) or one fp32 scale per token (2)
-        c_mode = meta_args[9]
-        K_ = x.shape[-1]
-        if FUSE_ACT_QUANT_M1 and ((c_mode == 4 and in_code in (DType.MXFP8.value, DType.MXFP4.value, DType.NVFP4.value)) or (c_mode == 2 and in_code == DType.MXFP8.value)) and \
-                x.numel() == K_ and matmul_type < 0 and \
-                TUNING_OVERRIDE is None and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.data_ptr() % 16 == 0:
-            # ONE row: the few-row kernel quantises it block by block itself (round 4; bit-identical to quantiser + matmul); where the
-            # library has no such kernel for the shape it says so once and the answer is remembered
-            fkey = (W_q.shape[1], K_, in_code, meta_args[1], x.dtype, "mx", c_mode, x.device.index)
-            if fkey not in _NO_FUSED_QUANT:
-                out = _hip_matmul(x if x.dim() == 2 else x.view(-1, K_), W_q, scales, zeros, None, meta_args, matmul_type, fused_quant_optional=True)
-                if out is not None:
-                    if len(out_shape) != 2:
-                        out = out.view(out_shape)
-                    if bias is not None:
-                        out += bias
-                    return out
-                _NO_FUSED_QUANT.add(fkey)
-        if in_code == DType.MXFP8.value and c_mode == 4:
-            x, scales_x = scale_activations_mxfp8(x, w_dtype=torch.float8_e4m3fn)
-        elif in_code == DType.MXFP8.value and c_mode == 2:
-            x, scales_x = scale_activations_per_token(x, w_dtype=torch.float8_e4m3fn)
-        elif in_code == DType.MXFP4.value and c_mode == 4:
-            x, scales_x = scale_activations_mxfp4(x)
-        elif in_code == DType.NVFP4.value and c_mode == 4:
-            x, scales_x = scale_activations_nvfp4(x)
+    raw_x = False
+    if bool(meta_args[0]) and (is_mx_dtype(in_code) or DType(in_code) in FP8_INT8_DTYPES):
+        # Dynamic activation quantisation (core.py:155-175): per token (int8 / fp8) or per block (MXFP8 / MXFP4 / NVFP4).  Where the library
+        # has a kernel that quantises the rows itself — one row: inside the decode kernels, bit-identical to quantiser + matmul; several
+        # rows: opt-in, see FUSE_ACT_QUANT_ROWS — the unquantised x goes straight in (ONE launch); the library is the one that knows.
+        x2f = x if x.dim() == 2 else x.view(-1, x.shape[-1])
+        if _library_quantises_inside(x2f, W_q, scales, zeros, meta_args, matmul_type):
+            raw_x = True
+        elif is_mx_dtype(in_code):
+            c_mode = meta_args[9]  # microscales (channel_scale_mode 4) or one fp32 scale per token (2)
+            if in_code == DType.MXFP8.value and c_mode == 4:
+                x, scales_x = scale_activations_mxfp8(x, w_dtype=torch.float8_e4m3fn)
+            elif in_code == DType.MXFP8.value and c_mode == 2:
+                x, scales_x = scale_activations_per_token(x, w_dtype=torch.float8_e4m3fn)
+            elif in_code == DType.MXFP4.value and c_mode == 4:
+                x, scales_x = scale_activations_mxfp4(x)
+            elif in_code == DType.NVFP4.value and c_mode == 4:
+                x, scales_x = scale_activations_nvfp4(x)
+            else:
+                raise NotImplementedError(f"no activation quantiser for {DType(in_code).name} with channel_scale_mode {c_mode}")
         else:
-            raise NotImplementedError(f"no activation quantiser for {DType(in_code).name} with channel_scale_mode {c_mode}")
-    elif bool(meta_args[0]) and DType(in_code) in FP8_INT8_DTYPES:
-        # dynamic per-token activation quantisation (core.py:155-175).  One row of 16-bit activations against unpacked
-        # 8-bit weights (decode): the library quantises x inside the matmul kernel's prologue — one launch, not two.
-        # (the fused kernel's own preconditions — api.hip: K-contiguous weights, K % 16 == 0, K <= 65536, 16-byte aligned rows —
-        #  are checked HERE, so a layer that runs at M = 2 also runs at M = 1 without catching the library's refusal)
-        K_ = x.shape[-1]
-        fused = (FUSE_ACT_QUANT_M1 and x.numel() == K_ and meta_args[4] == 1 and meta_args[10] == 0 and
-                 x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0 and K_ % 16 == 0 and K_ <= 65536 and
-                 W_q.stride(0) == 1 and W_q.stride(1) % 16 == 0 and W_q.data_ptr() % 16 == 0 and
-                 (x.is_contiguous() and x.data_ptr() % 16 == 0))
-        if not fused and FUSE_ACT_QUANT_M1 and x.numel() == K_ and meta_args[4] > 1 and matmul_type < 0 and TUNING_OVERRIDE is None and \
-                x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.data_ptr() % 16 == 0:
-            # one row against PACKED weights (A8W4 / A8W2 fp8 dynamic, BitNet int8 dynamic): the decode kernel quantises the row itself
-            # (round 4); where the library has no such kernel for the shape it says so once and the answer is remembered
-            x2f = x if x.dim() == 2 else x.view(-1, K_)
-            fkey = (W_q.shape[1], K_, in_code, meta_args[1], x.dtype, 1, x.device.index)
-            if fkey not in _NO_FUSED_QUANT:
-                out = _hip_matmul(x2f, W_q, scales, zeros, None, meta_args, matmul_type, fused_quant_optional=True)
-                if out is not None:
-                    if len(out_shape) != 2:
-                        out = out.view(out_shape)
-                    if bias is not None:
-                        out += bias
-                    return out
-                _NO_FUSED_QUANT.add(fkey)
-        if not fused and FUSE_ACT_QUANT_ROWS and x.numel() > K_ and meta_args[4] == 1 and meta_args[10] == 0 and \
-                x.dtype in (torch.float16, torch.bfloat16) and matmul_type < 0 and TUNING_OVERRIDE is None and x.is_contiguous():
-            # 2 <= M: ONE launch where the library has a kernel whose blocks quantise the rows among themselves (same arithmetic,
-            # bit-identical to the two-launch path); where it has none it says so once per (shape, M) and the answer is remembered
-            x2f = x if x.dim() == 2 else x.view(-1, K_)
-            fkey = (W_q.shape[1], K_, in_code, x.dtype, x2f.shape[0], x.device.index)
-            if fkey not in _NO_FUSED_QUANT:
-                out = _hip_matmul(x2f, W_q, scales, zeros, None, meta_args, matmul_type, fused_quant_optional=True)
-                if out is not None:
-                    if len(out_shape) != 2:
-                        out = out.view(out_shape)
-                    if bias is not None:
-                        out += bias
-                    return out
-                _NO_FUSED_QUANT.add(fkey)
-        if not fused:
             x, scales_x = scale_activations_per_token(x, w_dtype=DTYPE_TO_TORCH[in_code])
     x2 = x if x.dim() == 2 else x.view(-1, x.shape[-1])
     # matmul_type < 0 (auto) is resolved inside the library: the HIP kernel families have their own M
     # thresholds (GEMV <= 4 rows, streaming MFMA above), unlike the Triton ones of get_matmul_type()
-    out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type)
+    out = _hip_matmul(x2, W_q, scales, zeros, scales_x, meta_args, matmul_type, raw_x=raw_x)
     if len(out_shape) != 2:
         out = out.view(out_shape)
     if bias is not None:

@@ -318,10 +318,20 @@ static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
     return tiles <= 256 || (tiles <= 512 && a.K <= 4096);
 }
 
-// gemm_wn_rows.hip defaults (round 5; refined by profiles/r05/probe_rows5*.log): from how many rows, and up to how many bytes of x
-// re-read per launch, the 16-column rows kernel is the default for A16W4
-static int rows5_min_m() { return 5; }
-static int64_t rows5_budget_bytes() { return 144ll << 20; }
+// When gemm_w4_rows_kernel (gemm_wn_rows.hip, round 5) is the default for A16W4 (profiles/r05/probe_rows5_v2.log: 8 layer shapes x M = 2 .. 64
+// against the round-4 choice, graph-replayed layer(x) in us):
+//   * its 16-column blocks hold 146 KB of LDS, so one block per CU: it pays while ONE round of blocks covers N (N / 16 <= CUs: N <= 4096 —
+//     4096^2 M = 16 / 32 / 64: 7.4 / 12.2 / 12.9 -> 6.8 / 8.5 / 11.0; at N = 5120 .. 14336 two or three rounds lose 1.3 - 2.2x);
+//   * every block re-reads all of x through L2 -> LDS: past ~176 MB per launch the tile kernels win (4096 x 11008: M = 32 17.7 -> 17.2,
+//     M = 48 19.9 -> 21.5);
+//   * weights are requested two chunks (2 KB per wave) ahead: enough for K <= 12288 (4096 x 11008, M = 2 / 8 / 16: 12.9 / 17.1 / 17.3 ->
+//     12.0 / 12.7 / 13.1), not for K = 14336 (M = 16: 14.6 -> 16.3);
+//   * at K <= 4096 the MFMA GEMV (2 .. 4 rows) and the registers-only kernel keep 2 .. 7 rows (6.2 - 6.9 vs 6.3 - 6.5: a draw).
+static bool rows5_pays(int64_t M, int64_t N, int64_t K) {
+    if (M > 64 || N % 16 != 0 || N / 16 > gl::resident_block_limit() || N / 16 < 96 || K > 12288) return false;
+    if (M < (K <= 4096 ? 8 : 2)) return false;
+    return (N / 16) * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
+}
 
 static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
     r.status = validate(&a);
@@ -428,9 +438,7 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         if (x16 && a.W_nbits == 4 && (mt == GEMLITE_MATMUL_AUTO || mt == GEMLITE_MATMUL_GEMM_SPLITK || (mt == GEMLITE_MATMUL_GEMM && a.tuning[0] == 9)) &&
             !(a.tuning[3] & 65536) && (a.tuning[0] == 9 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && a.M >= 2))) {
             const bool only_here = p.gs_shift == 5 || a.N % 64 != 0;  // nothing but the coverage kernel behind this one
-            const int64_t mpad = (a.M + 15) / 16 * 16;
-            const int64_t x_reread = (a.N / 16) * mpad * a.K * 2;      // bytes of x through the address paths of the launch
-            const bool in_budget = a.M >= rows5_min_m() && a.M <= 64 && x_reread <= rows5_budget_bytes();
+            const bool in_budget = rows5_pays(a.M, a.N, a.K);
             if (a.tuning[0] == 9 || only_here || in_budget) {
                 WnParams pr = p;
                 LaunchPlan lr{};

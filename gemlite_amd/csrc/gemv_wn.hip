@@ -800,7 +800,10 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
             // keeps the round-3 kernel (A/B runs).
             if (nw == 16 && !(a.tuning[3] & 4096) && a.channel_scale_mode == 0 && a.stride_on == 1 && p.gs_shift >= 0 && p.gs_shift < 32 &&
                 (int64_t)rows * 16 < (1ll << 31)) {
-                const bool need_s2 = p.w_mode >= 2, need_z2 = (p.w_mode == 1 || p.w_mode >= 3) && !p.zero_is_scalar;
+                // (the scalar-zero bit and pointer only when the mode HAS a zero point — a C-ABI caller may pass zero_is_scalar
+                //  with zeros = NULL for W_group_mode 0 / 2, and the kernel reads zp[0] whenever the bit is set)
+                const bool has_z2 = p.w_mode == 1 || p.w_mode >= 3, z_scalar2 = has_z2 && p.zero_is_scalar;
+                const bool need_s2 = p.w_mode >= 2, need_z2 = has_z2 && !p.zero_is_scalar;
                 lp.arg_kind = 1;
                 lp.fn = gemv_w4_decode3_fn(f16 ? 0 : 1, nt);
                 lp.name = "gemv_w4_decode3_kernel<tile16,16w>";
@@ -808,12 +811,12 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
                 lp.d3.w = (const char*)p.w;
                 lp.d3.x = (const char*)p.x;
                 lp.d3.s = need_s2 ? (const char*)p.scales : (const char*)p.w;
-                lp.d3.z = (need_z2 || p.zero_is_scalar) ? (const char*)p.zeros : (const char*)p.w;
+                lp.d3.z = (need_z2 || z_scalar2) ? (const char*)p.zeros : (const char*)p.w;
                 lp.d3.out = (uint16_t*)p.epi.out;
                 lp.d3.sw4 = (uint32_t)p.stride_wk * 4u;
                 lp.d3.mstride2 = (need_s2 || need_z2) ? (uint32_t)p.stride_meta_g * 2u : 0u;
                 lp.d3.nch_total = rows / 32;
-                lp.d3.modes = (uint32_t)p.w_mode | (p.zero_is_scalar ? 16u : 0u) | (((tiles & 15) == 0) ? 32u : 0u) | ((a.tuning[3] & 4) ? 64u : 0u) |
+                lp.d3.modes = (uint32_t)p.w_mode | (z_scalar2 ? 16u : 0u) | (((tiles & 15) == 0) ? 32u : 0u) | ((a.tuning[3] & 4) ? 64u : 0u) |
                               ((uint32_t)p.gs_shift << 8);
                 lp.d3.counters = nullptr;
             }

@@ -17,10 +17,12 @@
 #include <torch/csrc/autograd/python_variable.h>
 
 #include <array>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "../../include/gemlite_hip.h"
 
@@ -51,6 +53,12 @@ struct WsKey {
 };
 std::mutex g_ws_mutex;
 std::map<WsKey, at::Tensor> g_ws;
+// Replaced (outgrown) workspaces are RETIRED, never released: another thread may still hold the raw pointer of the old
+// buffer in its thread-local view below and launch with it — split-K tickets and slabs written into memory the caching allocator had
+// already handed to an activation tensor would corrupt it silently.  A process grows a workspace a handful of times (geometrically),
+// so the retired list stays at a few MB.  g_ws_generation tells the thread-local views to look again.
+std::vector<at::Tensor> g_ws_retired;
+std::atomic<uint64_t> g_ws_generation{1};
 
 at::Tensor workspace_for(int dev, void* stream, uint64_t nbytes) {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
@@ -60,7 +68,9 @@ at::Tensor workspace_for(int dev, void* stream, uint64_t nbytes) {
     uint64_t p2 = 1;
     while (p2 < size) p2 <<= 1;  // grow geometrically
     at::Tensor ws = at::zeros({(int64_t)p2}, at::TensorOptions().dtype(at::kByte).device(at::kCUDA, dev));
+    if (it != g_ws.end()) g_ws_retired.push_back(it->second);
     g_ws[WsKey{dev, stream}] = ws;
+    g_ws_generation.fetch_add(1, std::memory_order_release);
     return ws;
 }
 
@@ -176,21 +186,28 @@ PyObject* fast_forward(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     void* stream = (void*)c10::hip::getCurrentHIPStream(L->dev).stream();
     int rc;
     {
-        // thread-local view of the last workspace: no lock on the steady path
+        // thread-local view of the last workspace: no lock on the steady path.  It holds the TENSOR (a reference), not just its pointer,
+        // and is refreshed whenever any workspace of the process was replaced (generation counter) — ADVICE r4
         thread_local int tl_dev = -1;
         thread_local void* tl_stream = nullptr;
+        thread_local at::Tensor tl_ws;
         thread_local void* tl_ptr = nullptr;
         thread_local uint64_t tl_bytes = 0;
-        if (tl_dev != L->dev || tl_stream != stream || !tl_ptr) {
-            at::Tensor ws = workspace_for(L->dev, stream, 0);
-            tl_dev = L->dev; tl_stream = stream; tl_ptr = ws.data_ptr(); tl_bytes = (uint64_t)ws.numel();
+        thread_local uint64_t tl_gen = 0;
+        const uint64_t gen = g_ws_generation.load(std::memory_order_acquire);
+        if (tl_dev != L->dev || tl_stream != stream || !tl_ptr || tl_gen != gen) {
+            tl_ws = workspace_for(L->dev, stream, 0);
+            tl_gen = g_ws_generation.load(std::memory_order_acquire);
+            tl_dev = L->dev; tl_stream = stream; tl_ptr = tl_ws.data_ptr(); tl_bytes = (uint64_t)tl_ws.numel();
         }
         a.workspace = tl_ptr;
         a.workspace_bytes = tl_bytes;
         rc = gemlite_hip_forward(&a, stream);
         if (rc == GEMLITE_ERR_WORKSPACE) {
             const uint64_t need = gemlite_hip_workspace_bytes(&a);
-            at::Tensor ws = workspace_for(L->dev, stream, need);
+            tl_ws = workspace_for(L->dev, stream, need);
+            tl_gen = g_ws_generation.load(std::memory_order_acquire);
+            const at::Tensor& ws = tl_ws;
             tl_ptr = ws.data_ptr(); tl_bytes = (uint64_t)ws.numel();
             a.workspace = tl_ptr;
             a.workspace_bytes = tl_bytes;

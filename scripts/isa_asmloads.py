@@ -37,15 +37,33 @@ def first_operand_regs(text):
     return regs_of(ops.split(",")[0])
 
 
-def replay(lines, seq):
-    """seq: instruction indices in execution order.  Returns [(address, text, registers)] of early touches."""
+def replay(lines, seq, weakest_of_alternatives=False):
+    """seq: instruction indices in execution order.  Returns [(address, text, registers)] of early touches.
+    weakest_of_alternatives (gemm_w4_rows_kernel, round 5): that kernel picks ONE of up to four counted waits with uniform branches (what sits
+    behind the awaited piece depends on how many chunks are left); a linear replay would execute all four, vmcnt(0) included.  A run of
+    `s_waitcnt vmcnt` separated only by scalar branch / compare instructions is therefore replayed as its WEAKEST member — the steady-state
+    path, on which every conditional request is issued — which can only raise alarms, never hide one."""
     queue, bad = [], []  # queue: oldest first; each entry = set of destination registers (empty: store / LDS-DMA)
-    for i in seq:
+    skip_until = -1
+    for pos, i in enumerate(seq):
+        if pos <= skip_until:
+            continue
         a, t = lines[i]
         op = t.split()[0]
         m = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t)
         if m:
             k = int(m.group(1))
+            if weakest_of_alternatives:
+                nxt = pos + 1
+                while nxt < len(seq) and nxt - pos < 24:
+                    t2 = lines[seq[nxt]][1]
+                    m2 = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t2)
+                    if m2:
+                        k = max(k, int(m2.group(1)))
+                        skip_until = nxt
+                    elif not t2.startswith(("s_cbranch", "s_branch", "s_cmp", "s_and", "s_or", "s_cselect", "s_mov", "s_nop", "s_xor")):
+                        break
+                    nxt += 1
             if len(queue) > k:
                 queue = queue[len(queue) - k:] if k else []
             continue
@@ -103,7 +121,7 @@ def check():
                 return
             lo, hi, _ = best
             seq = list(range(0, hi + 1)) + list(range(lo, hi + 1))
-            for (a, t, r) in replay(lines, seq)[:4]:
+            for (a, t, r) in replay(lines, seq, weakest_of_alternatives="gemm_w4_rows_kernel" in fn)[:4]:
                 reports.append((fn, hex(a), t, r))
         for line in asm.split("\n"):
             m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)

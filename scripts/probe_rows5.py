@@ -18,7 +18,7 @@ if os.environ.get("GL_SHAPES"):
 MS = [int(a) for a in sys.argv[1:]] or [2, 4, 5, 8, 16, 24, 32, 48, 64]
 DT = os.environ.get("GL_DT", "fp16")
 GS = int(os.environ.get("GL_GS", "128"))
-CANDS = {"r4": (0, 0, 0, 65536), "rows5": (9, 0, 0, 0), "rows5_8w": (9, 0, 8, 0), "default": None}
+CANDS = {"r4": (0, 0, 0, 65536), "rows5": (9, 0, 0, 0), "default": None}
 
 
 def time_us(mods, x, tuning, min_seconds=0.06):
@@ -78,8 +78,6 @@ for (N, K) in SHAPES:
             kn = kname(mods[0], x, t)
             if label.startswith("rows5") and not kn.startswith("gemm_w4_rows_kernel"):
                 continue
-            if label == "rows5_8w" and M > 32:
-                continue  # (8 waves is the default there)
             try:
                 res[label] = round(time_us(mods, x, t), 2)
                 names[label] = kn

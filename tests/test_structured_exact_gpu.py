@@ -120,9 +120,8 @@ WN_FAMILIES = [
     ("stream", 3, 8, (0, 0, 1, 0), "gemm_wn_stream_kernel"),
     # round 5: the decode-shaped rows kernel (gemm_wn_rows.hip): every row-tile count, 8 waves, 64-row blocks along grid.y
     ("rows5_m13", 3, 13, (9, 0, 0, 0), "gemm_w4_rows_kernel<16x16>"),
-    ("rows5_m13_8w", 3, 13, (9, 0, 8, 0), "gemm_w4_rows_kernel<16x16>"),
     ("rows5_m32", 3, 32, (9, 0, 0, 0), "gemm_w4_rows_kernel<32x16>"),
-    ("rows5_m32_8w", -1, 32, (9, 0, 8, 0), "gemm_w4_rows_kernel<32x16>"),
+    ("rows5_m32_auto", -1, 32, (9, 0, 0, 0), "gemm_w4_rows_kernel<32x16>"),
     ("rows5_m40", 3, 40, (9, 0, 0, 0), "gemm_w4_rows_kernel<48x16>"),
     ("rows5_m64", -1, 64, (9, 0, 0, 0), "gemm_w4_rows_kernel<64x16>"),
     ("rows5_m150_gridy", -1, 150, (9, 0, 0, 0), "gemm_w4_rows_kernel<64x16>"),
@@ -171,7 +170,7 @@ def test_packed_weight_families_one_hot_times_position_coded_is_exact(nbits, fma
         if K == 2048:
             must |= {"direct16", "direct32", "direct64_sk2", "direct32_8w", "direct64_8w_sk2", "stream"}
     if nbits == 4:
-        must |= {"rows5_m13", "rows5_m13_8w", "rows5_m32", "rows5_m32_8w", "rows5_m40", "rows5_m64", "rows5_m150_gridy"}
+        must |= {"rows5_m13", "rows5_m32", "rows5_m32_auto", "rows5_m40", "rows5_m64", "rows5_m150_gridy"}
     assert must <= set(ran), (sorted(must - set(ran)), ran)
 
 
