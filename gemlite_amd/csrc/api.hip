@@ -318,19 +318,25 @@ static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
     return tiles <= 256 || (tiles <= 512 && a.K <= 4096);
 }
 
-// When gemm_w4_rows_kernel (gemm_wn_rows.hip, round 5) is the default for A16W4 (profiles/r05/probe_rows5_v2.log: 8 layer shapes x M = 2 .. 64
-// against the round-4 choice, graph-replayed layer(x) in us):
+// When gemm_w4_rows_kernel (gemm_wn_rows.hip, round 5) is the default for A16W4 (profiles/r05/probe_rows5_v2*.log: 14 layer shapes x
+// M = 2 .. 64 against the round-4 choice, graph-replayed layer(x) in us):
 //   * its 16-column blocks hold 146 KB of LDS, so one block per CU: it pays while ONE round of blocks covers N (N / 16 <= CUs: N <= 4096 —
-//     4096^2 M = 16 / 32 / 64: 7.4 / 12.2 / 12.9 -> 6.8 / 8.5 / 11.0; at N = 5120 .. 14336 two or three rounds lose 1.3 - 2.2x);
+//     4096^2 M = 16 / 32 / 64: 7.4 / 12.2 / 12.9 -> 6.8 / 8.5 / 11.0, 3584 x 4096: 9.0 / 12.0 / 14.8 -> 6.7 / 8.5 / 11.1; at N = 5120 ..
+//     14336 two or three rounds lose 1.3 - 2.2x).  From 192 column tiles at any row count below, from 128 (N = 2048) with 16 .. 32 rows;
 //   * every block re-reads all of x through L2 -> LDS: past ~176 MB per launch the tile kernels win (4096 x 11008: M = 32 17.7 -> 17.2,
-//     M = 48 19.9 -> 21.5);
-//   * weights are requested two chunks (2 KB per wave) ahead: enough for K <= 12288 (4096 x 11008, M = 2 / 8 / 16: 12.9 / 17.1 / 17.3 ->
-//     12.0 / 12.7 / 13.1), not for K = 14336 (M = 16: 14.6 -> 16.3);
-//   * at K <= 4096 the MFMA GEMV (2 .. 4 rows) and the registers-only kernel keep 2 .. 7 rows (6.2 - 6.9 vs 6.3 - 6.5: a draw).
+//     M = 48 19.9 -> 21.5; 4096 x 8192 M = 64, 256 MB: 18.3 -> 19.0);
+//   * weights are requested two chunks (2 KB per wave) ahead: enough for K <= 12288, not for K = 14336 (M = 16: 14.6 -> 16.3);
+//   * from how many rows: K <= 2048 from 2 (4096 x 1024 / x 2048, M = 2: 5.0 / 5.1 -> 3.7 / 4.4); K <= 4096 from 8 (2 .. 7 rows are a
+//     draw with the MFMA GEMV / the registers-only kernel: 6.2 - 6.9 vs 6.3 - 6.5); longer K from 16 (4096 x 8192, M = 8: 9.2 -> 10.1
+//     but M = 32: 15.6 -> 13.7) — unless the registers-only kernel does not take K (K % 2048 != 0: 4096 x 11008 M = 2 / 8 / 16:
+//     12.9 / 17.1 / 17.3 -> 12.0 / 12.7 / 13.1).
 static bool rows5_pays(int64_t M, int64_t N, int64_t K) {
-    if (M > 64 || N % 16 != 0 || N / 16 > gl::resident_block_limit() || N / 16 < 96 || K > 12288) return false;
-    if (M < (K <= 4096 ? 8 : 2)) return false;
-    return (N / 16) * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
+    if (M < 2 || M > 64 || N % 16 != 0 || K > 12288) return false;
+    const int64_t tiles = N / 16;
+    if (tiles > gl::resident_block_limit() || tiles < ((M >= 16 && M <= 32) ? 128 : 192)) return false;  // (2048 x 8192: M = 16 / 32 win, M = 64 loses)
+    const int64_t min_m = K <= 2048 ? 2 : (K <= 4096 ? 8 : (K % 2048 != 0 ? 2 : 16));
+    if (M < min_m) return false;
+    return tiles * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
 }
 
 static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {

@@ -489,7 +489,8 @@ def test_direct_mfma_kernel_tiles_and_splits(nbits, N, K, tdt):
             torch.cuda.synchronize()
             _compare(f"direct/w{nbits}/{N}x{K}/{str(tdt)[6:]}/M{M}/{tuning}", y, y_or, lin.output_dtype.value)
     x = torch.from_numpy(O.gen_x(8, K, seed=1).astype(np.float32)).to(tdt).to(DEV)
-    assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel"), _kernel_name(lin, x)
+    # (round 5: at 4096^2 from 8 rows the default is the decode-shaped rows kernel; tuning[3] & 65536 = the round-4 choice)
+    assert _kernel_name(lin, x, -1, (0, 0, 0, 65536)).startswith("gemm_wn_direct_kernel"), _kernel_name(lin, x)
 
 
 @pytest.mark.parametrize("zeros_kind,fma,scales_kind", [("tensor", False, "group"), ("none", True, "group"),

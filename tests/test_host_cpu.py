@@ -96,30 +96,53 @@ def test_struct_abi_and_validation():
     (dict(M=4), "gemv_mfma_kernel<tile16,rows4>"),
     (dict(M=4, tuning=(0, 0, 0, 512)), "gemm_wn_direct_kernel<tile16>"),   # 2 <= M <= 32: registers-only MFMA kernel, K not split
     (dict(M=5), "gemm_wn_direct_kernel<tile32,8w>"),   # round 3: from 5 rows 32-column tiles x 2 K slices x 8 waves
-    (dict(M=8), "gemm_wn_direct_kernel<tile32,8w>"),     # >= 8 rows: 32-column tiles x split-K 2 (less x traffic), round 3: 8 waves per block
+    (dict(M=8, tuning=(0, 0, 0, 65536)), "gemm_wn_direct_kernel<tile32,8w>"),     # >= 8 rows: 32-column tiles x split-K 2 (less x traffic), round 3: 8 waves per block (tuning[3] & 65536: the round-4 choice)
+    # round 5: the decode-shaped rows kernel (gemm_wn_rows.hip) from 8 rows where ONE round of its 16-column blocks covers N (N / 16 <= 256 CUs)
+    (dict(M=8), "gemm_w4_rows_kernel<16x16>"),
+    (dict(M=16), "gemm_w4_rows_kernel<16x16>"),
+    (dict(M=17), "gemm_w4_rows_kernel<32x16>"),
+    (dict(M=33), "gemm_w4_rows_kernel<48x16>"),
+    (dict(M=64), "gemm_w4_rows_kernel<64x16>"),
+    (dict(M=65), "gemm_w4_mma_kernel<64x64>"),
+    (dict(M=7), "gemm_wn_direct_kernel<tile32,8w>"),     # ... 2 .. 7 rows at K <= 4096 keep the round-3 kernels (a draw)
+    (dict(M=2, N=4096, K=11008), "gemm_w4_rows_kernel<16x16>"),   # ... a longer K: from 2 rows (M = 8: 17.1 -> 12.7 us)
+    (dict(M=32, N=4096, K=11008), "gemm_w4_rows_kernel<32x16>"),
+    (dict(M=48, N=4096, K=11008), "gemm_w4_mma_kernel<64x128>"),  # past the x re-read budget (176 MB): tile kernel
+    (dict(M=16, N=4096, K=14336), "gemm_wn_direct_kernel<tile32>"),   # K > 12288: weights only two chunks ahead: the round-3 kernels
+    (dict(M=16, N=6144, K=4096), "gemm_wn_direct_kernel<tile32>"),    # more blocks than CUs (one 146-KB block per CU): two rounds lose
+    (dict(M=9, tuning=(9, 0, 0, 0), N=8192, K=8192), "gemm_w4_rows_kernel<16x16>"),   # tuning[0] = 9 forces it
+    (dict(M=200, tuning=(9, 0, 0, 0)), "gemm_w4_rows_kernel<64x16>"),                   # ... at any M: 64-row blocks along grid.y
+    (dict(M=4, gs=32, N=8192, K=8192), "gemm_w4_rows_kernel<16x16>"),   # groups of 32 at M >= 2: nothing but the coverage kernel behind it on shapes the streaming kernel refuses
+    (dict(M=300, gs=32), "gemm_w4_rows_kernel<32x16>"),                 # ... any M (32-row blocks along grid.y)
+    (dict(M=40, N=4112, K=4096), "gemm_w4_rows_kernel<48x16>"),         # N % 64 != 0 (N % 16 == 0)
     (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile64,8w>"),   # ... 64-column tiles x 2 where they still fill the chip
     (dict(M=8, N=6144, K=4096), "gemm_wn_direct_kernel<tile32>"),      # 192 blocks of 32 columns, unsplit: 4 waves
-    (dict(M=8, tuning=(0, 0, 4, 0)), "gemm_wn_direct_kernel<tile32>"),   # tuning[2] = 4 / 8: waves per block
+    (dict(M=6, tuning=(0, 0, 4, 0)), "gemm_wn_direct_kernel<tile32>"),   # tuning[2] = 4 / 8: waves per block
     (dict(M=7), "gemm_wn_direct_kernel<tile32,8w>"),   # ... from 5 rows (M = 6: 7.7 -> 6.5 us)
     (dict(M=5, N=8192, K=8192), "gemm_wn_direct_kernel<tile64,8w>"),
     (dict(M=16, N=16384, K=16384), "gemm_wn_direct_kernel<tile64>"),
     (dict(M=24, N=16384, K=16384), "gemm_w4_mma_kernel<32x128>"),   # 17..32 rows over K >= 8192: LDS-staged x wins
-    (dict(M=8, tuning=(0, 0, 1, 0)), "gemm_wn_stream_kernel"),  # tuning[2] = 1: LDS-staged streaming kernel
+    (dict(M=6, tuning=(0, 0, 1, 0)), "gemm_wn_stream_kernel"),  # tuning[2] = 1: LDS-staged streaming kernel
     (dict(M=4, gs=64), "gemv_mfma_kernel<tile16,rows4>"),
-    (dict(M=8, gs=64), "gemm_wn_direct_kernel<tile32>"),   # group size 64: registers-only kernel up to 16 rows
-    (dict(M=24, gs=64), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32
-    (dict(M=4, gs=32), "gemm_wn_stream_kernel"),
-    (dict(M=48), "gemm_w4_mma_kernel<64x64>"),       # from 33 rows: the 8-wave MFMA kernel; 4096^2: 32-row tiles x 4 slices (15.8 us vs 16.4)  [round 4, late: narrow 64 x 64 tiles]
+    (dict(M=6, gs=64), "gemm_wn_direct_kernel<tile32>"),   # group size 64: registers-only kernel up to 16 rows (round 5: 2 .. 7 at 4096^2)
+    (dict(M=8, gs=64), "gemm_w4_rows_kernel<16x16>"),
+    (dict(M=24, gs=64, tuning=(0, 0, 0, 65536)), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32 (the round-4 choice)
+    (dict(M=24, gs=64), "gemm_w4_rows_kernel<32x16>"),
+    (dict(M=4, gs=32, tuning=(0, 0, 0, 65536)), "gemm_wn_stream_kernel"),
+    (dict(M=4, gs=32), "gemm_w4_rows_kernel<16x16>"),
+    (dict(M=48, tuning=(0, 0, 0, 65536)), "gemm_w4_mma_kernel<64x64>"),       # (the round-4 choice) from 33 rows: the 8-wave MFMA kernel; 4096^2: 32-row tiles x 4 slices (15.8 us vs 16.4)  [round 4, late: narrow 64 x 64 tiles]
     (dict(M=48, N=11008, K=4096), "gemm_w4_mma_kernel<64x64>"),   # round 4: one row tile, 172 column tiles: unsplit 64 x 64 tiles (18.0 -> 16.5 us)
     (dict(M=48, N=11008, K=4096, tuning=(0, 0, 0, 16384)), "gemm_w4_mma_kernel<64x128>"),
     (dict(M=8, N=11008, K=4096), "gemm_wn_direct_kernel<tile64>"),   # wide N: 64-column tiles, K not split
-    (dict(M=48, mt=3), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK at 33..64 rows: LDS-staged streaming kernel
+    (dict(M=48, mt=3, tuning=(0, 0, 0, 65536)), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK at 33..64 rows: LDS-staged streaming kernel (the round-4 choice)
+    (dict(M=48, mt=3), "gemm_w4_rows_kernel<48x16>"),      # round 5: the rows kernel IS the GEMM_SPLITK family's kernel at 4096^2
     (dict(M=48, nbits=2), "gemm_w2_mma_kernel<64x64>"),   # every bit width has the tiled MFMA kernel  [round 4, late: narrow 64 x 64 tiles]
     (dict(M=48, nbits=1), "gemm_w1_mma_kernel<64x128>"),
     (dict(M=200, nbits=8), "gemm_w8_mma_kernel<64x128>"),   # tallest tile with >= 128 tiles: at most two K slices
     (dict(M=48, tuning=(1, 0, 0, 0)), "gemm_wn_stream_kernel"),          # tuning[0] = 1: LDS-staged streaming kernel
     (dict(M=48, tuning=(2, 0, 0, 0)), "gemm_w4_tiled_kernel<128x128>"),  # tuning[0] = 2: the 4-wave kernel of round 1
-    (dict(M=48, gs=32), "gemm_wn_stream_kernel"),     # group size 32: two groups per 64-k sub-block
+    (dict(M=48, gs=32, tuning=(0, 0, 0, 65536)), "gemm_wn_stream_kernel"),     # group size 32: two groups per 64-k sub-block (the round-4 choice)
+    (dict(M=48, gs=32), "gemm_w4_rows_kernel<32x16>"),
     # K = 11008 / 8960 (Llama-2-7B down_proj, Qwen2.5-1.5B): specialised kernels at every M, never the coverage kernel
     (dict(M=1, N=4096, K=11008), "gemv_w4_decode3_kernel<tile16,16w>"),
     (dict(M=1, N=4096, K=11008, gs=64), "gemv_w4_decode3_kernel<tile16,16w>"),
@@ -131,9 +154,9 @@ def test_struct_abi_and_validation():
     (dict(M=1, N=8960, K=1536), "gemv_mfma_kernel<tile64>"),
     (dict(M=1, N=8192, K=28672), "gemv_wn_kernel<tile64>"),             # long K over a narrow N: 64-column tiles x 2 K slices (23.1 vs 25.8 us)
     (dict(M=1, N=4096, K=14336), "gemv_wn_kernel<tile64>"),
-    (dict(M=4, N=4096, K=11008), "gemv_mfma_kernel<tile16,rows4>"),
-    (dict(M=8, N=4096, K=11008), "gemm_w4_mma_kernel<32x128>"),
-    (dict(M=32, N=4096, K=11008, gs=64), "gemm_w4_mma_kernel<32x128>"),
+    (dict(M=4, N=4096, K=11008), "gemm_w4_rows_kernel<16x16>"),   # round 5 (13.0 -> 12.3 us)
+    (dict(M=8, N=4096, K=11008, tuning=(0, 0, 0, 65536)), "gemm_w4_mma_kernel<32x128>"),
+    (dict(M=32, N=4096, K=11008, gs=64, tuning=(0, 0, 0, 65536)), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=16, N=1536, K=8960), "gemm_w4_mma_kernel<32x128>"),
     (dict(M=64, N=4096, K=11008), "gemm_w4_mma_kernel<64x128>"),
     (dict(M=8, N=4864, K=896), "gemm_w4_mma_kernel<128x128>"),   # K = 128 * 7 (Qwen2.5-0.5B): only the 128-k-step tiles divide it
@@ -145,7 +168,7 @@ def test_struct_abi_and_validation():
     (dict(M=1, N=11008, K=4096, tuning=(0, 0, 0, 512)), "gemv_wn_kernel<tile64>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64,8w>"),   # 2-bit, long K: two waves per SIMD
-    (dict(M=16), "gemm_wn_direct_kernel<tile32,8w>"),
+    (dict(M=16, tuning=(0, 0, 0, 65536)), "gemm_wn_direct_kernel<tile32,8w>"),
     (dict(M=1, mt=4), "gemm_w4_mma_kernel<32x128>"),   # manual GEMM family at M=1 -> the tiled MFMA kernel
     (dict(M=128), "gemm_w4_mma_kernel<64x64>"),        # round 4: 128 narrow tiles x 2 K slices (15.4 -> 13.7 us)
     (dict(M=256), "gemm_w4_mma_kernel<64x64>"),        # cfgA: 256 narrow tiles, K UNSPLIT: no slab + ticket combine (19.8 -> 16.8 us)

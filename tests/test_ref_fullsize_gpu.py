@@ -75,12 +75,15 @@ def test_fixture_is_the_reference_run_recorded_in_profiles():
 # tests/golden/fullsize_ref_r4.npz = `python oracle/run_ref_gpu.py --which ref --only r4 --fixture fullsize_ref_r4.npz` on an MI355X
 # (timings: profiles/r04/reference_triton_mi355x_r4.json).  Bounds: the reference's GEMV / GEMM_SPLITK families accumulate (fp16
 # inputs) or round partial sums (bf16 outputs through atomics) in 16 bits — measured distance of the fp32-accumulating HIP kernels
-# 2e-4 (fp16) / 1.7e-3 (bf16) at 2 .. 8 rows, 4.4e-3 at bf16 M = 1; 64 rows is the MFMA tile kernel on both sides (3e-7).
+# 2e-4 (fp16) / 1.7e-3 (bf16) at 2 .. 8 rows, 4.4e-3 at bf16 M = 1; 64 rows was the MFMA tile kernel on both sides in round 4 (3e-7).
 GOLD_R4 = os.path.join(ROOT, "tests", "golden", "fullsize_ref_r4.npz")
 BOUNDS_R4 = {
     "cfgA_bf16_m1": 9e-3, "a16w2_16384_bf16_m1": 9e-3,
     **{f"cfgA_fp16_m{m}": 1e-3 for m in (2, 4, 8)}, **{f"cfgA_bf16_m{m}": 4e-3 for m in (2, 4, 8)},
-    "cfgA_fp16_m64": 1e-4, "cfgA_bf16_m64": 1e-4,
+    # round 5: 64 rows run on gemm_w4_rows_kernel, which — like the 2 .. 32-row kernels — multiplies RAW integer codes and applies scale / zero
+    # to the fp32 group sums instead of rounding every dequantised weight to 16 bits as the reference's GEMM family does: ~2^-12 (fp16) /
+    # ~2^-9 (bf16) of mean |y| away from the reference, and closer to the float64 oracle (tests/test_gpu_parity.py)
+    "cfgA_fp16_m64": 1e-3, "cfgA_bf16_m64": 4e-3,
     "a8w4_fp8dyn_m1": 9e-3, "a8w4_fp8dyn_m16": 9e-3, "a8w4_fp8dyn_m256": 9e-3,
 }
 
