@@ -510,10 +510,10 @@ def main():
     full = {}  # verbose blocks (--full-out); the printed line carries their compact form inside `roofline`
     if extras:
         def compact(b):
-            c = {k: b[k] for k in ("kernel", "kernel_us", "achieved", "unit", "frac") if k in b}
-            c["traffic"] = b.get("traffic")
+            c = {"kernel": b.get("kernel"), "kernel_us": b.get("kernel_us"), "frac": b.get("frac"), "traffic": b.get("traffic")}
             if b.get("bound") == "mfma":
-                c["mfma_util"] = b.get("mfma_util")
+                mu = b.get("mfma_util")
+                c["mfma_util"] = mu.get("mfma_busy") if isinstance(mu, dict) else mu
             return c
 
         def block(wname, nl=None, samples=0, e2e=False):
@@ -542,12 +542,14 @@ def main():
                 roof[key] = {"error": f"{type(e).__name__}: {e}"[:160]}
                 print(f"[bench] block {key} failed: {type(e).__name__}: {e}", file=sys.stderr)
 
-        # the M=256 half of the headline metric, same process, bf16 — FIRST, right behind the headline
-        guarded("m256", lambda: {"cfgA_4096": block("a16w4_4096_m256", samples=64), "cfgB_8192": block("a16w4_8192_m256", samples=32)})
-        # SURVEY §8(d) config 2 is "fp16 + bf16": the bf16 twin of the headline
-        guarded("m1_bf16", lambda: {"a16w4_4096_m1_bf16": block("a16w4_4096_m1_bf16")})
-        # decode-batch sizes of the headline layer (row a9: 2 <= M <= 64), layer(x) in fp16
-        guarded("fewrows", lambda: {f"a16w4_4096_m{m}": block(f"a16w4_4096_m{m}") for m in (16, 32, 64)})
+        # Order of the groups = reverse order of importance: the driver keeps the TAIL of the printed line, so the bulky side groups go
+        # first and the two halves of BASELINE's metric (the M = 1 core fields and `m256`) are re-appended at the very end of `roofline`.
+        # block-scaled formats at decode-batch sizes (few-row scaled-MFMA kernel; NVFP4 on the fp16 tile kernel) and at M = 256 (unsplit
+        # 64 x 64 scaled-MFMA tiles): matmul on pre-quantised x and layer(x) with the activation quantiser
+        guarded("mx_fewrows", lambda: {**{w: block(w) for w in ("mx_a8w8_4096_m16", "mx_a4w4_4096_m16", "nvfp4_4096_m16", "nvfp4_4096_m256")},
+                                       **{w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a4w4_4096_m16", "nvfp4_4096_m16")}})
+        guarded("mx_m256", lambda: {**{w: block(w) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")},
+                                    **{w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")}})
         # BASELINE configs[3]: A8W8 int8 channel-wise 4096^2, M in {1, 16, 256}: the matmul alone on a pre-quantised x, and
         # (`*_layer_e2e`) layer(x) as the product runs it, dynamic activation quantisation included
         guarded("cfg4", lambda: {**{f"a8w8_int8_4096_m{m}": block(f"a8w8_4096_m{m}") for m in (1, 16, 256)},
@@ -560,12 +562,12 @@ def main():
         # the large-M end of the same kernel family (north star: "tiled GEMM for large-M prefill") and the GEMV family on larger layers
         guarded("prefill_m2048", lambda: {"a16w4_8192_m2048": block("a16w4_8192_m2048", 4)})
         guarded("trend_m1", lambda: {"8192": block("a16w4_8192_m1"), "16384": block("a16w4_16384_m1")})
-        # block-scaled formats at decode-batch sizes (few-row scaled-MFMA kernel; NVFP4 on the fp16 tile kernel) and at M = 256 (unsplit
-        # 64 x 64 scaled-MFMA tiles): matmul on pre-quantised x and layer(x) with the activation quantiser
-        guarded("mx_fewrows", lambda: {**{w: block(w) for w in ("mx_a8w8_4096_m16", "mx_a4w4_4096_m16", "nvfp4_4096_m16", "nvfp4_4096_m256")},
-                                       **{w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a4w4_4096_m16", "nvfp4_4096_m16")}})
-        guarded("mx_m256", lambda: {**{w: block(w) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")},
-                                    **{w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")}})
+        # SURVEY §8(d) config 2 is "fp16 + bf16": the bf16 twin of the headline
+        guarded("m1_bf16", lambda: {"a16w4_4096_m1_bf16": block("a16w4_4096_m1_bf16")})
+        # decode-batch sizes of the headline layer (row a9: 2 <= M <= 64), layer(x) in fp16
+        guarded("fewrows", lambda: {f"a16w4_4096_m{m}": block(f"a16w4_4096_m{m}") for m in (16, 32, 64)})
+        # the M=256 half of the headline metric, same process, bf16
+        guarded("m256", lambda: {"cfgA_4096": block("a16w4_4096_m256", samples=64), "cfgB_8192": block("a16w4_8192_m256", samples=32)})
         try:
             # the rotation size does not carry the headline: the same step over 32 layers (286 MB, rounds 1-3) and 64 (572 MB)
             r32 = block("a16w4_4096_m1", 32)
@@ -579,6 +581,11 @@ def main():
             full["sustained"] = dict(roof["sustained"], launches=nl, unit="GB/s")
         except Exception as e:
             print(f"[bench] eager / sustained legs failed: {type(e).__name__}: {e}", file=sys.stderr)
+        # the M = 256 half and the M = 1 core fields go to the END of `roofline` (dicts keep insertion order)
+        for k in ("fewrows", "m256", "bound", "kernel", "kernel_us", "achieved", "peak", "unit", "frac", "empty_launch_us",
+                  "kernel_us_minus_empty_launch", "traffic"):
+            if k in roof:
+                roof[k] = roof.pop(k)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.torch_cpu_path import time_cpu_baseline
@@ -588,11 +595,12 @@ def main():
         mm = r["matmul_only_sec"]
         line["cpu_baseline"] = {
             "value": round(cpu_val, 5), "unit": unit, "cores": r["threads"], "kind": "port",
-            "sample": f"{r['calls']} calls unpack+dequant+matmul torch-CPU fp32, one {N}x{K} layer M={M}, {sec * 1e3:.1f} ms/call",
-            "host_cpus": r["host_cpus"],
-            "thread_sweep_ms": {str(k): round(v * 1e3, 2) for k, v in r["sweep"].items()},
-            "matmul_only": {"ms_per_call": round(mm * 1e3, 3), "threads": r["matmul_only_threads"],
-                            "note": "x @ W.T on the pre-dequantised fp32 W (64 MiB read per call)"}}
+            "sample": f"{r['calls']} calls unpack+dequant+matmul torch-CPU fp32, one {N}x{K} layer M={M}, {sec * 1e3:.1f} ms/call"}
+        full["cpu_baseline"] = dict(line["cpu_baseline"], host_cpus=r["host_cpus"],
+                                    thread_sweep_ms={str(k): round(v * 1e3, 2) for k, v in r["sweep"].items()},
+                                    matmul_only={"ms_per_call": round(mm * 1e3, 3), "threads": r["matmul_only_threads"],
+                                                 "note": "x @ W.T on the pre-dequantised fp32 W (64 MiB read per call)"})
+    line["roofline"] = line.pop("roofline")  # last key of the line: its tail (fewrows, m256, the M = 1 core) is what a truncated record keeps
     if rank == 0:
         if args.full_out:
             with open(args.full_out, "w") as f:
