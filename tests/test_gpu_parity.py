@@ -1601,11 +1601,13 @@ def test_rows5_kernel_all_modes(zeros_kind, fma, scales_kind, tdt):
         _compare(f"rows5-modes/{zeros_kind}-{fma}-{scales_kind}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x), lin.output_dtype.value)
 
 
-@pytest.mark.parametrize("N,K,gs", [(4096, 4096, 128), (1040, 2816, 128), (512, 256, 128), (2064, 11008, 64), (1024, 8192, 32)])
+@pytest.mark.parametrize("N,K,gs", [(4096, 4096, 128), (1040, 2816, 128), (512, 256, 128), (2064, 11008, 64), (1024, 8192, 32),
+                                    (8192, 4096, 128), (6160, 2048, 64), (11008, 4096, 128), (4352, 11008, 128)])
 def test_rows5_kernel_shapes_strides_and_defaults(N, K, gs):
-    """Shapes: the headline layer, N % 64 != 0 with K = 11 chunks, a single chunk (15 of 16 waves idle), K = 11008 (43 chunks), two chunks
-    per wave; a strided x (rows of a wider buffer); the kernel agrees with the round-4 kernels within both tolerances; and what the planner
-    does by default: the rows kernel inside its budget, for groups of 32 and for N % 64 != 0 at any M >= 2."""
+    """Shapes: the headline layer, N % 64 != 0 with K = 11 chunks, a single chunk (7 of 8 waves idle), K = 11008 (43 chunks: 5 or 6 per wave),
+    four chunks per wave; more tiles than CUs (512 / 385 / 688 / 272 blocks); a strided x (rows of a wider buffer); the kernel agrees with the round-4
+    kernels within both tolerances; and what the planner does by default: the rows kernel inside its budget, for groups of 32 and for
+    N % 64 != 0 at any M >= 2."""
     from gemlite_amd.core import _hip_matmul
     tdt = torch.float16
     lin = _make_layer(N, K, 4, gs, tdt, seed=N % 13)
