@@ -49,6 +49,7 @@ const void* a16w8_decode_kernel_fn(int x_dt, int w_dt);
 const void* act_quant_kernel_fn();
 const void* act_quant_vec_kernel_fn(int in_dt, int out_dt, int64_t K, int64_t stride_xm, const void* x, const void* y);
 const void* pack_kernel_fn();
+const void* pack32_kernel_fn();
 const void* unpack_kernel_fn();
 
 }  // namespace gl
@@ -955,6 +956,10 @@ int gemlite_hip_pack_over_cols(const uint8_t* w_q, void* out, int64_t N, int64_t
     if (c != GEMLITE_OK) return c;
     const int64_t total = (K / (pack_bits / W_nbits)) * N;
     int nb = W_nbits, pb = pack_bits;
+    if (pack_bits == 32 && K % (32 / W_nbits) == 0 && (N + 63) / 64 <= 0x7FFFFFFF && (K + 255) / 256 <= 65535) {  // tiled through LDS: coalesced both ways
+        void* targs[] = {(void*)&w_q, (void*)&out, (void*)&N, (void*)&K, (void*)&ld_in, (void*)&nb};
+        return launch(pack32_kernel_fn(), dim3((unsigned)((N + 63) / 64), (unsigned)((K + 255) / 256), 1), dim3(256, 1, 1), targs, 0, (hipStream_t)stream);
+    }
     void* kargs[] = {(void*)&w_q, (void*)&out, (void*)&N, (void*)&K, (void*)&ld_in, (void*)&nb, (void*)&pb};
     return launch(pack_kernel_fn(), dim3((unsigned)((total + 255) / 256), 1, 1), dim3(256, 1, 1), kargs, 0, (hipStream_t)stream);
 }

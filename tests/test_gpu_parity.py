@@ -326,6 +326,12 @@ def test_gpu_pack_unpack_bit_exact(nbits, pb):
     assert np.array_equal(gpu.cpu().numpy(), O.pack_over_cols(W.numpy(), nbits, pb))
     back = bitpack.unpack_over_cols(gpu.t().contiguous(), nbits, 4096)
     assert torch.equal(back.cpu(), W)
+    # round 5 (the tiled 32-bit pack kernel): ragged N and K (not multiples of its 64 x 256 tile) and a strided, unaligned view as the source
+    Wr = torch.randint(0, 2 ** nbits, (1000, 2080 + 40), generator=g, dtype=torch.int32).to(torch.uint8)
+    for view in (Wr[:, :2080].contiguous(), Wr[:, 3:3 + 2080]):
+        cpu_r, _ = bitpack.pack_weights_over_cols(view.contiguous(), nbits, pb, True)
+        gpu_r, _ = bitpack.pack_weights_over_cols(Wr.to(DEV)[:, 3:3 + 2080] if not view.is_contiguous() else view.to(DEV), nbits, pb, True)
+        assert torch.equal(gpu_r.cpu(), cpu_r.contiguous()), (nbits, pb, view.is_contiguous())
 
 
 # ------------------------------------------------------ properties at full size (size-independent)
