@@ -89,6 +89,9 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
     constexpr int RPI = 64 / PPR;                             // rows per LDS-DMA instruction (1 KiB)
     constexpr int DPI = 16 * MT / RPI;                        // LDS-DMA instructions per piece
     constexpr int NWM = 2 + 2 * NML;                          // requests of one chunk's weights + metadata
+    constexpr int NS = 2;                                     // weight register sets = chunks the weight requests run ahead.  (4 sets — 64 KB per CU in
+                                                              // flight like the decode kernel — measured SLOWER: a wave's requests return in order, so every
+                                                              // x piece then waits behind more HBM round trips; 4096 x 8192 M = 8: 9.4 -> 10.7 us)
     static_assert(NG >= 2 && DPI * 1024 <= XBUF && (WSLOT_I1 + 256) * 4 <= WSLOT_BYTES && MT * 1024 <= XBUF, "LDS layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -183,8 +186,9 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
 
     // One chunk.  CPAR = chunk parity (which of the two register sets and — for one piece per chunk — which x buffer).  Request queue of the
     // wave, oldest first:
-    //     W(0) X(0) W(1) X(1) | end of piece i:  [W(c + 2) if i closed chunk c]  X(i + 2)            (each only if it exists)
-    // so behind X(i) sit [W(c + 1) if i opens chunk c and chunk c + 1 exists] and [X(i + 1) if it exists].
+    //     W(0) X(0) W(1) X(1) | end of piece i:  X(i + 2)  [W(c + 2) if i closed chunk c]            (each only if it exists)
+    // so behind X(i) sit [X(i + 1)] and [W(c + 1) if i opens chunk c] — x first: a wave's requests return in order, and a piece
+    // must not wait behind the HBM round trip of the weights requested with it (4096 x 11008, M = 8: 12.7 -> 11.4 us).
     auto chunk = [&](WSet& S, int ch, auto cpar) {
         constexpr int CPAR = decltype(cpar)::value;
         uint32_t bw[8];
@@ -238,20 +242,24 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
             }
             // the buffer is free once this wave's reads of it have returned; then the requests two pieces / two chunks ahead
             wait_lgkm0();
-            if (pi == NP - 1 && ch + 2 < nchunks) issue_w(S, ch + 2);
             if (i + 2 < npieces) issue_x(i + 2, par);
+            if (pi == NP - 1 && ch + NS < nchunks) issue_w(S, ch + NS);
         }
     };
 
-    WSet A, B;
-    if (nchunks > 0) issue_w(A, 0);
+    WSet W[NS];
+    if (nchunks > 0) issue_w(W[0], 0);
     if (npieces > 0) issue_x(0, 0);
-    if (nchunks > 1) issue_w(B, 1);
+    if (nchunks > 1) issue_w(W[1], 1);
     if (npieces > 1) issue_x(1, 1);
 #pragma unroll 1
-    for (int ch = 0; ch < nchunks; ch += 2) {
-        chunk(A, ch, std::integral_constant<int, 0>{});
-        if (ch + 1 < nchunks) chunk(B, ch + 1, std::integral_constant<int, 1>{});
+    for (int ch = 0; ch < nchunks; ch += NS) {
+        chunk(W[0], ch, std::integral_constant<int, 0>{});
+        if (ch + 1 < nchunks) chunk(W[1], ch + 1, std::integral_constant<int, 1>{});
+        if constexpr (NS == 4) {
+            if (ch + 2 < nchunks) chunk(W[2], ch + 2, std::integral_constant<int, 0>{});
+            if (ch + 3 < nchunks) chunk(W[3], ch + 3, std::integral_constant<int, 1>{});
+        }
     }
 
     // ---- the 8 waves (disjoint K) meet in LDS: [MT][16 rows][16 columns] fp32 at the start of each wave's region; C layout: column j,

@@ -76,6 +76,25 @@ def replay(lines, seq, weakest_of_alternatives=False):
             dest, srcs = set(), touched
         inflight = set().union(*queue) if queue else set()
         clash = (srcs | dest) & inflight if vmem and "load" in op else touched & inflight
+        if clash and op == "v_mad_u64_u32":
+            # hipcc uses v_mad_u64_u32 for 32-bit multiply-adds and leaves the HIGH half of the 64-bit addend undefined — any register,
+            # in-flight ones included.  That half only reaches the high half of the result: not a read of the loaded value if the high
+            # result register is overwritten before anything reads it.
+            m3 = re.match(r"v_mad_u64_u32 v\[(\d+):(\d+)\], [^,]+, [^,]+, [^,]+, v\[(\d+):(\d+)\]", t)
+            if m3 and clash == {int(m3.group(4))}:
+                hi = int(m3.group(2))
+                dead = True  # (not read within the next 200 instructions counts as dead)
+                for nxt in seq[pos + 1:pos + 200]:
+                    t2 = lines[nxt][1]
+                    ops2 = t2.split(None, 1)[1] if " " in t2 else ""
+                    parts = ops2.split(",")
+                    if hi in regs_of(",".join(parts[1:])) or (t2.split()[0].startswith(("buffer_store", "global_store", "ds_write", "scratch_store")) and hi in regs_of(ops2)):
+                        dead = False  # read first
+                        break
+                    if hi in regs_of(parts[0]):
+                        break  # overwritten first
+                if dead:
+                    clash = set()
         if clash:
             bad.append((a, t, sorted(clash)))
         if vmem and "atomic" not in op or (vmem and "atomic" in op):
