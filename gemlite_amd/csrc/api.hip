@@ -328,14 +328,14 @@ static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
 //     M = 48 19.9 -> 21.5; 4096 x 8192 M = 64, 256 MB: 18.3 -> 19.0);
 //   * weights are requested two chunks (2 KB per wave) ahead: enough for K <= 12288, not for K = 14336 (M = 16: 14.6 -> 16.3);
 //   * from how many rows: K <= 2048 from 2 (4096 x 1024 / x 2048, M = 2: 5.0 / 5.1 -> 3.7 / 4.4); K <= 4096 from 8 (2 .. 7 rows are a
-//     draw with the MFMA GEMV / the registers-only kernel: 6.2 - 6.9 vs 6.3 - 6.5); longer K from 16 (4096 x 8192, M = 8: 9.2 -> 10.1
-//     but M = 32: 15.6 -> 13.7) — unless the registers-only kernel does not take K (K % 2048 != 0: 4096 x 11008 M = 2 / 8 / 16:
-//     12.9 / 17.1 / 17.3 -> 12.0 / 12.7 / 13.1).
+//     draw with the MFMA GEMV / the registers-only kernel: 6.2 - 6.9 vs 6.1 - 6.5); longer K from 2 again since the x pieces are requested
+//     ahead of the weights (probe_rows5_v2b*.log: 4096 x 8192 M = 2 / 8 / 16 / 32: 10.1 / 9.3 / 10.5 / 15.6 -> 8.8 / 9.4 / 10.2 / 13.0;
+//     4096 x 11008: 12.8 / 17.0 / 17.1 / 17.8 -> 10.5 / 11.4 / 12.3 / 16.7; 3072 x 8192: 9.0 / 11.2 / 14.0 / 15.3 -> 8.7 / 9.4 / 10.1 / 12.8).
 static bool rows5_pays(int64_t M, int64_t N, int64_t K) {
     if (M < 2 || M > 64 || N % 16 != 0 || K > 12288) return false;
     const int64_t tiles = N / 16;
     if (tiles > gl::resident_block_limit() || tiles < ((M >= 16 && M <= 32) ? 128 : 192)) return false;  // (2048 x 8192: M = 16 / 32 win, M = 64 loses)
-    const int64_t min_m = K <= 2048 ? 2 : (K <= 4096 ? 8 : (K % 2048 != 0 ? 2 : 16));
+    const int64_t min_m = (K > 2048 && K <= 4096) ? 8 : 2;
     if (M < min_m) return false;
     return tiles * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
 }
