@@ -28,6 +28,7 @@ bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, Lau
 bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq = false);
 bool plan_a16w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
+bool plan_gemm_a8w8_sq128(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
 bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
@@ -340,6 +341,16 @@ static bool rows5_pays(int64_t M, int64_t N, int64_t K) {
     return tiles * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
 }
 
+// When the unsplit 128 x 128 A8W8 tiles are the default (profiles/r05/probe_a8w8_sq128.log): more than 64 rows, and the 128 x 128 tiles
+// number 192 .. 256 — one round with most CUs busy (FP8 16384^2 M = 256: 95.8 vs 98.5 us; int8 8192^2 M = 512: 47.0 vs 52.7;
+// 4096^2 M = 1024: 27.5 vs 32.2; 14336 x 4096 M = 256: 29.0 vs 31.1).  Fewer tiles (8192^2 M = 256: 44.5 vs 36.1 us) and several rounds
+// (8192^2 M = 1024: 89.8 vs 76.3) stay on the 128- / 256-row tiles with K slices.
+static bool a8w8_sq128_pays(const gemlite_hip_forward_args& a) {
+    if (a.M <= 64 || a.N % 128 != 0 || a.K < 4096) return false;
+    const int64_t tiles = (a.N / 128) * ((a.M + 127) / 128);
+    return tiles >= 192 && tiles <= gl::resident_block_limit();
+}
+
 static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
     r.status = validate(&a);
     if (r.status != GEMLITE_OK) return;
@@ -588,6 +599,14 @@ coverage:
         a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
         a.matmul_type != GEMLITE_MATMUL_GEMV_REVSPLITK && plan_a8w8_rows(a, r.lp)) {
         r.kind = K_KMAJOR;  // GenericParams, no workspace
+        return;
+    }
+    // A8W8 (int8 / fp8), round 5: 128 x 128 tiles with K unsplit where THEY number about one per CU (FP8 x FP8 16384^2 at M = 256: 256 tiles) —
+    // tuning[0] = 10 forces them, tuning[0] = 6 keeps the round-3 choice
+    if (!packed && a.matmul_type != GEMLITE_MATMUL_GEMV && a.matmul_type != GEMLITE_MATMUL_GEMV_SPLITK &&
+        a.matmul_type != GEMLITE_MATMUL_GEMV_REVSPLITK &&
+        (a.tuning[0] == 10 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 64) && a8w8_sq128_pays(a))) && plan_gemm_a8w8_sq128(a, r.gp, r.lp)) {
+        r.kind = K_A8_MMA;
         return;
     }
     // A8W8 (int8 / fp8), round 4: 64 x 64 tiles with K unsplit where they fill the chip about once (config 4 at M = 256: 256 tiles) —

@@ -758,6 +758,226 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
     }
 }
 
+// Round 5: 128 x 128 tiles, K NOT split ("gemm_a8w8_sq_kernel<128x128>") — the same structure for layers whose 128 x 128 tiles number
+// about one per CU (FP8 x FP8 16384^2 at M = 256, BASELINE configs[4]: 2 x 128 = 256 tiles; int8 8192^2 at M = 512; 4096^2 at M = 1024).
+// A wave owns a 64 x 64 block = 2 x 2 MFMA blocks (two A and two B fragments feed FOUR MFMAs: half the LDS reads per MFMA of the
+// 64 x 64 tiles), 8 waves = 2 x 2 wave tiles x 2 K halves of every step, NST stages of [128 x rows | 128 weight rows] x KSTEP bytes with
+// NST - 1 of them in flight.  Measured (profiles/r05/probe_a8w8_sq128.log): two 64-KB stages of 256-byte steps (ONE in flight: every step
+// pays the fill latency) 105 us on configs[4] at M = 256; four 32-KB stages of 128-byte steps 95.8 us (five: the same) against 98.5 us of
+// gemm_a8w8_lds_kernel<256x128> with two K slices — all of them at the operand-fill rate the CUs reach when a quarter .. half of the
+// stream comes from HBM (scripts/ubench/ldsfill.hip: 23 GB/s per CU for bytes read once, 105 GB/s for L2-resident ones, and the two
+// ADD: 1 MB of weights + 2 .. 3 MB of re-read operands per CU = 62 .. 72 us before any arithmetic); 10 - 15 % ahead of the K-sliced
+// tiles on the one-round shapes above.
+template <int DT, int KSTEP, int NST>
+__global__ __launch_bounds__(512, 2) void gemm_a8w8_sq128_kernel(const GenericParams p) {
+    using namespace async;
+    using AC = A8Acc<DT>;
+    typedef typename AC::T acc_t;
+    constexpr bool INT = DT == GEMLITE_DT_INT8;
+    constexpr int BM = 128, BN = 128, PITCH = KSTEP, KW = KSTEP / 2, NS = KW / 32;
+    constexpr int STAGE = (BM + BN) * PITCH;               // x rows, then weight rows: 64 KB (256-byte steps) / 32 KB (128-byte steps)
+    constexpr int PX = BM * PITCH / 1024 / 8, PW = BN * PITCH / 1024 / 8, PT = PX + PW;  // DMA pieces per wave and stage
+    static_assert((KSTEP == 256 || KSTEP == 128) && NST >= 2 && NST * STAGE <= 160 * 1024, "two 64-KB or up to five 32-KB stages");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST][STAGE], later the epilogue tiles
+    // 16-byte slots XOR-swizzled through the source address: key row & 15 (256-byte rows) / (row >> 1) & 7 (128-byte rows)
+    auto key = [](int r) { return KSTEP == 256 ? (r & 15) : ((r >> 1) & 7); };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = (wave >> 1) & 1, cb = wave & 1, kh = wave >> 2;  // 64 x 64 wave tile (rb, cb), K half kh
+    const int col = lane & 31, h = lane >> 5;
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = p.N / BN;
+    int mt, nt;
+    {
+        const int lin = blockIdx.x;
+        if ((ntiles & 7) == 0) {  // the row tiles of one weight column tile on one XCD, back to back in its dispatch order
+            const int xcd = lin & 7, idx = lin >> 3;
+            mt = idx % mtiles;
+            nt = (idx / mtiles) * 8 + xcd;
+        } else {
+            mt = lin % mtiles;
+            nt = lin / mtiles;
+        }
+    }
+    const int m0 = mt * BM;
+    const int nsteps = p.K / KSTEP;
+
+    const srd_t rsX = make_srd(p.x, (uint32_t)((int64_t)(p.M - 1) * p.stride_xm + p.K));
+    const srd_t rsW = make_srd(p.w, (uint32_t)((int64_t)(p.N - 1) * p.stride_wn + p.K));
+    // piece j of wave w covers LDS bytes [(w * P + j) * 1024, +1024) of its region: row = byte / PITCH, physical 16-byte slot
+    // (byte % PITCH) / 16 holds the logical slot phys ^ key(row)
+    uint32_t xvoff[PX], wvoff[PW];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int byte = (wave * PX + j) * 1024 + lane * 16;
+        const int r = byte / PITCH, phys = (byte % PITCH) / 16;
+        const int logical = phys ^ key(r);
+        xvoff[j] = m0 + r < p.M ? (uint32_t)((int64_t)(m0 + r) * p.stride_xm + logical * 16) : 0x80000000u;  // rows >= M: zeros
+    }
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int byte = (wave * PW + j) * 1024 + lane * 16;
+        const int r = byte / PITCH, phys = (byte % PITCH) / 16;
+        const int logical = phys ^ key(r);
+        wvoff[j] = (uint32_t)((int64_t)(nt * BN + r) * p.stride_wn + logical * 16);
+    }
+    const uint32_t ldsx = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PX) * 1024u);
+    const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(BM * PITCH) + (uint32_t)(wave * PW) * 1024u);
+    auto request = [&](int stage, int step) __attribute__((always_inline)) {
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], so);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) req_lds16(rsW, ldsw + (uint32_t)(stage * STAGE + j * 1024), wvoff[j], so);
+    };
+    // fragments of slice g (32 k) of MFMA block mi / ni: A row rb * 64 + mi * 32 + col, B weight row cb * 64 + ni * 32 + col, both at byte
+    // kh * KW + g * 32 + h * 16 (the swizzle key does not depend on mi / ni: one base per slice + an immediate)
+    int fa[NS], fb[NS];
+#pragma unroll
+    for (int g = 0; g < NS; ++g) {
+        const int slot = (kh * KW + g * 32 + h * 16) >> 4;
+        const int ra = rb * 64 + col, rw = cb * 64 + col;
+        fa[g] = ra * PITCH + ((slot ^ key(ra)) << 4);
+        fb[g] = (BM + rw) * PITCH + ((slot ^ key(rw)) << 4);
+    }
+    acc_t acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = AC::zero();
+
+    // NST - 1 stages in flight: steps 0 .. NST-2 requested here, step J + NST - 1 right behind the barrier of step J (into the stage step
+    // J - 1 read: every wave's reads of it completed before that wave reached the barrier)
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) request(st, st < nsteps ? st : nsteps - 1);
+    auto do_step = [&](auto Jc, int step) __attribute__((always_inline)) {
+        constexpr int stage = decltype(Jc)::value % NST, stage_fill = (decltype(Jc)::value + NST - 1) % NST;
+        wait_vm<(NST - 2) * PT>();     // this step's pieces have landed (those of the NST - 2 later steps stay in flight)
+        __builtin_amdgcn_s_barrier();  // ... everybody's have, and everybody is done reading the stage refilled next
+        asm volatile("" ::: "memory");
+        request(stage_fill, step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1);  // past the end: repeat the last step (never consumed)
+        u32x4 a[NS][2], b[NS][2];
+#pragma unroll
+        for (int g = 0; g < NS; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[g][i] = *(const u32x4*)(smem + stage * STAGE + fa[g] + i * 32 * PITCH);
+                b[g][i] = *(const u32x4*)(smem + stage * STAGE + fb[g] + i * 32 * PITCH);
+            }
+        if constexpr (INT) {
+#pragma unroll
+            for (int g = 0; g < NS; ++g)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = AC::mma(a[g][mi], b[g][ni], acc[mi][ni]);
+        } else {
+#pragma unroll
+            for (int g = 0; g < NS; g += 2)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = AC::mma64(a[g][mi], a[g + 1][mi], b[g][ni], b[g + 1][ni], acc[mi][ni]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the stage are complete before it reaches the next barrier
+    };
+    auto chain = [&](auto self, auto Jc, int s0) -> void {
+        constexpr int J = decltype(Jc)::value;
+        do_step(std::integral_constant<int, J>{}, s0 + J);
+        if constexpr (J + 1 < NST) {
+            if (s0 + J + 1 < nsteps) self(self, std::integral_constant<int, J + 1>{}, s0);
+        }
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += NST) chain(chain, std::integral_constant<int, 0>{}, s0);
+    wait_vm<0>();
+    __syncthreads();
+
+    // ---- epilogue: add the two K halves (raw accumulator words: int32 stays exact), transpose through LDS, 16-byte output rows
+    typedef typename std::conditional<INT, int, float>::type word_t;
+    typedef word_t word4 __attribute__((ext_vector_type(4)));
+    constexpr int C_PITCH = BN + 4;
+    {
+        acc_t* xch = (acc_t*)smem;  // [rb][cb][mi][ni][lane]
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if (kh == 1) xch[(((rb * 2 + cb) * 2 + mi) * 2 + ni) * 64 + lane] = acc[mi][ni];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if (kh == 0) acc[mi][ni] += xch[(((rb * 2 + cb) * 2 + mi) * 2 + ni) * 64 + lane];
+            }
+        __syncthreads();
+    }
+    word_t* ct = (word_t*)smem;  // [128][C_PITCH]
+    if (kh == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = rb * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    ct[r * C_PITCH + cb * 64 + ni * 32 + col] = acc[mi][ni][e];
+                }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int u = tid + 512 * i, r = u >> 5, c4 = (u & 31) * 4;
+        const int m = m0 + r;
+        if (m < p.M) {
+            const word4 v = *(const word4*)(ct + r * C_PITCH + c4);
+            store_out4_any(p.epi, (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, m, (int64_t)nt * BN + c4);
+        }
+    }
+}
+
+// tuning[0] = 10 forces it (tuning[2]: stage geometry); automatic: a8w8_sq128_pays() in api.hip
+bool plan_gemm_a8w8_sq128(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
+    if (a.elements_per_sample != 1 || a.W_group_mode != 0 || a.M < 2) return false;
+    if (a.w_dtype != a.input_dtype) return false;
+    if (!(a.input_dtype == GEMLITE_DT_INT8 || a.input_dtype == GEMLITE_DT_FP8E4 || a.input_dtype == GEMLITE_DT_FP8E5)) return false;
+    if (a.stride_wk != 1 || a.stride_xk != 1 || a.stride_on != 1 || a.N % 128 != 0 || a.K % 256 != 0) return false;
+    if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
+    if ((int64_t)a.M * a.stride_xm >= (1ll << 31) || (int64_t)a.N * a.stride_wn >= (1ll << 31)) return false;
+    if (!(a.output_dtype == GEMLITE_DT_FP32 || a.output_dtype == GEMLITE_DT_FP16 || a.output_dtype == GEMLITE_DT_BF16)) return false;
+    if ((a.channel_scale_mode == 1 || a.channel_scale_mode == 3) &&
+        !(a.meta_dtype == GEMLITE_DT_FP32 || a.meta_dtype == GEMLITE_DT_FP16 || a.meta_dtype == GEMLITE_DT_BF16)) return false;
+    if ((a.channel_scale_mode == 1 || a.channel_scale_mode == 3) && ((uintptr_t)a.scales % 16) != 0) return false;
+    const int oal = a.output_dtype == GEMLITE_DT_FP32 ? 16 : 8;  // 4 outputs per store
+    if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
+    const int64_t tiles = (int64_t)(a.N / 128) * ((a.M + 127) / 128);
+    if (tiles > 0x7FFFFFFF) return false;
+    typedef void (*fn_t)(const GenericParams);
+    // tuning[2]: 0 / 4 = four stages of 128-byte K steps (three in flight), 5 = five (two 64-KB stages of 256-byte steps: measured, removed)
+    const int geo = a.tuning[0] == 10 ? a.tuning[2] : 0;
+    if (!(geo == 0 || geo == 4 || geo == 5)) return false;
+    fn_t fn;
+    size_t lds;
+#define GL_SQ128(KS, NSTG) (a.input_dtype == GEMLITE_DT_INT8 ? gemm_a8w8_sq128_kernel<GEMLITE_DT_INT8, KS, NSTG>                            \
+                            : (a.input_dtype == GEMLITE_DT_FP8E4 ? gemm_a8w8_sq128_kernel<GEMLITE_DT_FP8E4, KS, NSTG>                      \
+                                                                 : gemm_a8w8_sq128_kernel<GEMLITE_DT_FP8E5, KS, NSTG>))
+    if (geo == 5) fn = GL_SQ128(128, 5), lds = (size_t)5 * 256 * 128;
+    else fn = GL_SQ128(128, 4), lds = (size_t)4 * 256 * 128;
+#undef GL_SQ128
+    if (lds < (size_t)128 * 132 * 4) lds = (size_t)128 * 132 * 4;
+    g.splitk = 1;
+    g.flags = a.tuning[3];
+    lp.fn = (const void*)fn;
+    lp.name = "gemm_a8w8_sq_kernel<128x128>";
+    lp.grid = dim3((unsigned)tiles, 1, 1);
+    lp.block = dim3(512, 1, 1);
+    lp.lds_bytes = lds;
+    lp.ws_bytes = 0;
+    lp.slab_bytes = 0;
+    return true;
+}
+
 bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
     if (a.elements_per_sample != 1 || a.W_group_mode != 0 || a.M < 2) return false;
     if (a.w_dtype != a.input_dtype) return false;

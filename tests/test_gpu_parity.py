@@ -529,7 +529,7 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
     # streaming kernel | 4-wave MFMA kernel of round 1 | 8-wave kernels: every tile height, K split 1 / 3 (uneven) / 8, weights
     # through LDS (128 / 256 rows, default) and straight from memory (tuning[3] & 64)
     for t in ((1, 0, 0, 0), (2, 0, 0, 0), (0, 1, 1, 0), (0, 3, 2, 0), (0, 8, 4, 0), (0, 1, 8, 0), (0, 5, 8, 0), (0, 3, 4, 0),
-              (0, 8, 4, 64), (0, 1, 8, 64), (0, 5, 8, 64), (6, 0, 0, 0), (5, 0, 2, 0), (5, 0, 3, 0), (5, 0, 4, 0)):
+              (0, 8, 4, 64), (0, 1, 8, 64), (0, 5, 8, 64), (6, 0, 0, 0), (5, 0, 2, 0), (5, 0, 3, 0), (5, 0, 4, 0), (10, 0, 0, 0)):
         gemlite_amd.core.TUNING_OVERRIDE = t
         try:
             outs[t] = lin(x)
@@ -552,6 +552,39 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
         assert torch.equal(ya, yb), M
 
 
+@pytest.mark.parametrize("kind", ["int8", "fp8e4", "fp8e5"])
+def test_a8w8_sq128_kernel_unsplit_128_tiles(kind):
+    """gemm_a8w8_sq_kernel<128x128> (round 5, tuning[0] = 10; the default where its tiles number about one per CU): ragged row tiles,
+    column-tile counts that are / are not a multiple of the 8 XCDs, one .. many K steps, strided activations.  int8 accumulates exactly:
+    bit for bit against the streaming kernel; fp8 sums in another order: 2 % of mean |y|."""
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    qdt = dict(int8=torch.int8, fp8e4=torch.float8_e4m3fn, fp8e5=torch.float8_e5m2)[kind]
+    for (N, K) in ((1024, 256), (1152, 768), (2048, 4096), (128, 2048)):
+        torch.manual_seed(N + K)
+        W = (torch.randn(N, K) / 30).half()
+        proc = H.A8W8_int8_dynamic(device=DEV, dtype=torch.float16) if kind == "int8" else H.A8W8_dynamic(device=DEV, dtype=torch.float16, fp8=qdt)
+        lin = proc.from_weights(W)
+        for M in (2, 65, 128, 129, 300):
+            x = (torch.randn(M, K) / 10).half().to(DEV)
+            xq, sx = scale_activations_per_token(x, qdt)
+            wide = torch.zeros(M, K + 64, dtype=xq.dtype, device=DEV)
+            wide[:, :K] = xq
+            outs = {}
+            for label, (xin, t) in dict(sq128=(xq, (10, 0, 0, 0)), sq128_strided=(wide[:, :K], (10, 0, 0, 0)), stream=(xq, (1, 0, 0, 0)),
+                                        sq128_5x128=(xq, (10, 0, 5, 0))).items():
+                outs[label] = _hip_matmul(xin, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, t)
+            torch.cuda.synchronize()
+            assert _kernel_name(lin, xq, -1, (10, 0, 0, 0)) == "gemm_a8w8_sq_kernel<128x128>"
+            assert torch.equal(outs["sq128"], outs["sq128_strided"]), (kind, N, K, M)
+            assert torch.equal(outs["sq128"], outs["sq128_5x128"]), (kind, N, K, M)   # (same 128-byte steps, another stage count: bitwise)
+            if kind == "int8":
+                assert torch.equal(outs["sq128"], outs["stream"]), (kind, N, K, M)
+            else:
+                d = (outs["sq128"].float() - outs["stream"].float()).abs()
+                assert float(d.max()) < 0.02 * float(outs["stream"].float().abs().mean()) + 1e-3, (kind, N, K, M, float(d.max()))
+
+
 @pytest.mark.parametrize("K", [256, 512, 768, 1280])
 def test_a8w8_lds_kernel_short_and_uneven_k(K):
     """Weights-through-LDS kernel with fewer K steps than LDS stages (K = 256: two 128-byte steps, 3-4 stages) and step counts
@@ -565,7 +598,7 @@ def test_a8w8_lds_kernel_short_and_uneven_k(K):
         if K % 256 == 0:  # the unsplit 64 x 64 tiles of round 4 (256-byte K steps): fewer steps than stages at K = 256 / 512 / 768
             assert _kernel_name(lin, torch.empty(M, K, dtype=torch.int8)) == "gemm_a8w8_sq_kernel<64x64>"
         outs = {}
-        for t in (None, (6, 0, 0, 0), (0, 0, 8, 0), (0, 2, 4, 0), (1, 0, 0, 0)) + (((5, 0, 2, 0), (5, 0, 4, 0)) if K % 256 == 0 else ()):
+        for t in (None, (6, 0, 0, 0), (0, 0, 8, 0), (0, 2, 4, 0), (1, 0, 0, 0)) + (((5, 0, 2, 0), (5, 0, 4, 0), (10, 0, 0, 0)) if K % 256 == 0 else ()):
             gemlite_amd.core.TUNING_OVERRIDE = t
             try:
                 outs[t] = lin(x)

@@ -207,9 +207,13 @@ def test_struct_abi_and_validation():
     (dict(M=256, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # ... two rounds of a long K: the 128-row tile
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 0, 64)), "gemm_a8w8_mma_kernel<128x128>"),   # A/B switch
     (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # two rounds at K = 4096: 2 stages, two blocks per CU
-    (dict(M=1024, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # 256-row tiles would leave half the chip idle
+    (dict(M=1024, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<128x128>"),   # round 5: 256 unsplit 128 x 128 tiles (27.5 vs 32.2 us)
+    (dict(M=1024, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_lds_kernel<128x128>"),   # (round 3; 256-row tiles would leave half the chip idle)
+    (dict(M=512, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<128x128>"),   # 256 tiles again (47.0 vs 52.7 us)
+    (dict(M=256, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),  # 128 tiles: K slices (36 vs 44 us)
     (dict(M=4096, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<256x128>"),
-    (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<256x128>"),  # config 5: 128 tiles x 2 slices of a long K
+    (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<128x128>"),  # config 5, round 5: 256 unsplit 128 x 128 tiles (95.8 vs 98.5 us)
+    (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_lds_kernel<256x128>"),  # (round 3: 128 tiles x 2 slices of a long K)
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(2, 0, 0, 0)), "gemm_a8w8_kernel<64x64>"),  # round-1 kernel
     (dict(M=256, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(1, 0, 0, 0)), "kmajor_matmul_kernel"),
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_decode_kernel<tile16,16w>"),   # A16W8 int8, pre-scale, one row (round 4)
