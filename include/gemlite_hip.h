@@ -177,6 +177,11 @@ typedef struct gemlite_hip_forward_args {
      *   few rows (2..32, MFMA)     [0] 1/2/4 = 16-/32-/64-column tiles, 3 = the 8-wave tiled kernel instead
      *                              [1] K slices   [2] 1 = LDS-staged streaming kernel, 4 / 8 = waves per block of the registers-only
      *                              kernel (8: one row tile, >= 32-column tiles; default with two K slices)
+     *   decode batch (2..64 rows, 4-bit words under 16-bit activations; round 5: gemm_w4_rows_kernel, 16-column blocks, K unsplit,
+     *                              raw integer codes through the MFMA)   [0] 9 = at any M >= 2 the kernel takes (row blocks along
+     *                              grid.y above 16 MT rows; [2] must be 0 or 8); default for 2..64 rows where N / 16 blocks are
+     *                              resident in one round and the x re-reads stay <= 176 MiB, and ALWAYS for group size 32 and
+     *                              N % 64 != 0 (no other MFMA kernel takes them)   [3] & 65536 = never (the round-4 choice, A/B runs)
      *   tiled (M > 32, MFMA)       [0] 1 = streaming kernel, 2 = the 4-wave tiled kernel of round 1 (4-bit only; the planner's
      *                              fallback for K = 64 * odd)
      *                              [1] K slices (any count <= K steps; slices may be uneven)
@@ -194,7 +199,9 @@ typedef struct gemlite_hip_forward_args {
      *                              M K N / 16 <= 88 MiB and, from 128 column tiles of 64, M N K <= 800 M) at any M <= 64 and at M = 1, 5 = the unsplit 64 x 64 tiles of round 4
      *                              (default from 65 rows where they fill the chip once or twice, and from 2 rows past the few-row budget; [2] = 2/3/4 LDS stages),
      *                              6 = the round-3 kernels instead; M = 1: 7 = the round-2 streaming kernels instead of
-     *                              a8w8_decode_kernel, 8 = a8w8_decode_kernel also for fp8 with N > 4096
+     *                              a8w8_decode_kernel, 8 = a8w8_decode_kernel also for fp8 with N > 4096;
+     *                              10 = the unsplit 128 x 128 tiles of round 5 (default above 64 rows where they number 192 .. 256 and
+     *                              K >= 4096; [2] = 4 / 5 LDS stages of 128-byte K steps)
      *                              [1] K slices   [2] tile rows / 32 (forces the 8-wave kernels at any M)
      *                              [3] & 64: 128- / 256-row tiles with the weights straight from memory (default: through LDS)
      *                              [3] & 32768: test switch of the in-launch activation quantisation (no producer block runs)
