@@ -332,10 +332,22 @@ static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
 //     draw with the MFMA GEMV / the registers-only kernel: 6.2 - 6.9 vs 6.1 - 6.5); longer K from 2 again since the x pieces are requested
 //     ahead of the weights (probe_rows5_v2b*.log: 4096 x 8192 M = 2 / 8 / 16 / 32: 10.1 / 9.3 / 10.5 / 15.6 -> 8.8 / 9.4 / 10.2 / 13.0;
 //     4096 x 11008: 12.8 / 17.0 / 17.1 / 17.8 -> 10.5 / 11.4 / 12.3 / 16.7; 3072 x 8192: 9.0 / 11.2 / 14.0 / 15.3 -> 8.7 / 9.4 / 10.1 / 12.8).
-static bool rows5_pays(int64_t M, int64_t N, int64_t K) {
+//   * 4096 < N <= 8192 (N % 32 = 0, groups of >= 64): TWO column tiles per block (N / 32 resident blocks, an x piece read from LDS feeds both;
+//     probe_rows5_nt2*.log) — each CU then streams twice the weights through the same 8 waves, which loses below 17 rows against the
+//     registers-only kernel (8192^2 M = 16: 12.5 -> 16.0) and wins where that kernel's K-slice combine or the 32-row tile kernel took over:
+//     17 .. 32 rows (8192^2 19.5 -> 18.5, 8192 x 4096 13.6 -> 11.9, 6144 x 4096 13.4 -> 11.4, 5120^2 15.5 -> 13.4; groups of 64 in bf16 at
+//     6144 x 4096: 33.5 -> 12.1 — the round-4 planner fell to the LDS-staged streaming kernel there), and 8 .. 64 rows over K <= 2048
+//     (8192 x 2048: 6.6 / 7.4 / 9.0 / 11.0 -> 6.2 / 6.3 / 7.3 / 9.4).  Groups of 64 over K > 4096 stay (8192^2 M = 32: 19.0 -> 20.3).
+static bool rows5_pays(int64_t M, int64_t N, int64_t K, int gs_shift) {
     if (M < 2 || M > 64 || N % 16 != 0 || K > 12288) return false;
-    const int64_t tiles = N / 16;
-    if (tiles > gl::resident_block_limit() || tiles < ((M >= 16 && M <= 32) ? 128 : 192)) return false;  // (2048 x 8192: M = 16 / 32 win, M = 64 loses)
+    const int64_t tiles = N / 16, resident = gl::resident_block_limit();
+    if (tiles > resident) {
+        if (N % 32 != 0 || tiles / 2 > resident || gs_shift < 6) return false;
+        if (K <= 2048 ? M < 8 : (M < 17 || M > 32)) return false;
+        if (gs_shift == 6 && (K > 4096 || M > 32)) return false;
+        return (tiles / 2) * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
+    }
+    if (tiles < ((M >= 16 && M <= 32) ? 128 : 192)) return false;  // (2048 x 8192: M = 16 / 32 win, M = 64 loses)
     const int64_t min_m = (K > 2048 && K <= 4096) ? 8 : 2;
     if (M < min_m) return false;
     return tiles * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
@@ -456,7 +468,7 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         if (x16 && a.W_nbits == 4 && (mt == GEMLITE_MATMUL_AUTO || mt == GEMLITE_MATMUL_GEMM_SPLITK || (mt == GEMLITE_MATMUL_GEMM && a.tuning[0] == 9)) &&
             !(a.tuning[3] & 65536) && (a.tuning[0] == 9 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && a.M >= 2))) {
             const bool only_here = p.gs_shift == 5 || a.N % 64 != 0;  // nothing but the coverage kernel behind this one
-            const bool in_budget = rows5_pays(a.M, a.N, a.K);
+            const bool in_budget = rows5_pays(a.M, a.N, a.K, p.gs_shift);
             if (a.tuning[0] == 9 || only_here || in_budget) {
                 WnParams pr = p;
                 LaunchPlan lr{};

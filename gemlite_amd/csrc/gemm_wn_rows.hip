@@ -72,14 +72,15 @@ __device__ __forceinline__ void tie1(uint32_t& v) { asm volatile("" : "+v"(v)); 
 
 }  // namespace rows5
 
-// MT = row tiles of 16 (M <= 16 MT); SPG = 32-k steps per quantisation group (4: groups of >= 128, 2: 64, 1: 32)
-template <typename Tag, int MT, int SPG>
+// MT = row tiles of 16 (M <= 16 MT); SPG = 32-k steps per quantisation group (4: groups of >= 128, 2: 64, 1: 32); NT = 16-column tiles
+// per block (2: layers with 4096 < N <= 8192 — N / 32 blocks stay resident in ONE round, and an x piece read from LDS feeds both tiles)
+template <typename Tag, int MT, int SPG, int NT = 1>
 __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const char* wb, const char* xb, const char* sp, const char* zp, uint16_t* out,
                                                                           uint32_t sw4, uint32_t mstride2, int nch_total, uint32_t modes,
                                                                           int M, uint32_t sxm2, uint32_t som) {
     using namespace rows5;
     using TR = F16Traits<Tag>;
-    constexpr int CHUNK = 32, TC = 16, CSTRIDE = NW * CHUNK;  // packed rows per chunk (256 k), tile columns
+    constexpr int CHUNK = 32, TC = 16, TCN = TC * NT, CSTRIDE = NW * CHUNK;  // packed rows per chunk (256 k), tile columns, block columns
     constexpr int NG = 8 / SPG;                               // quantisation groups per chunk (group sizes above 256 repeat their row)
     constexpr int NML = (NG + 3) / 4;                         // metadata loads per chunk and kind (scales / zeros), each 4 groups x 16 columns
     constexpr int XK = MT == 1 ? 256 : (MT == 2 ? 128 : 64);  // k per x piece
@@ -88,17 +89,17 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
     constexpr int PPR = XK / 8;                               // 16-byte slots per row of a piece
     constexpr int RPI = 64 / PPR;                             // rows per LDS-DMA instruction (1 KiB)
     constexpr int DPI = 16 * MT / RPI;                        // LDS-DMA instructions per piece
-    constexpr int NWM = 2 + 2 * NML;                          // requests of one chunk's weights + metadata
+    constexpr int NWM = NT * (2 + 2 * NML);                   // requests of one chunk's weights + metadata
     constexpr int NS = 2;                                     // weight register sets = chunks the weight requests run ahead.  (4 sets — 64 KB per CU in
                                                               // flight like the decode kernel — measured SLOWER: a wave's requests return in order, so every
                                                               // x piece then waits behind more HBM round trips; 4096 x 8192 M = 8: 9.4 -> 10.7 us)
-    static_assert(NG >= 2 && DPI * 1024 <= XBUF && (WSLOT_I1 + 256) * 4 <= WSLOT_BYTES && MT * 1024 <= XBUF, "LDS layout");
+    static_assert(NG >= 2 && DPI * 1024 <= XBUF && (WSLOT_I1 + 256) * 4 <= WSLOT_BYTES && MT * NT * 1024 <= XBUF, "LDS layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.x;
-    if (modes & M_PAIR) {  // adjacent half-line tiles on one XCD (speed only; any mapping is correct)
+    if (NT == 1 && (modes & M_PAIR)) {  // adjacent half-line tiles on one XCD (speed only; any mapping is correct)
         const int xcd = tile & 7, idx = tile >> 3;
         tile = (((idx >> 1) << 3) + xcd) * 2 + (idx & 1);
     }
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
     // ds_read_b32 half (kb = 0, 1 or 2, 3) land on banks j and 16 + j
     const int wr_off = g * 16 + c * 4;
     const int rd_off = (kb & 1) * WSLOT_I1 + (kb >> 1) * 16 + j;
-    const uint32_t wo0 = (uint32_t)(wave * CHUNK + g * 2) * sw4 + (uint32_t)(tile * TC + c * 4) * 4u;
+    const uint32_t wo0 = (uint32_t)(wave * CHUNK + g * 2) * sw4 + (uint32_t)(tile * TCN + c * 4) * 4u;  // (+ 64 bytes per further column tile)
 
     // ---- x pieces: LDS slot (row r, 16-byte slot p') of a buffer holds piece p = p' ^ f(r) of the row; DMA instruction q fills rows
     //      q RPI .. q RPI + RPI - 1 lane-linearly.  f: the low bits of r that separate the rows one ds_read_b128 lane group touches
@@ -155,20 +156,25 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
     //      always in bounds — so the loop stays branch-free)
     const char* sbase = need_s ? sp : wb;
     const char* zbase = need_z ? zp : wb;
-    const uint32_t mcol = (uint32_t)(tile * TC + j) * 2u;
-    struct WSet { u32x4 w0, w1; uint32_t s[NML], z[NML]; };
+    const uint32_t mcol = (uint32_t)(tile * TCN + j) * 2u;  // (+ 32 bytes per further column tile)
+    struct WSet { u32x4 w0[NT], w1[NT]; uint32_t s[NT][NML], z[NT][NML]; };
     auto issue_w = [&](WSet& S, int ch) {
         const uint32_t wo = wo0 + (uint32_t)(ch * CSTRIDE) * sw4;
-        gld128_nt(S.w0, wb, wo);
-        gld128_nt(S.w1, wb, wo + sw4);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            gld128_nt(S.w0[n], wb, wo + (uint32_t)(n * 64));
+            gld128_nt(S.w1[n], wb, wo + sw4 + (uint32_t)(n * 64));
+        }
         const uint32_t k0 = (uint32_t)(ch * CSTRIDE + wave * CHUNK) * 8u;
 #pragma unroll
-        for (int l = 0; l < NML; ++l) {
-            const int gq = 4 * l + kb < NG ? 4 * l + kb : NG - 1;
-            const uint32_t mo = ((k0 + (uint32_t)(gq * 32 * SPG)) >> gs_shift) * mstride2 + mcol;
-            gld16(S.s[l], sbase, need_s ? mo : 0u);
-            gld16(S.z[l], zbase, need_z ? mo : 0u);
-        }
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int l = 0; l < NML; ++l) {
+                const int gq = 4 * l + kb < NG ? 4 * l + kb : NG - 1;
+                const uint32_t mo = ((k0 + (uint32_t)(gq * 32 * SPG)) >> gs_shift) * mstride2 + mcol + (uint32_t)(n * 32);
+                gld16(S.s[n][l], sbase, need_s ? mo : 0u);
+                gld16(S.z[n][l], zbase, need_z ? mo : 0u);
+            }
     };
     // everything but the newest `newer` requests of this wave has landed; newer is wave-uniform and one of four values
     auto wait_newer = [&](bool w_behind, bool x_behind) {
@@ -176,9 +182,11 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
         else          { if (x_behind) wait_vm<DPI>(); else wait_vm<0>(); }
     };
 
-    f32x4 tot[MT];
+    f32x4 tot[MT][NT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) tot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) tot[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float scalar_zero = (modes & M_ZSCALAR) ? (float)((const int32_t*)zp)[0] : 0.f;
     const float bz = (w_mode == 1 || w_mode == 3) ? -1.f : (w_mode == 4 ? 1.f : 0.f);
     const bool b_times_s = w_mode == 3;
@@ -191,53 +199,66 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
     // must not wait behind the HBM round trip of the weights requested with it (4096 x 11008, M = 8: 12.7 -> 11.4 us).
     auto chunk = [&](WSet& S, int ch, auto cpar) {
         constexpr int CPAR = decltype(cpar)::value;
-        uint32_t bw[8];
-        f32x4 acc[MT], ones[MT];
+        uint32_t bw[NT][8];
+        f32x4 acc[MT][NT], ones[MT];
 #pragma unroll
         for (int pi = 0; pi < NP; ++pi) {
             const int i = ch * NP + pi;
             const int par = ((NP & 1) ? CPAR : 0) ^ (pi & 1);
             wait_newer(pi == 0 && ch + 1 < nchunks, i + 1 < npieces);
             if (pi == 0) {  // the wave's 2 KB of weights: registers -> own LDS slot -> MFMA layout
-                tie4(S.w0);
-                tie4(S.w1);
 #pragma unroll
-                for (int l = 0; l < NML; ++l) {
-                    tie1(S.s[l]);
-                    tie1(S.z[l]);
+                for (int n = 0; n < NT; ++n) {
+                    tie4(S.w0[n]);
+                    tie4(S.w1[n]);
+#pragma unroll
+                    for (int l = 0; l < NML; ++l) {
+                        tie1(S.s[n][l]);
+                        tie1(S.z[n][l]);
+                    }
                 }
-                *(u32x4*)(wslot + wr_off) = S.w0;
-                *(u32x4*)(wslot + WSLOT_I1 + wr_off) = S.w1;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) bw[s] = wslot[rd_off + s * 32];
+                for (int n = 0; n < NT; ++n) {  // (one slot, tile after tile: the DS operations of a wave execute in order)
+                    *(u32x4*)(wslot + wr_off) = S.w0[n];
+                    *(u32x4*)(wslot + WSLOT_I1 + wr_off) = S.w1[n];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) bw[n][s] = wslot[rd_off + s * 32];
+                }
             }
             const unsigned char* xbuf = wl + par * XBUF;
 #pragma unroll
             for (int sq = 0; sq < SPP; ++sq) {
                 const int s = pi * SPP + sq;
-                const uint32_t t_lo = bw[s] & 0x0F0F0F0Fu, t_hi = (bw[s] >> 4) & 0x0F0F0F0Fu;
-                u32x4 bf;
+                u32x4 bf[NT];
 #pragma unroll
-                for (int pq = 0; pq < 4; ++pq) bf[pq] = __builtin_amdgcn_perm(t_hi, t_lo, 0x0C040C00u + (uint32_t)pq * 0x00010001u) | TR::MAGIC2;
+                for (int n = 0; n < NT; ++n) {
+                    const uint32_t t_lo = bw[n][s] & 0x0F0F0F0Fu, t_hi = (bw[n][s] >> 4) & 0x0F0F0F0Fu;
+#pragma unroll
+                    for (int pq = 0; pq < 4; ++pq) bf[n][pq] = __builtin_amdgcn_perm(t_hi, t_lo, 0x0C040C00u + (uint32_t)pq * 0x00010001u) | TR::MAGIC2;
+                }
                 const bool first = s % SPG == 0;
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const u32x4 a = *(const u32x4*)(xbuf + (abase[t] ^ (uint32_t)(sq << 6)));
-                    acc[t] = mfma16<Tag>(a, bf, first ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[t]);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[t][n] = mfma16<Tag>(a, bf[n], first ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[t][n]);
                     ones[t] = mfma16<Tag>(a, onesb, first ? (f32x4){0.f, 0.f, 0.f, 0.f} : ones[t]);
                 }
                 if ((s + 1) % SPG == 0) {  // end of a quantisation group: fold scale / zero into the totals
                     const int q = s / SPG, l = q >> 2, gq = q & 3;  // group q of the chunk: loaded by the lanes kb = gq of load l
-                    const uint32_t sraw = (uint32_t)__builtin_amdgcn_ds_bpermute((j + 16 * gq) * 4, (int)S.s[l]);
-                    const uint32_t zraw = (uint32_t)__builtin_amdgcn_ds_bpermute((j + 16 * gq) * 4, (int)S.z[l]);
-                    const float sv = need_s ? TR::to_float((uint16_t)sraw) : 1.f;
-                    const float zv = need_z ? TR::to_float((uint16_t)zraw) : scalar_zero;
-                    const float a = sv;
-                    const float b = bz * zv * (b_times_s ? sv : 1.f) - a * TR::OFF;
 #pragma unroll
-                    for (int t = 0; t < MT; ++t)
+                    for (int n = 0; n < NT; ++n) {
+                        const uint32_t sraw = (uint32_t)__builtin_amdgcn_ds_bpermute((j + 16 * gq) * 4, (int)S.s[n][l]);
+                        const uint32_t zraw = (uint32_t)__builtin_amdgcn_ds_bpermute((j + 16 * gq) * 4, (int)S.z[n][l]);
+                        const float sv = need_s ? TR::to_float((uint16_t)sraw) : 1.f;
+                        const float zv = need_z ? TR::to_float((uint16_t)zraw) : scalar_zero;
+                        const float a = sv;
+                        const float b = bz * zv * (b_times_s ? sv : 1.f) - a * TR::OFF;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) tot[t][r] += a * acc[t][r] + b * ones[t][r];
+                        for (int t = 0; t < MT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) tot[t][n][r] += a * acc[t][n][r] + b * ones[t][r];
+                    }
                 }
             }
             // the buffer is free once this wave's reads of it have returned; then the requests two pieces / two chunks ahead
@@ -262,30 +283,33 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
         }
     }
 
-    // ---- the 8 waves (disjoint K) meet in LDS: [MT][16 rows][16 columns] fp32 at the start of each wave's region; C layout: column j,
+    // ---- the 8 waves (disjoint K) meet in LDS: [MT x 16 rows][16 NT columns] fp32 at the start of each wave's region; C layout: column j,
     //      rows 4 kb + r ------------------------------------------------------------------------------------------------------------------
     float* part = (float*)wl;
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part[(t * 16 + 4 * kb + r) * TC + j] = tot[t][r];
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(t * 16 + 4 * kb + r) * TCN + n * TC + j] = tot[t][n][r];
     __syncthreads();
-    constexpr int NPAIR = MT * 16 * (TC / 2);  // pairs of adjacent columns in the tile
+    constexpr int CPR = TCN / 2;               // pairs of adjacent columns per row of the block
+    constexpr int NPAIR = MT * 16 * CPR;
     for (int o = tid; o < NPAIR; o += NW * 64) {
-        const int m = o >> 3, cp = o & 7;
+        const int m = o / CPR, cp = o % CPR;
         float v0 = 0.f, v1 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const float2 pv = *(const float2*)(smem + (size_t)w * WAVE_LDS + (size_t)(m * TC + cp * 2) * 4);
+            const float2 pv = *(const float2*)(smem + (size_t)w * WAVE_LDS + (size_t)(m * TCN + cp * 2) * 4);
             v0 += pv.x;
             v1 += pv.y;
         }
         if (modes & M_POST) {  // channel scales of the kernel's 16-bit type (channel_scale_mode 1)
-            const uint32_t sw = *(const uint32_t*)(sp + (size_t)(tile * TC + cp * 2) * 2);
+            const uint32_t sw = *(const uint32_t*)(sp + (size_t)(tile * TCN + cp * 2) * 2);
             v0 *= TR::to_float((uint16_t)(sw & 0xFFFFu));
             v1 *= TR::to_float((uint16_t)(sw >> 16));
         }
-        if (m < M) *(uint32_t*)(out + (size_t)m * som + (size_t)(tile * TC + cp * 2)) = (uint32_t)TR::from_float(v0) | ((uint32_t)TR::from_float(v1) << 16);
+        if (m < M) *(uint32_t*)(out + (size_t)m * som + (size_t)(tile * TCN + cp * 2)) = (uint32_t)TR::from_float(v0) | ((uint32_t)TR::from_float(v1) << 16);
     }
 }
 
@@ -295,7 +319,14 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
 typedef void (*rows5_fn)(const char*, const char*, const char*, const char*, uint16_t*, uint32_t, uint32_t, int, uint32_t, int, uint32_t, uint32_t);
 
 template <typename Tag, int MT>
-static rows5_fn rows5_pick_spg(int spg) {
+static rows5_fn rows5_pick_spg(int spg, int nt) {
+    if (nt == 2) {  // two column tiles per block: groups of >= 128 up to 64 rows, groups of 64 up to 32 rows (registers)
+        if (spg == 4) return gemm_w4_rows_kernel<Tag, MT, 4, 2>;
+        if constexpr (MT <= 2) {
+            if (spg == 2) return gemm_w4_rows_kernel<Tag, MT, 2, 2>;
+        }
+        return nullptr;
+    }
     switch (spg) {
         case 4: return gemm_w4_rows_kernel<Tag, MT, 4>;
         case 2: return gemm_w4_rows_kernel<Tag, MT, 2>;
@@ -306,12 +337,12 @@ static rows5_fn rows5_pick_spg(int spg) {
     }
 }
 template <typename Tag>
-static rows5_fn rows5_pick(int mt, int spg) {
+static rows5_fn rows5_pick(int mt, int spg, int nt) {
     switch (mt) {
-        case 1: return rows5_pick_spg<Tag, 1>(spg);
-        case 2: return rows5_pick_spg<Tag, 2>(spg);
-        case 3: return rows5_pick_spg<Tag, 3>(spg);
-        case 4: return rows5_pick_spg<Tag, 4>(spg);
+        case 1: return rows5_pick_spg<Tag, 1>(spg, nt);
+        case 2: return rows5_pick_spg<Tag, 2>(spg, nt);
+        case 3: return rows5_pick_spg<Tag, 3>(spg, nt);
+        case 4: return rows5_pick_spg<Tag, 4>(spg, nt);
         default: return nullptr;
     }
 }
@@ -339,21 +370,32 @@ bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPla
     // 32-bit byte offsets in the kernel
     if (rows * a.stride_wk * 4 + a.N * 4 >= (1ll << 32) || (64 * a.stride_xm + a.K) * 2 >= (1ll << 32) || 64 * a.stride_om * 2 >= (1ll << 32)) return false;
     if (p.gs_shift < 31 && ((a.K >> p.gs_shift) * p.stride_meta_g + a.N) * 2 >= (1ll << 32)) return false;
+    // two column tiles per block (tuning[1] = 2 forces, 1 = never): up to 32 rows of a layer whose 16-column tiles do not fit one round
+    // of resident blocks but whose 32-column blocks do (4096 < N <= 8192 on 256 CUs)
+    const int64_t resident = resident_block_limit();
+    int nt = 1;
+    if (a.tuning[1] == 2 || (a.tuning[1] == 0 && a.N / 16 > resident && a.N / 32 <= resident)) nt = 2;
+    if (nt == 2 && (a.N % 32 != 0 || spg == 1 || a.M > (spg == 4 ? 64 : 32))) {
+        if (a.tuning[1] == 2) return false;
+        nt = 1;
+    }
+    if (a.tuning[1] < 0 || a.tuning[1] > 2) return false;
     const int mt_cap = spg == 1 ? 2 : 4;  // row tiles per block; more rows: blocks along grid.y (the weights stream once per block row)
     const int mt = a.M > 16 * mt_cap ? mt_cap : (int)((a.M + 15) / 16);
     if ((a.M + 16 * mt - 1) / (16 * mt) > 65535) return false;
     if (a.tuning[2] != 0 && a.tuning[2] != 8) return false;
     const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
-    const rows5_fn fn = f16 ? rows5_pick<half_tag>(mt, spg) : rows5_pick<bf16_tag>(mt, spg);
+    const rows5_fn fn = f16 ? rows5_pick<half_tag>(mt, spg, nt) : rows5_pick<bf16_tag>(mt, spg, nt);
     if (!fn) return false;
     const int nw = rows5::NW;
-    const int tiles = (int)(a.N / 16);
+    const int tiles = (int)(a.N / (16 * nt));
     const bool need_s = loop_s, need_z = has_z && !a.zero_is_scalar;
     p.splitk = 1;
     p.rows_per_slice = (int)rows;
     lp.fn = (const void*)fn;
     static const char* names[4] = {"gemm_w4_rows_kernel<16x16>", "gemm_w4_rows_kernel<32x16>", "gemm_w4_rows_kernel<48x16>", "gemm_w4_rows_kernel<64x16>"};
-    lp.name = names[mt - 1];
+    static const char* names2[4] = {"gemm_w4_rows_kernel<16x32>", "gemm_w4_rows_kernel<32x32>", "gemm_w4_rows_kernel<48x32>", "gemm_w4_rows_kernel<64x32>"};
+    lp.name = nt == 2 ? names2[mt - 1] : names[mt - 1];
     lp.grid = dim3((unsigned)tiles, (unsigned)((a.M + 16 * mt - 1) / (16 * mt)), 1);
     lp.block = dim3(64 * nw, 1, 1);
     lp.lds_bytes = (size_t)rows5::WAVE_LDS * nw;
@@ -368,7 +410,7 @@ bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPla
     lp.r5.sw4 = (uint32_t)a.stride_wk * 4u;
     lp.r5.mstride2 = ((need_s || need_z) && p.gs_shift < 31) ? (uint32_t)p.stride_meta_g * 2u : 0u;
     lp.r5.nch_total = (int)(rows / 32);
-    lp.r5.modes = (uint32_t)a.W_group_mode | ((has_z && a.zero_is_scalar) ? 16u : 0u) | (((tiles & 15) == 0) ? 32u : 0u) | (post_s ? 128u : 0u) | ((uint32_t)p.gs_shift << 8);
+    lp.r5.modes = (uint32_t)a.W_group_mode | ((has_z && a.zero_is_scalar) ? 16u : 0u) | ((nt == 1 && (tiles & 15) == 0) ? 32u : 0u) | (post_s ? 128u : 0u) | ((uint32_t)p.gs_shift << 8);
     lp.r5.M = (int)a.M;
     lp.r5.sxm2 = (uint32_t)a.stride_xm * 2u;
     lp.r5.som = (uint32_t)a.stride_om;

@@ -87,6 +87,17 @@ for da in sorted(glob.glob(os.path.join(out, "*_A"))):
             if wc and med(cs.get(k, [])) is not None:
                 u[nm] = round(med(cs[k]) / wc, 3)
         util[w] = u
+# per-kernel means of every counter, one small CSV per pass (the raw per-dispatch files are deleted by pmc_official.sh afterwards)
+for d in sorted(glob.glob(os.path.join(out, "*_[AB]"))):
+    if not os.path.isdir(d):
+        continue
+    t = load(d)
+    with open(d + "_counters_by_kernel.csv", "w") as f:
+        f.write("Kernel_Name,Counter_Name,samples,mean_value\n")
+        for kn in sorted(t):
+            for cn in sorted(t[kn]):
+                v = t[kn][cn]
+                f.write('"%s",%s,%d,%.3f\n' % (kn.replace('"', "'"), cn, len(v), sum(v) / max(1, len(v))))
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 json.dump(util, open(os.path.join(out, "mfma_util.json"), "w"), indent=1)
 print(json.dumps({"calibration": calib, "traffic": {k: v for k, v in traffic.items() if not k.startswith("_")}, "mfma_util": {k: v for k, v in util.items() if not k.startswith("_")}}, indent=1))

@@ -15,3 +15,5 @@ timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $PW
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $PWD/$O/calib_B -o p -- scripts/ubench/fetch_calib > $O/calib_B.log 2>&1
 find $O/calib_A $O/calib_B -name "*kernel_trace.csv" -delete 2>/dev/null
 python scripts/pmc_official.py $O | tee $O/summary.txt
+# keep the summaries (*_counters_by_kernel.csv, *.json, summary.txt, logs); the raw per-dispatch CSVs exceed what gpurun copies back
+for d in $O/*_A $O/*_B; do [ -d "$d" ] && rm -rf "$d"; done

@@ -510,9 +510,19 @@ def test_direct_mfma_kernel_all_modes(zeros_kind, fma, scales_kind, tdt):
         x = torch.from_numpy(O.gen_x(M, 4096, seed=M).astype(np.float32)).to(tdt).to(DEV)
         y = lin(x)
         torch.cuda.synchronize()
-        assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel" if M > 4 else "gemv_mfma_kernel"), _kernel_name(lin, x)
+        # (round 5: 16 .. 32 rows of a layer with >= 128 16-column tiles run the rows kernel by default; tuning[3] & 65536 = the round-4 choice)
+        assert _kernel_name(lin, x).startswith(("gemm_wn_direct_kernel", "gemm_w4_rows_kernel") if M > 4 else "gemv_mfma_kernel"), _kernel_name(lin, x)
         _compare(f"direct-modes/{zeros_kind}-{fma}-{scales_kind}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x),
                  lin.output_dtype.value)
+        if M > 4:
+            assert _kernel_name(lin, x, -1, (0, 0, 0, 65536)).startswith("gemm_wn_direct_kernel"), _kernel_name(lin, x, -1, (0, 0, 0, 65536))
+            gemlite_amd.core.TUNING_OVERRIDE = (0, 0, 0, 65536)
+            try:
+                y4 = lin(x)
+            finally:
+                gemlite_amd.core.TUNING_OVERRIDE = None
+            torch.cuda.synchronize()
+            _compare(f"direct-modes-r4/{zeros_kind}-{fma}-{scales_kind}/{str(tdt)[6:]}/M{M}", y4, _oracle_from_layer(lin, x), lin.output_dtype.value)
 
 
 def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
@@ -683,8 +693,8 @@ def test_direct_mfma_kernel_group_size_64(nbits, tdt):
     for M in (2, 9, 16):
         x = torch.from_numpy(O.gen_x(M, 4096, seed=M + 5).astype(np.float32)).to(tdt).to(DEV)
         y_or = _oracle_from_layer(lin, x)
-        assert _kernel_name(lin, x).startswith("gemm_wn_direct_kernel" if M > 4 else ("gemv_mfma_kernel", "gemm_wn_direct_kernel")), _kernel_name(lin, x)
-        for tuning in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (4, 0, 0, 0), (4, 2, 0, 0), (0, 0, 1, 0)):
+        assert _kernel_name(lin, x, -1, (0, 0, 0, 65536)).startswith("gemm_wn_direct_kernel" if M > 4 else ("gemv_mfma_kernel", "gemm_wn_direct_kernel")), _kernel_name(lin, x)
+        for tuning in ((0, 0, 0, 0), (0, 0, 0, 65536), (1, 0, 0, 0), (2, 0, 0, 0), (4, 0, 0, 0), (4, 2, 0, 0), (0, 0, 1, 0)):
             y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
             torch.cuda.synchronize()
             _compare(f"direct-g64/w{nbits}/{str(tdt)[6:]}/M{M}/{tuning}", y, y_or, lin.output_dtype.value)
@@ -1638,6 +1648,12 @@ def test_rows5_kernel_all_modes(zeros_kind, fma, scales_kind, tdt):
         y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, ROWS5)
         torch.cuda.synchronize()
         _compare(f"rows5-modes/{zeros_kind}-{fma}-{scales_kind}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x), lin.output_dtype.value)
+        # two 16-column tiles per block (tuning[1] = 2; automatic for 4096 < N <= 8192): the same arithmetic per tile, bit for bit
+        assert _kernel_name(lin, x, -1, (9, 2, 0, 0)).endswith("x32>") and _kernel_name(lin, x, -1, (9, 1, 0, 0)).endswith("x16>")
+        y2 = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, (9, 2, 0, 0))
+        y1 = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, (9, 1, 0, 0))
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2) and torch.equal(y, y1), (M, float((y1.float() - y2.float()).abs().max()))
 
 
 @pytest.mark.parametrize("N,K,gs", [(4096, 4096, 128), (1040, 2816, 128), (512, 256, 128), (2064, 11008, 64), (1024, 8192, 32),

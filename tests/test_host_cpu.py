@@ -110,7 +110,8 @@ def test_struct_abi_and_validation():
     (dict(M=48, N=4096, K=11008), "gemm_w4_mma_kernel<64x128>"),  # past the x re-read budget (176 MB): tile kernel
     (dict(M=16, N=4096, K=14336), "gemm_wn_direct_kernel<tile32>"),   # K > 12288: weights only two chunks ahead: the round-3 kernels
     (dict(M=16, N=6144, K=4096), "gemm_wn_direct_kernel<tile32>"),    # more blocks than CUs (one 146-KB block per CU): two rounds lose
-    (dict(M=9, tuning=(9, 0, 0, 0), N=8192, K=8192), "gemm_w4_rows_kernel<16x16>"),   # tuning[0] = 9 forces it
+    (dict(M=9, tuning=(9, 0, 0, 0), N=8192, K=8192), "gemm_w4_rows_kernel<16x32>"),   # tuning[0] = 9 forces it (4096 < N <= 8192: two column tiles per block)
+    (dict(M=9, tuning=(9, 1, 0, 0), N=8192, K=8192), "gemm_w4_rows_kernel<16x16>"),   # ... tuning[1] = 1: one
     (dict(M=200, tuning=(9, 0, 0, 0)), "gemm_w4_rows_kernel<64x16>"),                   # ... at any M: 64-row blocks along grid.y
     (dict(M=4, gs=32, N=8192, K=8192), "gemm_w4_rows_kernel<16x16>"),   # groups of 32 at M >= 2: nothing but the coverage kernel behind it on shapes the streaming kernel refuses
     (dict(M=300, gs=32), "gemm_w4_rows_kernel<32x16>"),                 # ... any M (32-row blocks along grid.y)
