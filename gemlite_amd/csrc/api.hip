@@ -347,7 +347,9 @@ static bool rows5_pays(int64_t M, int64_t N, int64_t K, int gs_shift) {
         if (gs_shift == 6 && (K > 4096 || M > 32)) return false;
         return (tiles / 2) * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
     }
-    if (tiles < ((M >= 16 && M <= 32) ? 128 : 192)) return false;  // (2048 x 8192: M = 16 / 32 win, M = 64 loses)
+    // groups of 64 at 17 .. 32 rows have no registers-only kernel behind them (only the 32-row MFMA tiles: 1024 x 4096 11.8 vs 7.8 us here)
+    const bool g64_two_tiles = gs_shift == 6 && M >= 17 && M <= 32;
+    if (tiles < (g64_two_tiles ? 32 : ((M >= 16 && M <= 32) ? 128 : 192))) return false;  // (2048 x 8192: M = 16 / 32 win, M = 64 loses)
     const int64_t min_m = (K > 2048 && K <= 4096) ? 8 : 2;
     if (M < min_m) return false;
     return tiles * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
@@ -523,6 +525,12 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
             if (long_k && plan_gemm_wn_mma(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
             // few rows: registers-only MFMA path (tuning[2] == 1 keeps the LDS-staged streaming kernel)
             if (a.M <= 32 && a.tuning[2] != 1 && a.tuning[0] != 3 && plan_gemm_wn_direct(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
+            // 17 .. 32 rows the registers-only kernel refuses (groups of 64 — hqq's default — need one row tile there): rounds 2-4 fell to the
+            // LDS-staged streaming kernel, 1.3 - 2.2x behind the 32-row MFMA tiles (profiles/r05/probe_g64_m17_32_w{4,2}.log, 4-bit / 2-bit:
+            // 4096^2 16.3 / 15.7 -> 12.9 / 11.9 us, 6144 x 4096 2-bit 23.1 -> 12.2, 11008 x 4096 31.4 / 31.0 -> 16.5 / 22.6, 8192^2 2-bit 25.3 -> 17.2);
+            // a short K keeps the streaming kernel (8960 x 1536: 10.6 vs 11.1)
+            if (mt == GEMLITE_MATMUL_AUTO && a.M > 16 && a.K >= 2048 && a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 65536) &&
+                plan_gemm_wn_mma(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
             if (a.tuning[0] != 3 && plan_gemm_wn_stream(a, p, lp)) { r.kind = K_STREAM_WN; r.wn = p; r.lp = lp; return; }
             // shapes the few-row kernels do not take (K = 11008, 8960, ...): small tiles of the MFMA kernel, never the
             // coverage kernel (tuning[0] == 3 forces this path for A/B runs)

@@ -18,7 +18,8 @@ if os.environ.get("GL_SHAPES"):
 MS = [int(a) for a in sys.argv[1:]] or [2, 4, 5, 8, 16, 24, 32, 48, 64]
 DT = os.environ.get("GL_DT", "fp16")
 GS = int(os.environ.get("GL_GS", "128"))
-CANDS = {"r4": (0, 0, 0, 65536), "rows5": (9, 0, 0, 0), "rows5_nt1": (9, 1, 0, 0), "default": None}
+BITS = int(os.environ.get("GL_BITS", "4"))
+CANDS = {"r4": (0, 0, 0, 65536), "rows5": (9, 0, 0, 0), "rows5_nt1": (9, 1, 0, 0), "mma": (3, 0, 0, 65536), "default": None}
 
 
 def time_us(mods, x, tuning, min_seconds=0.06):
@@ -67,8 +68,8 @@ def kname(lin, x, tuning):
 
 for (N, K) in SHAPES:
     name = f"probe_{N}x{K}"
-    nl = max(2, min(32, int(300e6 // (N * K // 2))))
-    bench.WORKLOADS[name] = (N, K, 4, GS, 1, DT, nl, "hbm")
+    nl = max(2, min(32, int(300e6 // (N * K * BITS // 8))))
+    bench.WORKLOADS[name] = (N, K, BITS, GS, 1, DT, nl, "hbm")
     mods, _ = bench.build_layers(name, dev)
     g = torch.Generator(device=dev).manual_seed(1)
     for M in MS:
@@ -81,6 +82,8 @@ for (N, K) in SHAPES:
             try:
                 res[label] = round(time_us(mods, x, t), 2)
                 names[label] = kn
+                if label == "mma":
+                    res["mma_kernel"] = kn
             except Exception as e:  # noqa: BLE001
                 res[label] = None
                 names[label] = str(e)[:60]

@@ -698,6 +698,14 @@ def test_direct_mfma_kernel_group_size_64(nbits, tdt):
             y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
             torch.cuda.synchronize()
             _compare(f"direct-g64/w{nbits}/{str(tdt)[6:]}/M{M}/{tuning}", y, y_or, lin.output_dtype.value)
+    # 17 .. 32 rows: round 5 sends them to the rows kernel (4-bit) / the 32-row MFMA tiles, no longer to the LDS-staged streaming kernel
+    x = torch.from_numpy(O.gen_x(24, 4096, seed=3).astype(np.float32)).to(tdt).to(DEV)
+    name = _kernel_name(lin, x)
+    assert name.startswith("gemm_w4_rows_kernel" if nbits == 4 else "gemm_w2_mma_kernel<32x128>"), name
+    for tuning in ((0, 0, 0, 0), (3, 0, 0, 65536), (0, 0, 0, 65536)):
+        y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
+        torch.cuda.synchronize()
+        _compare(f"direct-g64/w{nbits}/{str(tdt)[6:]}/M24/{tuning}", y, _oracle_from_layer(lin, x), lin.output_dtype.value)
 
 
 @pytest.mark.parametrize("M", [1, 8])

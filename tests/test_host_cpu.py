@@ -128,6 +128,10 @@ def test_struct_abi_and_validation():
     (dict(M=6, gs=64), "gemm_wn_direct_kernel<tile32>"),   # group size 64: registers-only kernel up to 16 rows (round 5: 2 .. 7 at 4096^2)
     (dict(M=8, gs=64), "gemm_w4_rows_kernel<16x16>"),
     (dict(M=24, gs=64, tuning=(0, 0, 0, 65536)), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32 (the round-4 choice)
+    (dict(M=24, gs=64, N=11008, K=4096), "gemm_w4_mma_kernel<32x128>"),             # round 5: ... where the rows kernel does not pay, the 32-row MFMA tiles (31.6 -> 16.6 us), not the streaming kernel
+    (dict(M=24, gs=64, nbits=2), "gemm_w2_mma_kernel<32x128>"),                     # ... 2-bit too (16.4 -> 12.0 us)
+    (dict(M=24, gs=64, N=1024, K=4096), "gemm_w4_rows_kernel<32x16>"),              # ... small N: the rows kernel (18.8 -> 8.1 us)
+    (dict(M=24, gs=64, N=8960, K=1536), "gemm_wn_stream_kernel"),                   # ... a short K keeps the streaming kernel (10.6 vs 11.1 us)
     (dict(M=24, gs=64), "gemm_w4_rows_kernel<32x16>"),
     (dict(M=4, gs=32, tuning=(0, 0, 0, 65536)), "gemm_wn_stream_kernel"),
     (dict(M=4, gs=32), "gemm_w4_rows_kernel<16x16>"),
