@@ -10,8 +10,8 @@ The step is captured once as a hipGraph (the launch-bound regime the reference i
 graphs, config.py:17) and replayed; `value` is whole-job algorithmic GB/s over all ranks.
 
 The JSON line carries BOTH halves of BASELINE.json's metric ("... at M=1 and M=256") and all five BASELINE configs, measured in this
-process.  Round 5: EVERY block below lives INSIDE the `roofline` object in compact form ({kernel, kernel_us, achieved, unit, frac,
-traffic, mfma_util}) — the driver's parsed record keeps `roofline` whole and only the NAMES of other top-level keys, so the M = 256
+process.  Round 5: EVERY block below lives INSIDE the `roofline` object in compact form ({kernel, kernel_us, frac, traffic, mfma_util};
+`achieved` / `unit` per block: --full-out) — the driver's parsed record keeps `roofline` whole and only the NAMES of other top-level keys, so the M = 256
 half of the metric (`roofline.m256`) is now driver-retained evidence.  `--full-out PATH` writes the verbose blocks to a file.  Every block uses ONE clock: wall time of a replayed hipGraph that holds >= 32 back-to-back launches of the workload over
 rotating (cache-cold) layers, divided by the launches — the same quantity as the timed region of `value`, and the one that
 reproduces from `rocprofv3 --kernel-trace --stats` of this command (profiles/r03/official/: the kernel's average duration agrees
