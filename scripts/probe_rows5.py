@@ -19,7 +19,7 @@ MS = [int(a) for a in sys.argv[1:]] or [2, 4, 5, 8, 16, 24, 32, 48, 64]
 DT = os.environ.get("GL_DT", "fp16")
 GS = int(os.environ.get("GL_GS", "128"))
 BITS = int(os.environ.get("GL_BITS", "4"))
-CANDS = {"r4": (0, 0, 0, 65536), "rows5": (9, 0, 0, 0), "rows5_nt1": (9, 1, 0, 0), "mma": (3, 0, 0, 65536), "default": None}
+CANDS = {"r4": (0, 0, 0, 65536), "rows5": (9, 0, 0, 0), "rows5_nt1": (9, 1, 0, 0), "rows5_nt2": (9, 2, 0, 0), "mma": (3, 0, 0, 65536), "default": None}
 
 
 def time_us(mods, x, tuning, min_seconds=0.06):
