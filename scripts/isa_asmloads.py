@@ -95,6 +95,12 @@ def replay(lines, seq, weakest_of_alternatives=False):
                         break  # overwritten first
                 if dead:
                     clash = set()
+        if clash and op.startswith("v_pk_") and "op_sel_hi:[1,0]" in t and "op_sel:" not in t:
+            # packed fp32 with the SECOND source broadcast from its low register (op_sel_hi[1] = 0, op_sel[1] = 0): the high register of that
+            # 64-bit operand is encoded but never read
+            m4 = re.match(r"v_pk_\w+ v\[\d+:\d+\], [^,]+, v\[(\d+):(\d+)\]", t)
+            if m4 and clash == {int(m4.group(2))}:
+                clash = set()
         if clash:
             bad.append((a, t, sorted(clash)))
         if vmem and "atomic" not in op or (vmem and "atomic" in op):
@@ -139,7 +145,20 @@ def check():
             if best is None:
                 return
             lo, hi, _ = best
-            seq = list(range(0, hi + 1)) + list(range(lo, hi + 1))
+            # first pass: straight-line from the top, following UNCONDITIONAL forward branches (hipcc rotates some loops: the preheader ends in an
+            # s_branch into the middle of the body — the ring form of the rows kernel with four pieces per chunk); then full iterations
+            seq, i = [], 0
+            while i <= hi:
+                seq.append(i)
+                m = re.match(r"s_branch\s+(\d+)", lines[i][1])
+                if m:
+                    offw = int(m.group(1))
+                    tgt = index.get(lines[i][0] + 4 + offw * 4) if offw < 32768 else None
+                    if tgt is not None and i < tgt <= hi:
+                        i = tgt
+                        continue
+                i += 1
+            seq += list(range(lo, hi + 1)) + list(range(lo, hi + 1))
             for (a, t, r) in replay(lines, seq, weakest_of_alternatives="gemm_w4_rows_kernel" in fn)[:4]:
                 reports.append((fn, hex(a), t, r))
         for line in asm.split("\n"):
