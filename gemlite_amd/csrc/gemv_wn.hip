@@ -69,6 +69,12 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
     constexpr int E = 32 / NBITS;    // elements per packed word
     constexpr int HALF = E / 2;      // (k, k+HALF) pairs per word == LDS dwords per packed row
     constexpr int WP = WN::WP;
+    // fp16, 4-bit (two fields per 16-bit window): the field read 4 bits up gets its OWN fp32 accumulator and the 2^-4 is applied once to the sum
+    // (round 5; rounds 2-4 pre-scaled the matching x by 2^-4 in fp16: mantissa bits lost below |x| = 2^-10).  2- and 1-bit words
+    // (four / eight fields per window) keep the pre-scaled x: 4 / 8 accumulator sets do not fit
+    // (A/B on one box, scripts/r5/run_j_ab_gemv_split.sh: 16384^2 M = 1 27.9 vs 28.3 us in the single-workload bench — no cost)
+    constexpr bool SPLIT = SUBN && NBITS == 4 && WP == 2;
+    constexpr int NACC = SPLIT ? WP : 1;
     constexpr int G = 64 >> CQ;      // row sub-groups per wave
     constexpr int CHUNK = G * R;     // packed rows one wave consumes per step
     constexpr int TC = 4 << CQ;      // tile columns
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
                 for (int d = 0; d < HALF; ++d) {
                     const float lo = TR::to_float(v[wdi * E + d]), hi = TR::to_float(v[wdi * E + d + HALF]);
                     sum_t += lo + hi;
-                    if constexpr (WP > 1) {  // pre-scale by 2^-(NBITS * position-in-window): exact
+                    if constexpr (WP > 1 && !SPLIT) {  // pre-scale by 2^-(NBITS * position-in-window): exact
                         const float sc = __builtin_bit_cast(float, (uint32_t)(127 - NBITS * (d % WP)) << 23);
                         const uint16_t slo = TR::from_float(lo * sc), shi = TR::from_float(hi * sc);
                         sum_s += TR::to_float(slo) + TR::to_float(shi);
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
                         outv[wdi * HALF + d] = (uint32_t)v[wdi * E + d] | ((uint32_t)v[wdi * E + d + HALF] << 16);
                     }
                 }
-            if constexpr (WP == 1) sum_s = sum_t;
+            if constexpr (WP == 1 || SPLIT) sum_s = sum_t;
         } else {
 #pragma unroll
             for (int d = 0; d < 16; ++d) outv[d] = 0u;
@@ -254,12 +260,14 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
 
     auto compute = [&](const Chunk& ck, int chunk) {
         const int row_rel = row_w0 + chunk * CSTRIDE + g * R;  // first of this lane's R rows (slice-relative)
-        float acc[MB][4];
+        float acc[NACC][MB][4];
         float xd_sum = 0.f;  // XD: sum of the run's true x
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int a = 0; a < NACC; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[a][m][j] = 0.f;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             constexpr int XW = HALF >= 4 ? 4 : HALF;  // x dwords fetched per LDS read
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
                     xr[0][3] = __builtin_amdgcn_perm(d3, d1, 0x07060302u);
 #pragma unroll
                     for (int dd = 0; dd < 4; ++dd) xd_sum = TR::dot2(xr[0][dd], TR::ONES2, xd_sum);
-                    if constexpr (WP > 1) {
+                    if constexpr (WP > 1 && !SPLIT) {
 #pragma unroll
                         for (int dd = 0; dd < 4; ++dd)
                             if (dd % WP) {
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
                         uint32_t h = (ck.w[i][j] >> (NBITS * WP * win)) & wmask[wi];
                         if constexpr (!SUBN) h |= TR::MAGIC2;
 #pragma unroll
-                        for (int m = 0; m < MB; ++m) acc[m][j] = TR::dot2(h, xr[m][dd], acc[m][j]);
+                        for (int m = 0; m < MB; ++m) acc[SPLIT ? wi : 0][m][j] = TR::dot2(h, xr[m][dd], acc[SPLIT ? wi : 0][m][j]);
                     }
                 }
             }
@@ -332,7 +340,8 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
             for (int j = 0; j < 4; ++j) {
                 const float a = s[j] * QSCALE;
                 const float b = bz * z[j] * (b_times_s ? s[j] : 1.f);
-                float v = acc[m][j];
+                float v = acc[0][m][j];
+                if constexpr (SPLIT) v = __builtin_fmaf(acc[NACC - 1][m][j], 1.0f / 16.0f, v);
                 if constexpr (!SUBN) v -= TR::OFF * xst;
                 tot[m][j] += a * v + b * xt;
             }
@@ -515,7 +524,14 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_w4_decode_kernel(const WnPara
     for (int i = 0; i < WP; ++i) wmask[i] = (15u * 0x00010001u) << (4 * i);
 
     auto compute = [&](const Chunk& ck) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // fp16: the second field of a 16-bit window is read 4 bits up; its products go to their OWN accumulator and the 2^-4 is applied once to
+        // the fp32 sum (round 5, ADVICE r4: rounds 2-4 scaled the matching x pairs by 2^-4 in fp16 here, which lost mantissa bits below |x| = 2^-10;
+        // the same scheme as gemv_w4_decode3_kernel)
+        float acc[WP][4];
+#pragma unroll
+        for (int wi = 0; wi < WP; ++wi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[wi][j] = 0.f;
         float xsum = 0.f;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -529,14 +545,6 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_w4_decode_kernel(const WnPara
             xr[3] = __builtin_amdgcn_perm(d3, d1, 0x07060302u);
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) xsum = TR::dot2(xr[dd], TR::ONES2, xsum);
-            if constexpr (WP > 1) {  // fp16: odd pairs * 2^-4 (exact), the matching fields are read 4 bits up
-#pragma unroll
-                for (int dd = 0; dd < 4; ++dd)
-                    if (dd % WP) {
-                        const h2_t v = __builtin_bit_cast(h2_t, xr[dd]) * (h2_t){(_Float16)(1.0f / (1 << (4 * (dd % WP)))), (_Float16)(1.0f / (1 << (4 * (dd % WP))))};
-                        xr[dd] = __builtin_bit_cast(uint32_t, v);
-                    }
-            }
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {
                 const int win = dd / WP, wi = dd % WP;
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_w4_decode_kernel(const WnPara
                 for (int j = 0; j < 4; ++j) {
                     uint32_t h = (ck.w[i][j] >> (4 * WP * win)) & wmask[wi];
                     if constexpr (!SUBN) h |= TR::MAGIC2;
-                    acc[j] = TR::dot2(h, xr[dd], acc[j]);
+                    acc[wi][j] = TR::dot2(h, xr[dd], acc[wi][j]);
                 }
             }
         }
@@ -557,7 +565,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_w4_decode_kernel(const WnPara
             if (!need_z) z[j] = scalar_zero;
             const float a = s[j] * QSCALE;
             const float b = bz * z[j] * (b_times_s ? s[j] : 1.f);
-            float v = acc[j];
+            float v = acc[0][j];
+            if constexpr (WP > 1) v = __builtin_fmaf(acc[WP - 1][j], 1.0f / 16.0f, v);
             if constexpr (!SUBN) v -= TR::OFF * xsum;
             tot[j] += a * v + b * xsum;
         }

@@ -1596,13 +1596,16 @@ def test_small_magnitude_fp16_activations_on_the_decode_kernels(amp):
     multiplies the unscaled x — but accumulates its GEMV in fp16, where products of this size are subnormal as well).  The round-4 decode
     kernel (gemv_decode.hip) keeps the two field positions in separate fp32 accumulators instead and applies the 2^-4 once to the sum:
     nothing is rounded there, so its error against the float64 oracle is the fp16 rounding of the OUTPUT alone whatever the magnitude
-    of x.  The kernels that still pre-scale (round-3 decode kernel, matrix-core decode kernels at 1 and 3 rows, the 2-bit variant) are
+    of x (round 5: the round-3 decode kernel and the 4-bit forms of gemv_wn_kernel do the same).  The kernels that still pre-scale
+    (matrix-core decode kernels at 1 and 3 rows — one MFMA mixes both field positions —, the 2- and 1-bit variants) are
     bounded: measured 3e-4 / 8e-4 / 1.8e-3 of mean |y| at |x| ~ 1e-3 / 3e-4 / 1e-4 (profiles/r04/pytest_gpu_c16.log)."""
     from gemlite_amd.core import _hip_matmul
     bound_scaled = {1e-3: 1e-3, 3e-4: 2e-3, 1e-4: 5e-3}[amp]
     for nbits, N, K, M, tuning, want, bound in (
             (4, 1024, 4096, 1, (0, 0, 0, 0), "gemv_w4_decode3_kernel", 4e-4),          # exact products: output rounding only
-            (4, 4096, 4096, 1, (0, 0, 0, 4096), "gemv_w4_decode_kernel", bound_scaled),
+            (4, 4096, 4096, 1, (0, 0, 0, 4096), "gemv_w4_decode_kernel", 4e-4),       # round 5: split accumulators there too (ADVICE r4)
+            (4, 4096, 4096, 1, (0, 0, 0, 16), "gemv_wn_kernel<tile16,xdirect,16w>", 4e-4),   # ... and in the 4-bit forms of gemv_wn_kernel: x direct,
+            (4, 4096, 8192, 1, (0, 0, 0, 512), "gemv_wn_kernel<tile16>", 4e-4),              #     x staged through LDS
             (4, 8192, 4096, 1, (0, 0, 0, 0), "gemv_mfma_kernel", bound_scaled),
             (4, 1024, 4096, 3, (0, 0, 0, 0), "gemv_mfma_kernel", bound_scaled),
             (2, 1024, 4096, 1, (0, 0, 0, 0), "gemv_w2_mfma_kernel", 4 * bound_scaled)):
