@@ -557,10 +557,10 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
         best, default_us, timed = None, None, {}
         cands = list(candidates or _TUNING_CANDIDATES[fam])
         if candidates is None and not mx and M >= 2:
-            # round 5: the decode-shaped rows kernel of 4-bit words under 16-bit activations ([0] = 9; [1] = 1 / 2 column tiles per block), the
-            # round-4 choice ([3] & 65536), and the unsplit 128 x 128 tiles of unpacked 8-bit layers ([0] = 10; [2] = stages)
+            # round 5: the decode-shaped rows kernel of 4-bit words under 16-bit activations ([0] = 9; [1] = 1 / 2 column tiles per block)
+            # and the unsplit 128 x 128 tiles of unpacked 8-bit layers ([0] = 10; [2] = stages)
             if layer.W_nbits == 4 and layer.elements_per_sample == 8 and not layer.scaled_activations:
-                cands += [(9, 0, 0, 0), (9, 1, 0, 0), (9, 2, 0, 0), (0, 0, 0, 65536)]
+                cands += [(9, 0, 0, 0), (9, 1, 0, 0), (9, 2, 0, 0)]
             if layer.elements_per_sample == 1 and layer.scaled_activations and M > 64:
                 cands += [(10, 0, 0, 0), (10, 0, 5, 0)]
         for cand in cands:
