@@ -338,6 +338,23 @@ static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
 //     17 .. 32 rows (8192^2 19.5 -> 18.5, 8192 x 4096 13.6 -> 11.9, 6144 x 4096 13.4 -> 11.4, 5120^2 15.5 -> 13.4; groups of 64 in bf16 at
 //     6144 x 4096: 33.5 -> 12.1 — the round-4 planner fell to the LDS-staged streaming kernel there), and 8 .. 64 rows over K <= 2048
 //     (8192 x 2048: 6.6 / 7.4 / 9.0 / 11.0 -> 6.2 / 6.3 / 7.3 / 9.4).  Groups of 64 over K > 4096 stay (8192^2 M = 32: 19.0 -> 20.3).
+//   * 2-bit words (A16W2, BitNet A16W158; late round 5, probe_rows5_w2*.log): the same kernel, 512 k per chunk.  4096^2 M = 16 / 32 / 48 / 64:
+//     6.8 / 11.6 / 12.2 / 12.3 -> 6.1 / 7.6 / 8.8 / 10.1; 3584 x 4096: 7.9 / 11.6 / 13.8 / 14.0 -> 6.0 / 7.5 / 8.7 / 10.1; 4096 x 2048 from 8 rows
+//     (5.4 / 6.4 / 8.9 / 9.8 -> 4.4 / 4.5 / 5.5 / 7.1; 2 - 4 rows lose 0.1 - 0.3); 4096 x 14336 up to 32 rows (M = 32: 21.4 -> 17.8; 48 / 64 lose);
+//     2048 x 8192 16 .. 32 rows (9.9 / 13.7 -> 9.0 / 11.5); groups of 64 hold 32 rows per block (M = 64 along grid.y loses: 11.6 -> 13.7);
+//     one column tile per block only (N <= 4096).
+static bool rows5_pays_w2(int64_t M, int64_t N, int64_t K, int gs_shift) {
+    if (M < 2 || M > 64 || N % 16 != 0 || K % 512 != 0 || K > 16384) return false;
+    const int64_t tiles = N / 16;
+    if (tiles > gl::resident_block_limit()) return false;
+    const bool g64_two_tiles = gs_shift == 6 && M >= 17 && M <= 32;
+    if (tiles < (g64_two_tiles ? 32 : ((M >= 16 && M <= 32) ? 128 : 192))) return false;
+    if (gs_shift == 6 && M > 32) return false;
+    if (gs_shift < 6) return false;  // (groups of 32: 16 rows per block — only where nothing else applies)
+    if (M < (K <= 2048 ? 8 : 2)) return false;
+    const int64_t bytes = tiles * ((M + 15) / 16 * 16) * K * 2;
+    return bytes <= (192ll << 20) || (M <= 32 && bytes <= (256ll << 20));  // (4096 x 8192 M = 48, 192 MiB: 17.6 -> 14.4 us)
+}
 static bool rows5_pays(int64_t M, int64_t N, int64_t K, int gs_shift) {
     if (M < 2 || M > 64 || N % 16 != 0 || K > 12288) return false;
     const int64_t tiles = N / 16, resident = gl::resident_block_limit();
@@ -467,10 +484,10 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         // CU's 64 B/clk address path), so the default stops at a budget on that traffic; groups of 32 and N % 64 != 0 — which no other
         // specialised kernel takes at M >= 2 — always come here (any M: 64-row blocks along grid.y).  tuning[0] = 9 forces the kernel,
         // tuning[3] & 65536 keeps the round-4 choice (A/B runs).
-        if (x16 && a.W_nbits == 4 && (mt == GEMLITE_MATMUL_AUTO || mt == GEMLITE_MATMUL_GEMM_SPLITK || (mt == GEMLITE_MATMUL_GEMM && a.tuning[0] == 9)) &&
+        if (x16 && (a.W_nbits == 4 || a.W_nbits == 2) && (mt == GEMLITE_MATMUL_AUTO || mt == GEMLITE_MATMUL_GEMM_SPLITK || (mt == GEMLITE_MATMUL_GEMM && a.tuning[0] == 9)) &&
             !(a.tuning[3] & 65536) && (a.tuning[0] == 9 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && a.M >= 2))) {
             const bool only_here = p.gs_shift == 5 || a.N % 64 != 0;  // nothing but the coverage kernel behind this one
-            const bool in_budget = rows5_pays(a.M, a.N, a.K, p.gs_shift);
+            const bool in_budget = a.W_nbits == 4 ? rows5_pays(a.M, a.N, a.K, p.gs_shift) : rows5_pays_w2(a.M, a.N, a.K, p.gs_shift);
             if (a.tuning[0] == 9 || only_here || in_budget) {
                 WnParams pr = p;
                 LaunchPlan lr{};

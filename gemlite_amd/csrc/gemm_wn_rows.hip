@@ -74,17 +74,23 @@ __device__ __forceinline__ void tie1(uint32_t& v) { asm volatile("" : "+v"(v)); 
 
 // MT = row tiles of 16 (M <= 16 MT); SPG = 32-k steps per quantisation group (4: groups of >= 128, 2: 64, 1: 32); NT = 16-column tiles
 // per block (2: layers with 4096 < N <= 8192 — N / 32 blocks stay resident in ONE round, and an x piece read from LDS feeds both tiles)
-template <typename Tag, int MT, int SPG, int NT = 1>
+// BITS = 4 or 2 (late round 5: 2-bit words — A16W2, BitNet A16W158 — through the same kernel): a packed row holds E = 32 / BITS k-values, a chunk
+// of 32 packed rows is 256 / 512 k = 8 / 16 MFMA k-steps.  2-bit: lane (j, kb) of k-step s needs k = 32 s + 8 kb .. + 7 = HALF (kb & 1) of the word
+// of packed row 2 s + (kb >> 1): sixteen ds_read_b32 per chunk instead of eight (two lanes share an address: broadcast), the 16-bit half is
+// spread to eight nibbles (three shift-or + and pairs) and then treated like a 4-bit word — natural k order again, so groups of 32 work
+template <typename Tag, int MT, int SPG, int NT = 1, int BITS = 4>
 __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const char* wb, const char* xb, const char* sp, const char* zp, uint16_t* out,
                                                                           uint32_t sw4, uint32_t mstride2, int nch_total, uint32_t modes,
                                                                           int M, uint32_t sxm2, uint32_t som) {
     using namespace rows5;
     using TR = F16Traits<Tag>;
     constexpr int CHUNK = 32, TC = 16, TCN = TC * NT, CSTRIDE = NW * CHUNK;  // packed rows per chunk (256 k), tile columns, block columns
-    constexpr int NG = 8 / SPG;                               // quantisation groups per chunk (group sizes above 256 repeat their row)
+    constexpr int E = 32 / BITS, KS = E;                      // k-values per packed row; MFMA k-steps (32 k) per chunk
+    constexpr int KCH = 32 * E;                               // k per chunk: 256 (4-bit) / 512 (2-bit)
+    constexpr int NG = KS / SPG;                              // quantisation groups per chunk (group sizes above the chunk repeat their row)
     constexpr int NML = (NG + 3) / 4;                         // metadata loads per chunk and kind (scales / zeros), each 4 groups x 16 columns
     constexpr int XK = MT == 1 ? 256 : (MT == 2 ? 128 : 64);  // k per x piece
-    constexpr int NP = 256 / XK;                              // x pieces per chunk
+    constexpr int NP = KCH / XK;                              // x pieces per chunk
     constexpr int SPP = XK / 32;                              // MFMA k-steps per piece
     constexpr int PPR = XK / 8;                               // 16-byte slots per row of a piece
     constexpr int RPI = 64 / PPR;                             // rows per LDS-DMA instruction (1 KiB)
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
     constexpr int NS = 2;                                     // weight register sets = chunks the weight requests run ahead.  (4 sets — 64 KB per CU in
                                                               // flight like the decode kernel — measured SLOWER: a wave's requests return in order, so every
                                                               // x piece then waits behind more HBM round trips; 4096 x 8192 M = 8: 9.4 -> 10.7 us)
-    static_assert(NG >= 2 && DPI * 1024 <= XBUF && (WSLOT_I1 + 256) * 4 <= WSLOT_BYTES && MT * NT * 1024 <= XBUF, "LDS layout");
+    static_assert((BITS == 4 || BITS == 2) && NG >= 2 && DPI * 1024 <= XBUF && (WSLOT_I1 + 256) * 4 <= WSLOT_BYTES && MT * NT * 1024 <= XBUF, "LDS layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -124,7 +130,9 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
     // bytes); read side: row 4 s + kb = 2 (2 s + (kb >> 1)) + (kb & 1) -> dword (kb & 1) WSLOT_I1 + 32 s + 16 (kb >> 1) + j: the 32 lanes of a
     // ds_read_b32 half (kb = 0, 1 or 2, 3) land on banks j and 16 + j
     const int wr_off = g * 16 + c * 4;
-    const int rd_off = (kb & 1) * WSLOT_I1 + (kb >> 1) * 16 + j;
+    const int rd_off = BITS == 4 ? (kb & 1) * WSLOT_I1 + (kb >> 1) * 16 + j   // row 4 s + kb: + 32 s
+                                 : (kb >> 1) * WSLOT_I1 + j;                  // 2-bit: row 2 s + (kb >> 1): + 16 s (kb = 2 m, 2 m + 1 read the same dword)
+    const uint32_t half_sh = (uint32_t)(kb & 1) * 16u;                        // 2-bit: which half of that word
     const uint32_t wo0 = (uint32_t)(wave * CHUNK + g * 2) * sw4 + (uint32_t)(tile * TCN + c * 4) * 4u;  // (+ 64 bytes per further column tile)
 
     // ---- x pieces: LDS slot (row r, 16-byte slot p') of a buffer holds piece p = p' ^ f(r) of the row; DMA instruction q fills rows
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
         const int r = q * RPI + lane / PPR, pp = lane % PPR;
         xvo[q] = r < M ? (uint32_t)r * sxm2 + (uint32_t)((pp ^ fswz(r)) * 16) : 0x80000000u;
     }
-    const async::srd_t rsX = async::make_srd(xb, (uint32_t)(M - 1) * sxm2 + (uint32_t)nch_total * 512u);
+    const async::srd_t rsX = async::make_srd(xb, (uint32_t)(M - 1) * sxm2 + (uint32_t)nch_total * (uint32_t)(KCH * 2));
     const uint32_t xlds = async::lds_addr_of(wl);
     uint32_t abase[MT];  // byte offset of this lane's A fragment (k-step 0 of a piece) inside a buffer; k-step s' = abase ^ (s' << 6)
 #pragma unroll
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
     }
     // piece i of the wave = (chunk i / NP, part i % NP): its first k as a byte offset inside a row of x
     auto issue_x = [&](int i, int par) {
-        const uint32_t koff = (uint32_t)(((i / NP) * CSTRIDE + wave * CHUNK) * 8 + (i % NP) * XK) * 2u;
+        const uint32_t koff = (uint32_t)(((i / NP) * CSTRIDE + wave * CHUNK) * E + (i % NP) * XK) * 2u;
 #pragma unroll
         for (int q = 0; q < DPI; ++q) async::req_lds16(rsX, xlds + (uint32_t)(par * XBUF + q * 1024), xvo[q] + koff, 0u);
     };
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
             gld128_nt(S.w0[n], wb, wo + (uint32_t)(n * 64));
             gld128_nt(S.w1[n], wb, wo + sw4 + (uint32_t)(n * 64));
         }
-        const uint32_t k0 = (uint32_t)(ch * CSTRIDE + wave * CHUNK) * 8u;
+        const uint32_t k0 = (uint32_t)(ch * CSTRIDE + wave * CHUNK) * (uint32_t)E;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
     // must not wait behind the HBM round trip of the weights requested with it (4096 x 11008, M = 8: 12.7 -> 11.4 us).
     auto chunk = [&](WSet& S, int ch, auto cpar) {
         constexpr int CPAR = decltype(cpar)::value;
-        uint32_t bw[NT][8];
+        uint32_t bw[NT][KS];
         f32x4 acc[MT][NT], ones[MT];
 #pragma unroll
         for (int pi = 0; pi < NP; ++pi) {
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
                     *(u32x4*)(wslot + wr_off) = S.w0[n];
                     *(u32x4*)(wslot + WSLOT_I1 + wr_off) = S.w1[n];
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) bw[n][s] = wslot[rd_off + s * 32];
+                    for (int s = 0; s < KS; ++s) bw[n][s] = wslot[rd_off + s * (BITS == 4 ? 32 : 16)];
                 }
             }
             const unsigned char* xbuf = wl + par * XBUF;
@@ -232,7 +240,14 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
                 u32x4 bf[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const uint32_t t_lo = bw[n][s] & 0x0F0F0F0Fu, t_hi = (bw[n][s] >> 4) & 0x0F0F0F0Fu;
+                    uint32_t wv = bw[n][s];
+                    if constexpr (BITS == 2) {  // this lane's 16-bit half -> eight nibbles (q0 .. q7 in the low two bits of each)
+                        wv = (wv >> half_sh) & 0xFFFFu;
+                        wv = (wv | (wv << 8)) & 0x00FF00FFu;
+                        wv = (wv | (wv << 4)) & 0x0F0F0F0Fu;
+                        wv = (wv | (wv << 2)) & 0x33333333u;
+                    }
+                    const uint32_t t_lo = wv & 0x0F0F0F0Fu, t_hi = (wv >> 4) & 0x0F0F0F0Fu;
 #pragma unroll
                     for (int pq = 0; pq < 4; ++pq) bf[n][pq] = __builtin_amdgcn_perm(t_hi, t_lo, 0x0C040C00u + (uint32_t)pq * 0x00010001u) | TR::MAGIC2;
                 }
@@ -319,7 +334,20 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
 typedef void (*rows5_fn)(const char*, const char*, const char*, const char*, uint16_t*, uint32_t, uint32_t, int, uint32_t, int, uint32_t, uint32_t);
 
 template <typename Tag, int MT>
-static rows5_fn rows5_pick_spg(int spg, int nt) {
+static rows5_fn rows5_pick_spg(int spg, int nt, int bits) {
+    if (bits == 2) {  // 2-bit words: one column tile per block
+        if (nt != 1) return nullptr;
+        switch (spg) {  // (16 unrolled k-steps per chunk: groups of 64 fit 256 registers up to 32 rows, groups of 32 up to 16)
+            case 4: return gemm_w4_rows_kernel<Tag, MT, 4, 1, 2>;
+            case 2:
+                if constexpr (MT <= 2) return gemm_w4_rows_kernel<Tag, MT, 2, 1, 2>;
+                else return nullptr;
+            case 1:
+                if constexpr (MT <= 1) return gemm_w4_rows_kernel<Tag, MT, 1, 1, 2>;
+                else return nullptr;
+            default: return nullptr;
+        }
+    }
     if (nt == 2) {  // two column tiles per block: groups of >= 128 up to 64 rows, groups of 64 up to 32 rows (registers)
         if (spg == 4) return gemm_w4_rows_kernel<Tag, MT, 4, 2>;
         if constexpr (MT <= 2) {
@@ -337,18 +365,19 @@ static rows5_fn rows5_pick_spg(int spg, int nt) {
     }
 }
 template <typename Tag>
-static rows5_fn rows5_pick(int mt, int spg, int nt) {
+static rows5_fn rows5_pick(int mt, int spg, int nt, int bits) {
     switch (mt) {
-        case 1: return rows5_pick_spg<Tag, 1>(spg, nt);
-        case 2: return rows5_pick_spg<Tag, 2>(spg, nt);
-        case 3: return rows5_pick_spg<Tag, 3>(spg, nt);
-        case 4: return rows5_pick_spg<Tag, 4>(spg, nt);
+        case 1: return rows5_pick_spg<Tag, 1>(spg, nt, bits);
+        case 2: return rows5_pick_spg<Tag, 2>(spg, nt, bits);
+        case 3: return rows5_pick_spg<Tag, 3>(spg, nt, bits);
+        case 4: return rows5_pick_spg<Tag, 4>(spg, nt, bits);
         default: return nullptr;
     }
 }
 
 bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp) {
-    if (a.W_nbits != 4 || a.w_pack_bits != 32) return false;
+    if ((a.W_nbits != 4 && a.W_nbits != 2) || a.w_pack_bits != 32) return false;
+    const int bits = a.W_nbits, epr = 32 / bits;  // k-values per packed row
     if (a.M < 1 || a.M > 65535 * 64) return false;  // above 64 rows: 64-row blocks along grid.y (the weights stream once per block row)
     if (a.input_dtype != GEMLITE_DT_FP16 && a.input_dtype != GEMLITE_DT_BF16) return false;
     if (a.output_dtype != a.input_dtype || a.stride_on != 1 || a.stride_xk != 1 || a.stride_wn != 1) return false;
@@ -363,10 +392,10 @@ bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPla
     if ((a.stride_xm * 2) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;        // 16-byte A fragments
     if (((uintptr_t)a.w_q % 16) != 0 || (a.stride_wk % 4) != 0) return false;            // 16-byte weight loads
     if (((uintptr_t)a.out % 4) != 0 || a.stride_om % 2 != 0) return false;               // packed pairs of outputs
-    if (a.N % 16 != 0 || a.K % 256 != 0) return false;
+    if (a.N % 16 != 0 || a.K % (32 * epr) != 0) return false;   // whole chunks of 32 packed rows: K % 256 (4-bit) / % 512 (2-bit)
     if (p.gs_shift < 5 || (p.gs_shift > 30 && p.gs_shift != 31)) return false;            // groups of 32, 64, 128, ... k (31: one group spans K)
     const int spg = p.gs_shift >= 7 ? 4 : (p.gs_shift == 6 ? 2 : 1);
-    const int64_t rows = a.K / 8;
+    const int64_t rows = a.K / epr;
     // 32-bit byte offsets in the kernel
     if (rows * a.stride_wk * 4 + a.N * 4 >= (1ll << 32) || (64 * a.stride_xm + a.K) * 2 >= (1ll << 32) || 64 * a.stride_om * 2 >= (1ll << 32)) return false;
     if (p.gs_shift < 31 && ((a.K >> p.gs_shift) * p.stride_meta_g + a.N) * 2 >= (1ll << 32)) return false;
@@ -375,17 +404,18 @@ bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPla
     const int64_t resident = resident_block_limit();
     int nt = 1;
     if (a.tuning[1] == 2 || (a.tuning[1] == 0 && a.N / 16 > resident && a.N / 32 <= resident)) nt = 2;
-    if (nt == 2 && (a.N % 32 != 0 || spg == 1 || a.M > (spg == 4 ? 64 : 32))) {
+    if (nt == 2 && (a.N % 32 != 0 || spg == 1 || bits != 4 || a.M > (spg == 4 ? 64 : 32))) {
         if (a.tuning[1] == 2) return false;
         nt = 1;
     }
     if (a.tuning[1] < 0 || a.tuning[1] > 2) return false;
-    const int mt_cap = spg == 1 ? 2 : 4;  // row tiles per block; more rows: blocks along grid.y (the weights stream once per block row)
+    // row tiles per block (registers); more rows: blocks along grid.y (the weights stream once per block row)
+    const int mt_cap = bits == 4 ? (spg == 1 ? 2 : 4) : (spg == 4 ? 4 : (spg == 2 ? 2 : 1));
     const int mt = a.M > 16 * mt_cap ? mt_cap : (int)((a.M + 15) / 16);
     if ((a.M + 16 * mt - 1) / (16 * mt) > 65535) return false;
     if (a.tuning[2] != 0 && a.tuning[2] != 8) return false;
     const bool f16 = a.input_dtype == GEMLITE_DT_FP16;
-    const rows5_fn fn = f16 ? rows5_pick<half_tag>(mt, spg, nt) : rows5_pick<bf16_tag>(mt, spg, nt);
+    const rows5_fn fn = f16 ? rows5_pick<half_tag>(mt, spg, nt, bits) : rows5_pick<bf16_tag>(mt, spg, nt, bits);
     if (!fn) return false;
     const int nw = rows5::NW;
     const int tiles = (int)(a.N / (16 * nt));
@@ -395,7 +425,8 @@ bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPla
     lp.fn = (const void*)fn;
     static const char* names[4] = {"gemm_w4_rows_kernel<16x16>", "gemm_w4_rows_kernel<32x16>", "gemm_w4_rows_kernel<48x16>", "gemm_w4_rows_kernel<64x16>"};
     static const char* names2[4] = {"gemm_w4_rows_kernel<16x32>", "gemm_w4_rows_kernel<32x32>", "gemm_w4_rows_kernel<48x32>", "gemm_w4_rows_kernel<64x32>"};
-    lp.name = nt == 2 ? names2[mt - 1] : names[mt - 1];
+    static const char* names_w2[4] = {"gemm_w2_rows_kernel<16x16>", "gemm_w2_rows_kernel<32x16>", "gemm_w2_rows_kernel<48x16>", "gemm_w2_rows_kernel<64x16>"};
+    lp.name = bits == 2 ? names_w2[mt - 1] : (nt == 2 ? names2[mt - 1] : names[mt - 1]);
     lp.grid = dim3((unsigned)tiles, (unsigned)((a.M + 16 * mt - 1) / (16 * mt)), 1);
     lp.block = dim3(64 * nw, 1, 1);
     lp.lds_bytes = (size_t)rows5::WAVE_LDS * nw;

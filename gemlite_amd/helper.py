@@ -561,6 +561,8 @@ def autotune_layer(layer: GemLiteLinear, batch_sizes=(1,), iters: int = 50, cand
             # and the unsplit 128 x 128 tiles of unpacked 8-bit layers ([0] = 10; [2] = stages)
             if layer.W_nbits == 4 and layer.elements_per_sample == 8 and not layer.scaled_activations:
                 cands += [(9, 0, 0, 0), (9, 1, 0, 0), (9, 2, 0, 0)]
+            if layer.W_nbits == 2 and layer.elements_per_sample == 16 and not layer.scaled_activations:
+                cands += [(9, 0, 0, 0)]
             if layer.elements_per_sample == 1 and layer.scaled_activations and M > 64:
                 cands += [(10, 0, 0, 0), (10, 0, 5, 0)]
         for cand in cands:

@@ -177,9 +177,9 @@ typedef struct gemlite_hip_forward_args {
      *   few rows (2..32, MFMA)     [0] 1/2/4 = 16-/32-/64-column tiles, 3 = the 8-wave tiled kernel instead
      *                              [1] K slices   [2] 1 = LDS-staged streaming kernel, 4 / 8 = waves per block of the registers-only
      *                              kernel (8: one row tile, >= 32-column tiles; default with two K slices)
-     *   decode batch (2..64 rows, 4-bit words under 16-bit activations; round 5: gemm_w4_rows_kernel, 16-column blocks, K unsplit,
+     *   decode batch (2..64 rows, 4- and 2-bit words under 16-bit activations; round 5: gemm_w{4,2}_rows_kernel, 16-column blocks, K unsplit,
      *                              raw integer codes through the MFMA)   [0] 9 = at any M >= 2 the kernel takes (row blocks along
-     *                              grid.y above 16 MT rows; [2] must be 0 or 8); default for 2..64 rows where N / 16 blocks are
+     *                              grid.y above 16 MT rows; [2] must be 0 or 8; [1] = 1 / 2 column tiles per block, 4-bit); default for 2..64 rows where N / 16 blocks are
      *                              resident in one round and the x re-reads stay <= 176 MiB, and ALWAYS for group size 32 and
      *                              N % 64 != 0 (no other MFMA kernel takes them)   [3] & 65536 = never (the round-4 choice, A/B runs)
      *   tiled (M > 32, MFMA)       [0] 1 = streaming kernel, 2 = the 4-wave tiled kernel of round 1 (4-bit only; the planner's

@@ -77,7 +77,7 @@ for (N, K) in SHAPES:
         res, names = {}, {}
         for label, t in CANDS.items():
             kn = kname(mods[0], x, t)
-            if label.startswith("rows5") and not kn.startswith("gemm_w4_rows_kernel"):
+            if label.startswith("rows5") and "_rows_kernel" not in kn:
                 continue
             try:
                 res[label] = round(time_us(mods, x, t), 2)

@@ -698,10 +698,11 @@ def test_direct_mfma_kernel_group_size_64(nbits, tdt):
             y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
             torch.cuda.synchronize()
             _compare(f"direct-g64/w{nbits}/{str(tdt)[6:]}/M{M}/{tuning}", y, y_or, lin.output_dtype.value)
-    # 17 .. 32 rows: round 5 sends them to the rows kernel (4-bit) / the 32-row MFMA tiles, no longer to the LDS-staged streaming kernel
+    # 17 .. 32 rows: round 5 sends them to the rows kernel (where it does not pay: the 32-row MFMA tiles), no longer to the LDS-staged streaming kernel
     x = torch.from_numpy(O.gen_x(24, 4096, seed=3).astype(np.float32)).to(tdt).to(DEV)
     name = _kernel_name(lin, x)
-    assert name.startswith("gemm_w4_rows_kernel" if nbits == 4 else "gemm_w2_mma_kernel<32x128>"), name
+    assert name.startswith("gemm_w4_rows_kernel" if nbits == 4 else "gemm_w2_rows_kernel"), name
+    assert _kernel_name(lin, x, -1, (3, 0, 0, 65536)).startswith("gemm_w%d_mma_kernel<32x128>" % nbits)
     for tuning in ((0, 0, 0, 0), (3, 0, 0, 65536), (0, 0, 0, 65536)):
         y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
         torch.cuda.synchronize()
@@ -1643,6 +1644,41 @@ def test_rows5_kernel_row_tiles_and_group_sizes(gs, tdt):
             y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 3, tuning)
             torch.cuda.synchronize()
             _compare(f"rows5/g{gs}/{str(tdt)[6:]}/M{M}/{tuning}", y, y_or, lin.output_dtype.value, extra=dict(kernel=name))
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("gs", [128, 64, 32, 1024, 2048])
+def test_rows5_kernel_two_bit_words(gs, tdt):
+    """The rows kernel on 2-bit words (A16W2, BitNet A16W158; late round 5): a chunk is 512 k = sixteen k-steps, each lane spreads its half of a
+    word to eight nibbles.  Every row-tile count the group size allows (64 / 32 / 16 rows per block, more along grid.y), ragged M, K of four
+    chunks (half of the waves idle) and of 10 (two waves with a second chunk) — against the oracle; and what the planner does by default:
+    groups of 32 and N % 64 != 0 at M >= 2 come here instead of the coverage kernel."""
+    from gemlite_amd.core import _hip_matmul
+    for (N, K) in ((1024, 2048), (528, 5120)):
+        if K % gs:
+            continue
+        lin = _make_layer(N, K, 2, gs, tdt, seed=60 + gs % 7, scales_kind="group" if gs < K else "channel")
+        for M in (2, 5, 16, 17, 31, 33, 48, 64, 100):
+            x = torch.from_numpy(O.gen_x(M, K, seed=M + 13).astype(np.float32)).to(tdt).to(DEV)
+            name = _kernel_name(lin, x, 3, ROWS5)
+            assert name.startswith("gemm_w2_rows_kernel<"), (name, M, gs)
+            y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 3, ROWS5)
+            torch.cuda.synchronize()
+            _compare(f"rows5-w2/{N}x{K}g{gs}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x), lin.output_dtype.value, extra=dict(kernel=name))
+            if gs == 32 or N % 64 != 0:
+                assert _kernel_name(lin, x).startswith("gemm_w2_rows_kernel<"), (M, _kernel_name(lin, x))
+
+
+@pytest.mark.parametrize("zeros_kind,fma,scales_kind", [("tensor", False, "group"), ("none", True, "group"), ("int", True, "group"), ("tensor", True, "channel")])
+def test_rows5_kernel_two_bit_words_all_modes(zeros_kind, fma, scales_kind):
+    from gemlite_amd.core import _hip_matmul
+    lin = _make_layer(2048, 4096, 2, 128 if scales_kind == "group" else 4096, torch.float16, seed=6, zeros_kind=zeros_kind, fma=fma, scales_kind=scales_kind)
+    for M in (6, 24, 56):
+        x = torch.from_numpy(O.gen_x(M, 4096, seed=M).astype(np.float32)).half().to(DEV)
+        assert _kernel_name(lin, x, -1, ROWS5).startswith("gemm_w2_rows_kernel<"), _kernel_name(lin, x, -1, ROWS5)
+        y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, ROWS5)
+        torch.cuda.synchronize()
+        _compare(f"rows5-w2-modes/{zeros_kind}-{fma}-{scales_kind}/M{M}", y, _oracle_from_layer(lin, x), lin.output_dtype.value)
 
 
 @pytest.mark.parametrize("zeros_kind,fma,scales_kind", [("tensor", False, "group"), ("none", True, "group"),

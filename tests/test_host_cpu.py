@@ -129,7 +129,8 @@ def test_struct_abi_and_validation():
     (dict(M=8, gs=64), "gemm_w4_rows_kernel<16x16>"),
     (dict(M=24, gs=64, tuning=(0, 0, 0, 65536)), "gemm_wn_stream_kernel"),          # ... LDS-staged streaming kernel for 17..32 (the round-4 choice)
     (dict(M=24, gs=64, N=11008, K=4096), "gemm_w4_mma_kernel<32x128>"),             # round 5: ... where the rows kernel does not pay, the 32-row MFMA tiles (31.6 -> 16.6 us), not the streaming kernel
-    (dict(M=24, gs=64, nbits=2), "gemm_w2_mma_kernel<32x128>"),                     # ... 2-bit too (16.4 -> 12.0 us)
+    (dict(M=24, gs=64, nbits=2), "gemm_w2_rows_kernel<32x16>"),                     # ... 2-bit: 16.4 -> 12.0 us on the MFMA tiles, then 7.8 on the rows kernel (late round 5)
+    (dict(M=24, gs=64, nbits=2, N=11008, K=4096), "gemm_w2_mma_kernel<32x128>"),    # ... where the rows kernel does not pay: the 32-row MFMA tiles (31.4 -> 22.6 us)
     (dict(M=24, gs=64, N=1024, K=4096), "gemm_w4_rows_kernel<32x16>"),              # ... small N: the rows kernel (18.8 -> 8.1 us)
     (dict(M=24, gs=64, N=8960, K=1536), "gemm_wn_stream_kernel"),                   # ... a short K keeps the streaming kernel (10.6 vs 11.1 us)
     (dict(M=24, gs=64), "gemm_w4_rows_kernel<32x16>"),
@@ -141,7 +142,8 @@ def test_struct_abi_and_validation():
     (dict(M=8, N=11008, K=4096), "gemm_wn_direct_kernel<tile64>"),   # wide N: 64-column tiles, K not split
     (dict(M=48, mt=3, tuning=(0, 0, 0, 65536)), "gemm_wn_stream_kernel"),      # manual GEMM_SPLITK at 33..64 rows: LDS-staged streaming kernel (the round-4 choice)
     (dict(M=48, mt=3), "gemm_w4_rows_kernel<48x16>"),      # round 5: the rows kernel IS the GEMM_SPLITK family's kernel at 4096^2
-    (dict(M=48, nbits=2), "gemm_w2_mma_kernel<64x64>"),   # every bit width has the tiled MFMA kernel  [round 4, late: narrow 64 x 64 tiles]
+    (dict(M=48, nbits=2), "gemm_w2_rows_kernel<48x16>"),   # late round 5: the rows kernel on 2-bit words (12.2 -> 8.8 us)
+    (dict(M=48, nbits=2, tuning=(0, 0, 0, 65536)), "gemm_w2_mma_kernel<64x64>"),   # (the round-4 choice)
     (dict(M=48, nbits=1), "gemm_w1_mma_kernel<64x128>"),
     (dict(M=200, nbits=8), "gemm_w8_mma_kernel<64x128>"),   # tallest tile with >= 128 tiles: at most two K slices
     (dict(M=48, tuning=(1, 0, 0, 0)), "gemm_wn_stream_kernel"),          # tuning[0] = 1: LDS-staged streaming kernel
