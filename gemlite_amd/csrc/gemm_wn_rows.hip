@@ -51,7 +51,7 @@ __device__ __forceinline__ f32x4 mfma16<bf16_tag>(u32x4 a, u32x4 b, f32x4 c) {
 }
 
 // modes: bits 0..3 W_group_mode | 4 zero_is_scalar | 5 pair the half-line tiles on one XCD | 7 channel scales (sp) in the epilogue | 8..15 log2(group)
-constexpr uint32_t M_ZSCALAR = 16u, M_PAIR = 32u, M_POST = 128u;
+constexpr uint32_t M_ZSCALAR = 16u, M_PAIR = 32u, M_POST32 = 64u, M_POST = 128u;  // (M_POST32: the epilogue's channel scales are fp32 — BitNet A16W158)
 constexpr int NW = 8;                              // waves per block
 constexpr int WSLOT_I1 = 272;                      // dword offset of the odd packed rows inside a wave's weight slot (16 dwords of padding: see below)
 constexpr int WSLOT_BYTES = 2304;                  // >= (WSLOT_I1 + 256) * 4
@@ -319,10 +319,16 @@ __global__ __launch_bounds__(rows5::NW * 64, 1) void gemm_w4_rows_kernel(const c
             v0 += pv.x;
             v1 += pv.y;
         }
-        if (modes & M_POST) {  // channel scales of the kernel's 16-bit type (channel_scale_mode 1)
-            const uint32_t sw = *(const uint32_t*)(sp + (size_t)(tile * TCN + cp * 2) * 2);
-            v0 *= TR::to_float((uint16_t)(sw & 0xFFFFu));
-            v1 *= TR::to_float((uint16_t)(sw >> 16));
+        if (modes & M_POST) {  // channel scales (channel_scale_mode 1): the kernel's 16-bit type, or fp32 (the BitNet processors' default)
+            if (modes & M_POST32) {
+                const float2 sw = *(const float2*)(sp + (size_t)(tile * TCN + cp * 2) * 4);
+                v0 *= sw.x;
+                v1 *= sw.y;
+            } else {
+                const uint32_t sw = *(const uint32_t*)(sp + (size_t)(tile * TCN + cp * 2) * 2);
+                v0 *= TR::to_float((uint16_t)(sw & 0xFFFFu));
+                v1 *= TR::to_float((uint16_t)(sw >> 16));
+            }
         }
         if (m < M) *(uint32_t*)(out + (size_t)m * som + (size_t)(tile * TCN + cp * 2)) = (uint32_t)TR::from_float(v0) | ((uint32_t)TR::from_float(v1) << 16);
     }
@@ -384,7 +390,8 @@ bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPla
     // channel scales (mode 1) of the kernel's 16-bit type ride in the epilogue — then nothing in the K loop reads scales (W_group_mode 0 / 1)
     const bool post_s = a.channel_scale_mode == 1;
     if (a.channel_scale_mode != 0 && !post_s) return false;
-    if (post_s && (a.W_group_mode >= 2 || a.meta_dtype != a.input_dtype || !a.scales || ((uintptr_t)a.scales % 4) != 0)) return false;
+    const bool post32 = post_s && a.meta_dtype == GEMLITE_DT_FP32;
+    if (post_s && (a.W_group_mode >= 2 || (a.meta_dtype != a.input_dtype && !post32) || !a.scales || ((uintptr_t)a.scales % (post32 ? 8 : 4)) != 0)) return false;
     const bool loop_s = a.W_group_mode >= 2, has_z = (a.W_group_mode == 1 || a.W_group_mode >= 3);
     if (loop_s && a.meta_dtype != a.input_dtype) return false;
     if (has_z && !a.zero_is_scalar && a.zeros_dtype != a.input_dtype) return false;
@@ -441,7 +448,7 @@ bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPla
     lp.r5.sw4 = (uint32_t)a.stride_wk * 4u;
     lp.r5.mstride2 = ((need_s || need_z) && p.gs_shift < 31) ? (uint32_t)p.stride_meta_g * 2u : 0u;
     lp.r5.nch_total = (int)(rows / 32);
-    lp.r5.modes = (uint32_t)a.W_group_mode | ((has_z && a.zero_is_scalar) ? 16u : 0u) | ((nt == 1 && (tiles & 15) == 0) ? 32u : 0u) | (post_s ? 128u : 0u) | ((uint32_t)p.gs_shift << 8);
+    lp.r5.modes = (uint32_t)a.W_group_mode | ((has_z && a.zero_is_scalar) ? 16u : 0u) | ((nt == 1 && (tiles & 15) == 0) ? 32u : 0u) | (post_s ? 128u : 0u) | (post32 ? 64u : 0u) | ((uint32_t)p.gs_shift << 8);
     lp.r5.M = (int)a.M;
     lp.r5.sxm2 = (uint32_t)a.stride_xm * 2u;
     lp.r5.som = (uint32_t)a.stride_om;

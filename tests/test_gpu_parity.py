@@ -1669,6 +1669,25 @@ def test_rows5_kernel_two_bit_words(gs, tdt):
                 assert _kernel_name(lin, x).startswith("gemm_w2_rows_kernel<"), (M, _kernel_name(lin, x))
 
 
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_rows5_kernel_bitnet_fp32_post_scale(tdt):
+    """BitNet A16W158 (ternary weights as 2-bit codes, scalar zero 1, ONE fp32 scale applied per output channel after the K reduction —
+    modes (1, 1) with fp32 metadata): the rows kernel's epilogue reads fp32 channel scales, so 2 .. 64 rows of a 4096-wide BitNet layer
+    run on it by default."""
+    H = gemlite_amd.helper
+    g = torch.Generator().manual_seed(77)
+    N, K = 4096, 2048
+    Wt = torch.randint(-1, 2, (N, K), generator=g).to(tdt)
+    lin = H.A16W158_INT(device=DEV, dtype=tdt).from_weights(Wt, torch.tensor(0.02))
+    for M in (8, 16, 40, 64):
+        x = (torch.randn(M, K, generator=g) / 10).to(tdt).to(DEV)
+        name = _kernel_name(lin, x)
+        assert name.startswith("gemm_w2_rows_kernel<"), (M, name)
+        y = lin(x)
+        torch.cuda.synchronize()
+        _compare(f"rows5-bitnet/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x), lin.output_dtype.value, extra=dict(kernel=name))
+
+
 @pytest.mark.parametrize("zeros_kind,fma,scales_kind", [("tensor", False, "group"), ("none", True, "group"), ("int", True, "group"), ("tensor", True, "channel")])
 def test_rows5_kernel_two_bit_words_all_modes(zeros_kind, fma, scales_kind):
     from gemlite_amd.core import _hip_matmul

@@ -256,8 +256,10 @@ def test_struct_abi_and_validation():
     (dict(M=1, in_dt=8, out_dt=1, meta_dt=1, zeros_dt=1, w_mode=3, c_mode=2), "generic_matmul_kernel"),   # e5m2 activations: coverage kernel
     # 16-bit activations whose output / channel-scale type differs (BitNet A16W158 with its fp32 scale; fp32 output)
     (dict(M=1, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemv_w2_mfma_kernel<tile16>"),   # round 4: fp32 post-scale in the GEMV epilogue
-    (dict(M=8, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_wn_direct_kernel<tile32,8w>"),  # ... and in the few-row kernels
-    (dict(M=64, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_w2_mma_kernel<64x64>"),  # round 4, late: narrow 64 x 64 tiles where narrow_auto() fires
+    (dict(M=8, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_w2_rows_kernel<16x16>"),  # ... late round 5: the rows kernel reads fp32 channel scales in its epilogue
+    (dict(M=8, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096, tuning=(0, 0, 0, 65536)), "gemm_wn_direct_kernel<tile32,8w>"),  # (round 4: the few-row kernels)
+    (dict(M=64, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096), "gemm_w2_rows_kernel<64x16>"),
+    (dict(M=64, nbits=2, in_dt=1, meta_dt=0, zeros_dt=6, zero_scalar=1, w_mode=1, c_mode=1, gs=4096, tuning=(0, 0, 0, 65536)), "gemm_w2_mma_kernel<64x64>"),  # round 4, late: narrow 64 x 64 tiles where narrow_auto() fires
     (dict(M=64, in_dt=1, out_dt=0), "gemm_w4_mma_kernel<64x64>"),  # round 4, late: narrow 64 x 64 tiles where narrow_auto() fires
 ])
 def test_kernel_selection(kw, kernel):
