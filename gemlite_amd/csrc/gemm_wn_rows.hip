@@ -1,5 +1,7 @@
-// gemm_wn_rows.hip — 2 .. 64 activation rows x packed 4-bit weights (round 5): the batched-decode regime, shaped like the M = 1
-// decode kernel of gemv_decode.hip instead of like a GEMM tile.
+// gemm_wn_rows.hip — 2 .. 64 activation rows x packed 4-bit (and, late in the round, 2-bit) weights (round 5): the batched-decode regime,
+// shaped like the M = 1 decode kernel of gemv_decode.hip instead of like a GEMM tile.  Template forms: MT = 1 .. 4 row tiles of 16, SPG = group
+// size class (128+ / 64 / 32), NT = 1 / 2 column tiles per block (4096 < N <= 8192), BITS = 4 / 2; epilogue channel scales in the 16-bit
+// type or fp32 (BitNet).  Experiments that did NOT ship are in profiles/r05/probe_rows5_*_slower.log.
 //
 // Replaces gemm_splitK_INT_kernel (gemlite/triton_kernels/gemm_splitK_kernels.py:277-450) for the decode-batch sizes where
 // rounds 2-4 paid either a cross-block K-slice combine (gemm_wn_direct.hip: 32- / 64-column tiles x 2 slices, 7.4 us at 4096^2 M = 16)
