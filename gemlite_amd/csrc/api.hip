@@ -802,7 +802,7 @@ extern "C" {
 int gemlite_hip_abi_version(void) { return GEMLITE_HIP_ABI_VERSION; }
 
 const char* gemlite_hip_build_info(void) {
-    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemv_decode, gemv_mfma, gemv_a8wn, gemm_wn_direct, gemm_wn_stream, gemm_wn_mma, gemm_wn_tiled, gemm_a8w8, "
+    return "libgemlite_hip gfx950 (CDNA4) abi=1 kernels: gemv_wn, gemv_decode, gemv_mfma, gemv_a8wn, gemm_wn_rows, gemm_wn_direct, gemm_wn_stream, gemm_wn_mma, gemm_wn_tiled, gemm_a8w8, "
            "gemm_mx, mx_rows, nvfp4_f16, kmajor, generic, act_quant_per_token, act_quant_mx, pack/unpack_over_cols"
 #ifdef GL_AB_KERNELS
            " +ab_kernels"
