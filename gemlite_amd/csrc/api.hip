@@ -479,11 +479,11 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
             plan_gemv_a8wn(a, p, lp)) {
             r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return;
         }
-        // round 5: 2 .. 64 rows of 16-bit activations x 4-bit words on the decode-shaped MFMA rows kernel (gemm_wn_rows.hip): 16-column
-        // blocks, K unsplit, weights requested first, x fragments straight from L2.  Every block re-reads all of x (M K 2 bytes through the
-        // CU's 64 B/clk address path), so the default stops at a budget on that traffic; groups of 32 and N % 64 != 0 — which no other
-        // specialised kernel takes at M >= 2 — always come here (any M: 64-row blocks along grid.y).  tuning[0] = 9 forces the kernel,
-        // tuning[3] & 65536 keeps the round-4 choice (A/B runs).
+        // round 5: 2 .. 64 rows of 16-bit activations x 4- / 2-bit words on the decode-shaped MFMA rows kernel (gemm_wn_rows.hip): 16-column
+        // blocks, K unsplit, weights requested first, x through LDS in whole cache lines.  Every block re-reads all of x (M K 2 bytes through
+        // the CU's L2 -> LDS path), so the default stops at a budget on that traffic; groups of 32 and N % 64 != 0 — which no other
+        // specialised kernel takes at M >= 2 — always come here (any M: row blocks along grid.y).  tuning[0] = 9 forces the kernel
+        // (tuning[1] = 1 / 2 column tiles per block), tuning[3] & 65536 keeps the round-4 choice (A/B runs).
         if (x16 && (a.W_nbits == 4 || a.W_nbits == 2) && (mt == GEMLITE_MATMUL_AUTO || mt == GEMLITE_MATMUL_GEMM_SPLITK || (mt == GEMLITE_MATMUL_GEMM && a.tuning[0] == 9)) &&
             !(a.tuning[3] & 65536) && (a.tuning[0] == 9 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && a.M >= 2))) {
             const bool only_here = p.gs_shift == 5 || a.N % 64 != 0;  // nothing but the coverage kernel behind this one
