@@ -864,3 +864,40 @@ def test_tuning_table_mutations_bump_the_epoch_of_the_cpp_fast_path():
     finally:
         core.GemLiteLinear.reset_config()
     assert core._CACHE_EPOCH[0] > e3 and not core.GEMLITE_HIP_CONFIG_CACHE
+
+
+def test_rows_kernel_bit_tricks_restate_natural_k_order():
+    """The integer identities gemm_wn_rows.hip builds its MFMA B fragments with, restated in numpy: (i) a 16-bit half of a 2-bit word spread to
+    eight nibbles by three shift-or + and steps holds q0 .. q7 in order; (ii) t_lo / t_hi + the byte selectors 0x0C040C00 + p * 0x00010001 of
+    v_perm_b32, OR-ed with the magic halves, give the fp16 / bf16 codes OFF + q_2p, OFF + q_2p+1 of pair p — k in natural order, which is
+    why the A fragment is x as it lies in memory."""
+    rng = np.random.default_rng(3)
+    halves = rng.integers(0, 1 << 16, size=4096, dtype=np.uint64)
+    w = halves.copy()
+    w = (w | (w << 8)) & 0x00FF00FF
+    w = (w | (w << 4)) & 0x0F0F0F0F
+    w = (w | (w << 2)) & 0x33333333
+    for i in range(8):
+        assert np.array_equal((w >> (4 * i)) & 0xF, (halves >> (2 * i)) & 0x3), i
+
+    def v_perm(s0, s1, sel):  # byte k of the result = byte sel_k of the 8-byte value {s0 (bytes 4..7), s1 (bytes 0..3)}; selector 0x0C = 0x00
+        src = [(s1 >> (8 * b)) & 0xFF for b in range(4)] + [(s0 >> (8 * b)) & 0xFF for b in range(4)]
+        out = np.zeros_like(s0)
+        for k in range(4):
+            sk = (sel >> (8 * k)) & 0xFF
+            out |= (np.zeros_like(s0) if sk == 0x0C else src[sk]) << (8 * k)
+        return out
+
+    words = rng.integers(0, 1 << 32, size=4096, dtype=np.uint64)
+    t_lo, t_hi = words & 0x0F0F0F0F, (words >> 4) & 0x0F0F0F0F
+    for magic, off in ((0x64006400, 1024), (0x43004300, 128)):
+        for p_ in range(4):
+            frag = v_perm(t_hi, t_lo, 0x0C040C00 + p_ * 0x00010001) | magic
+            lo, hi = frag & 0xFFFF, frag >> 16
+            q0, q1 = (words >> (8 * p_)) & 0xF, (words >> (8 * p_ + 4)) & 0xF
+            if off == 1024:   # fp16: 0x6400 | q = 1024 + q exactly
+                assert np.array_equal(lo.astype(np.uint16).view(np.float16).astype(np.float64), 1024.0 + q0)
+                assert np.array_equal(hi.astype(np.uint16).view(np.float16).astype(np.float64), 1024.0 + q1)
+            else:             # bf16: 0x4300 | q = 128 + q exactly (the upper half of the fp32 pattern)
+                assert np.array_equal((lo.astype(np.uint32) << 16).view(np.float32).astype(np.float64), 128.0 + q0)
+                assert np.array_equal((hi.astype(np.uint32) << 16).view(np.float32).astype(np.float64), 128.0 + q1)
