@@ -343,12 +343,21 @@ static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
 //     (5.4 / 6.4 / 8.9 / 9.8 -> 4.4 / 4.5 / 5.5 / 7.1; 2 - 4 rows lose 0.1 - 0.3); 4096 x 14336 up to 32 rows (M = 32: 21.4 -> 17.8; 48 / 64 lose);
 //     2048 x 8192 16 .. 32 rows (9.9 / 13.7 -> 9.0 / 11.5); groups of 64 hold 32 rows per block (M = 64 along grid.y loses: 11.6 -> 13.7);
 //     one column tile per block only (N <= 4096).
+//   * narrow layers (64 <= N / 16 < 192 tiles: the k / v projections of grouped-query models; probe_rows5_narrow_layers.log, 4-bit / 2-bit):
+//     K <= 4096 from 8 rows (1024 x 4096 M = 16 / 32 / 64: 7.2 / 10.7 / 12.7 -> 6.3 / 7.7 / 10.6; 2-bit 6.8 / 10.4 / 12.7 -> 5.7 / 6.8 / 9.6;
+//     1536 x 4096 the same), K <= 2048 from 4 (1024 x 2048 M = 32 / 64: 8.8 / 10.6 -> 5.0 / 6.7); a longer K only where the registers-only
+//     kernel's K-slice combine ends: 16 (128 tiles) / 17 .. 32 rows (1024 x 8192 M = 32: 15.4 -> 12.3; M = 8 / 16 / 64 lose 0.6 - 0.8 us)
+static bool rows5_narrow_layer_pays(int64_t M, int64_t tiles, int64_t K) {
+    if (tiles < 64) return false;
+    if (K <= 4096) return M >= (K <= 2048 ? 4 : 8);
+    return M >= (tiles >= 128 ? 16 : 17) && M <= 32;
+}
 static bool rows5_pays_w2(int64_t M, int64_t N, int64_t K, int gs_shift) {
     if (M < 2 || M > 64 || N % 16 != 0 || K % 512 != 0 || K > 16384) return false;
     const int64_t tiles = N / 16;
     if (tiles > gl::resident_block_limit()) return false;
     const bool g64_two_tiles = gs_shift == 6 && M >= 17 && M <= 32;
-    if (tiles < (g64_two_tiles ? 32 : ((M >= 16 && M <= 32) ? 128 : 192))) return false;
+    if (tiles < 192 && !(g64_two_tiles && tiles >= 32) && !rows5_narrow_layer_pays(M, tiles, K)) return false;
     if (gs_shift == 6 && M > 32) return false;
     if (gs_shift < 6) return false;  // (groups of 32: 16 rows per block — only where nothing else applies)
     if (M < (K <= 2048 ? 8 : 2)) return false;
@@ -366,7 +375,7 @@ static bool rows5_pays(int64_t M, int64_t N, int64_t K, int gs_shift) {
     }
     // groups of 64 at 17 .. 32 rows have no registers-only kernel behind them (only the 32-row MFMA tiles: 1024 x 4096 11.8 vs 7.8 us here)
     const bool g64_two_tiles = gs_shift == 6 && M >= 17 && M <= 32;
-    if (tiles < (g64_two_tiles ? 32 : ((M >= 16 && M <= 32) ? 128 : 192))) return false;  // (2048 x 8192: M = 16 / 32 win, M = 64 loses)
+    if (tiles < 192 && !(g64_two_tiles && tiles >= 32) && !rows5_narrow_layer_pays(M, tiles, K)) return false;
     const int64_t min_m = (K > 2048 && K <= 4096) ? 8 : 2;
     if (M < min_m) return false;
     return tiles * ((M + 15) / 16 * 16) * K * 2 <= (176ll << 20);
