@@ -750,11 +750,22 @@ def test_remaining_helper_processors_against_the_oracle(M):
     y = lin(x)
     torch.cuda.synchronize()
     # fp32 channel scale: at M = 1 the GEMV family (its epilogue reads any float scale type, round 4), above it the untyped epilogue of the tile kernel
-    assert _kernel_name(lin, x).startswith(("gemv_wn_kernel<tile", "gemv_w2_mfma_kernel<tile") if M == 1 else "gemm_wn_direct_kernel<tile"), _kernel_name(lin, x)
+    # (late round 5: from 8 rows of this narrow layer the rows kernel, whose epilogue reads fp32 channel scales too; tuning[3] & 65536 = round 4)
+    assert _kernel_name(lin, x).startswith(("gemv_wn_kernel<tile", "gemv_w2_mfma_kernel<tile") if M == 1 else ("gemm_wn_direct_kernel<tile", "gemm_w2_rows_kernel<")), _kernel_name(lin, x)
+    if M > 1:
+        assert _kernel_name(lin, x, -1, (0, 0, 0, 65536)).startswith("gemm_wn_direct_kernel<tile"), _kernel_name(lin, x, -1, (0, 0, 0, 65536))
     # ... and the tile kernel's untyped epilogue above 32 rows
     x64 = (torch.randn(64, K) / 10).half().to(DEV)
-    assert _kernel_name(lin, x64).startswith("gemm_w2_mma_kernel<"), _kernel_name(lin, x64)
+    assert _kernel_name(lin, x64, -1, (0, 0, 0, 65536)).startswith("gemm_w2_mma_kernel<"), _kernel_name(lin, x64, -1, (0, 0, 0, 65536))
     _compare(f"helpers/a16w158/M64", lin(x64), _oracle_from_layer(lin, x64), 1)
+    gemlite_amd.core.TUNING_OVERRIDE = (0, 0, 0, 65536)
+    try:
+        y64_r4, y_r4 = lin(x64), lin(x)
+    finally:
+        gemlite_amd.core.TUNING_OVERRIDE = None
+    torch.cuda.synchronize()
+    _compare(f"helpers/a16w158/M64/r4", y64_r4, _oracle_from_layer(lin, x64), 1)
+    _compare(f"helpers/a16w158/M{M}/r4", y_r4, _oracle_from_layer(lin, x), 1)
     _compare(f"helpers/a16w158/M{M}", y, _oracle_from_layer(lin, x), 1, extra=dict(kernel=_kernel_name(lin, x)))
 
 
