@@ -371,17 +371,30 @@ class Runner:
         return out
 
 
-def _committed(fname, name):
-    """Per-workload figure from a committed profile summary under profiles/ (PMC passes are separate runs), or None."""
+def _committed(fname, name, kernel):
+    """Per-workload figure from a committed profile summary under profiles/ (PMC passes are separate runs), or None.  Every entry is
+    stamped (`_stamp[name] = {kernel, commit}`, written by scripts/pmc_official.py) with the planner's kernel name it was collected on:
+    when the planner now picks another kernel for the workload the committed counter is STALE and the line says null instead."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", fname))).get(name)
+        d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        st = d.get("_stamp", {}).get(name)
+        if st is None or st.get("kernel") != kernel:
+            return None
+        return d.get(name)
     except Exception:
         return None
 
 
-def _traffic(name):
-    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), or None."""
-    return _committed("pmc_traffic.json", name)
+def _traffic(name, kernel):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), or None (absent, or taken on another kernel)."""
+    return _committed("pmc_traffic.json", name, kernel)
+
+
+def _counter_commit(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("_stamp", {}).get(name, {}).get("commit")
+    except Exception:
+        return None
 
 
 def event_clock_floor_us(lib, stream, samples=64):
@@ -489,8 +502,9 @@ def main():
     if bound == "hbm":
         roof["frac_vs_measured_copy_6290"] = round(roof["achieved"] / 6290.0, 4)
     else:
-        roof["mfma_util"] = _committed("mfma_util.json", name)
-    roof["traffic"] = _traffic(name)
+        roof["mfma_util"] = _committed("mfma_util.json", name, roof["kernel"])
+    roof["traffic"] = _traffic(name, roof["kernel"])
+    roof["traffic_commit"] = _counter_commit(name) if roof["traffic"] is not None else None
 
     metric = ("HBM GB/s (algorithmic bytes) vs roofline at M=1 [value], TFLOP/s vs bf16 MFMA roofline at M=256 [roofline.m256]; "
               "A16W4 gs=128 4096x4096" if name == "a16w4_4096_m1" else f"{unit} {name}")
@@ -522,9 +536,9 @@ def main():
             if e2e:
                 out["what"] = ("layer(x) on fp16 x, dynamic per-token quantisation included: " +
                                ("ONE fused launch" if r.M == 1 else "quantiser launch + matmul launch; kernel_us is the time of the pair"))
-            out["traffic"] = _traffic(wname)
+            out["traffic"] = _traffic(wname, out["kernel"])
             if out["bound"] == "mfma":
-                out["mfma_util"] = _committed("mfma_util.json", wname)
+                out["mfma_util"] = _committed("mfma_util.json", wname, out["kernel"])
             del r
             torch.cuda.empty_cache()
             return out
@@ -581,11 +595,28 @@ def main():
             full["sustained"] = dict(roof["sustained"], launches=nl, unit="GB/s")
         except Exception as e:
             print(f"[bench] eager / sustained legs failed: {type(e).__name__}: {e}", file=sys.stderr)
-        # the M = 256 half and the M = 1 core fields go to the END of `roofline` (dicts keep insertion order)
-        for k in ("fewrows", "m256", "bound", "kernel", "kernel_us", "achieved", "peak", "unit", "frac", "empty_launch_us",
-                  "kernel_us_minus_empty_launch", "traffic"):
+        # Key order of `roofline` (schema 6): the driver's parsed record keeps the FIRST 12 scalar keys of the object and the tail of the
+        # printed line.  So the 12 scalars that carry both halves of BASELINE's metric come first — the M = 1 core (bound, achieved, peak,
+        # unit, frac, traffic, kernel_us, empty_launch_us) and the M = 256 pair as flat scalars — then the other scalars, then the nested
+        # groups in reverse order of importance (`fewrows` and `m256` last: they survive a tail cut).
+        m256 = roof.get("m256", {})
+        flat = {"m256_cfgA_us": m256.get("cfgA_4096", {}).get("kernel_us"), "m256_cfgA_frac": m256.get("cfgA_4096", {}).get("frac"),
+                "m256_cfgB_us": m256.get("cfgB_8192", {}).get("kernel_us"), "m256_cfgB_frac": m256.get("cfgB_8192", {}).get("frac")}
+        first = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_us", "empty_launch_us")
+        ordered = {k: roof.get(k) for k in first}
+        ordered.update(flat)
+        ordered["schema"] = 6
+        for k, v in roof.items():  # remaining scalars, then the nested groups
+            if k not in ordered and not isinstance(v, dict):
+                ordered[k] = v
+        for k, v in roof.items():
+            if k not in ordered and k not in ("fewrows", "m256"):
+                ordered[k] = v
+        for k in ("fewrows", "m256"):
             if k in roof:
-                roof[k] = roof.pop(k)
+                ordered[k] = roof[k]
+        roof = ordered
+        line["roofline"] = roof
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.torch_cpu_path import time_cpu_baseline

@@ -148,7 +148,9 @@ def raise_for_status(code: int, what: str):
         raise NotImplementedError(msg)
     if code == ERR_LAUNCH:
         msg += f" (hipError_t={load().gemlite_hip_last_hip_error()})"
-    raise GemliteHipError(msg)
+    err = GemliteHipError(msg)
+    err.status = code
+    raise err
 
 
 def require_gpu_tensor(t: torch.Tensor, name: str):

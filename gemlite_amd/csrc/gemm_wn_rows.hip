@@ -405,8 +405,9 @@ bool plan_gemm_wn_rows(const gemlite_hip_forward_args& a, WnParams& p, LaunchPla
     if (p.gs_shift < 5 || (p.gs_shift > 30 && p.gs_shift != 31)) return false;            // groups of 32, 64, 128, ... k (31: one group spans K)
     const int spg = p.gs_shift >= 7 ? 4 : (p.gs_shift == 6 ? 2 : 1);
     const int64_t rows = a.K / epr;
-    // 32-bit byte offsets in the kernel
-    if (rows * a.stride_wk * 4 + a.N * 4 >= (1ll << 32) || (64 * a.stride_xm + a.K) * 2 >= (1ll << 32) || 64 * a.stride_om * 2 >= (1ll << 32)) return false;
+    // 32-bit byte offsets in the kernel; the x extent of a row block stays below 2^31 so that the 0x80000000 offset of the padded rows (>= M) is
+    // beyond the descriptor's num_records and reads zeros
+    if (rows * a.stride_wk * 4 + a.N * 4 >= (1ll << 32) || (64 * a.stride_xm + a.K) * 2 >= (1ll << 31) || 64 * a.stride_om * 2 >= (1ll << 32)) return false;
     if (p.gs_shift < 31 && ((a.K >> p.gs_shift) * p.stride_meta_g + a.N) * 2 >= (1ll << 32)) return false;
     // two column tiles per block (tuning[1] = 2 forces, 1 = never): up to 32 rows of a layer whose 16-column tiles do not fit one round
     // of resident blocks but whose 32-column blocks do (4096 < N <= 8192 on 256 CUs)

@@ -101,6 +101,22 @@ CASES_R4 = (
        ("a8w4_fp8dyn_m16", case_a8wn(4096, 4096, 4, 128, 16, 11, 4), (16, 4096, 4096)),
        ("a8w4_fp8dyn_m256", case_a8wn(4096, 4096, 4, 128, 256, 11, 5), (256, 4096, 4096))])
 
+# Round 6: the territory of gemm_w4_rows_kernel (round 5) had reference outputs at M = 64 g128 only.  16 / 32 / 48 rows in
+# both types, groups of 64 and 32 at 32 rows, 2-bit words at 32 rows, and the two-column-tile form (4096 < N <= 8192).  Written to
+# fullsize_ref_r5.npz by `--which ref --only r5 --fixture fullsize_ref_r5.npz`.
+CASES_R5 = (
+    [("cfgA_bf16_m16", case_int(4096, 4096, 4, 128, torch.bfloat16, 16, 0, 16), (16, 4096, 4096))]
+    + [(f"cfgA_{tn}_m{m}", case_int(4096, 4096, 4, 128, tdt, m, 0, m), (m, 4096, 4096))
+       for m in (32, 48) for tn, tdt in (("fp16", torch.float16), ("bf16", torch.bfloat16))]
+    + [("w4_g64_fp16_m32", case_int(4096, 4096, 4, 64, torch.float16, 32, 21, 22), (32, 4096, 4096)),
+       ("w4_g64_bf16_m32", case_int(4096, 4096, 4, 64, torch.bfloat16, 32, 21, 22), (32, 4096, 4096)),
+       ("w4_g32_fp16_m32", case_int(4096, 4096, 4, 32, torch.float16, 32, 23, 24), (32, 4096, 4096)),
+       ("a16w2_4096_fp16_m32", case_int(4096, 4096, 2, 128, torch.float16, 32, 25, 26), (32, 4096, 4096)),
+       ("w4_8192x4096_fp16_m32", case_int(8192, 4096, 4, 128, torch.float16, 32, 27, 28), (32, 8192, 4096)),
+       # (round 6) the decode kernels this round re-wrote, pinned as well: 8192^2 bf16 M = 1 and the 2-bit 4096^2 M = 1
+       ("cfgB_bf16_m1", case_int(8192, 8192, 4, 128, torch.bfloat16, 1, 3, 7), (1, 8192, 8192)),
+       ("a16w2_4096_fp16_m1", case_int(4096, 4096, 2, 128, torch.float16, 1, 25, 29), (1, 4096, 4096))])
+
 CASES = [
     # name, builder, shape-for-flops
     ("cfgA_fp16_m1", case_int(4096, 4096, 4, 128, torch.float16, 1, 0, 1), (1, 4096, 4096)),
@@ -127,7 +143,7 @@ CASES = [
     ("mx_a4w4_m256", case_helper("A4W4_MXFP_dynamic", 2048, 4096, 256, 35, torch.bfloat16, True), (256, 2048, 4096)),
     ("mx_a16w4_m16", case_helper("A16W4_MXFP", 2048, 4096, 16, 36, torch.bfloat16, True), (16, 2048, 4096)),
     ("nvfp4_m16", case_helper("A4W4_NVFP_dynamic", 2048, 4096, 16, 37, torch.bfloat16, True), (16, 2048, 4096)),
-] + list(CASES_R4)
+] + list(CASES_R4) + list(CASES_R5)
 
 _FLUSH = None
 
@@ -183,7 +199,7 @@ def main():
     ap.add_argument("--tmp", default="/tmp/gemlite_ref_full")
     ap.add_argument("--budget-s", type=float, default=480.0)
     ap.add_argument("--fast-shapes", default="cfgA_fp16_m1,cfgA_bf16_m256,cfgB_bf16_m256")
-    ap.add_argument("--only", default="", help="comma-separated case names, or `r4` = the round-4 additions")
+    ap.add_argument("--only", default="", help="comma-separated case names, or `r4` / `r5` = the round-4 / round-6 additions")
     ap.add_argument("--fixture", default="fullsize_ref.npz", help="file name of the golden fixture written by --which ref")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -193,8 +209,8 @@ def main():
     info = {"device": torch.cuda.get_device_properties(0).name, "torch": torch.__version__, "which": args.which,
             "triton": __import__("triton").__version__, "method": "256 MiB flush + event pair per call (benchmark_triton.py:44-60)"}
     golden, report = {}, []
-    only = set(c[0] for c in CASES_R4) if args.only == "r4" else set(filter(None, args.only.split(",")))
-    tag = "_r4" if args.only == "r4" else ""
+    only = set(c[0] for c in CASES_R4) if args.only == "r4" else (set(c[0] for c in CASES_R5) if args.only == "r5" else set(filter(None, args.only.split(","))))
+    tag = "_r4" if args.only == "r4" else ("_r5" if args.only == "r5" else "")
     out_json = os.path.join(args.out, f"reference_triton_mi355x{tag}.json" if args.which == "ref" else f"hip_same_method{tag}.json")
 
     def run_phase(mode, names, dump):

@@ -52,7 +52,23 @@ traffic = {"_calibration": calib,
            "_note": "bytes per launch = FETCH_SIZE KiB / (FETCH_SIZE per KiB of a 16 B/lane streaming read, measured) x 1024 + WRITE_SIZE KiB / "
                     "(WRITE_SIZE per KiB of plain 16-byte stores, measured) x 1024; median over the launches of the workload's dominant "
                     "library kernel, eager launches over rotating layers.  k_read4_rows = the tile kernel's B-operand pattern."}
-util = {"_note": "matrix-pipe busy share of the SIMD cycles at the clock the kernel ran at (SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 x 1024)), "
+# stamp: the PLANNER's kernel name of each workload (from the bench line the pass printed) + the commit the passes ran on (GL_COMMIT, set by
+# the caller: the GPU box has no .git).  bench.py prints `traffic: null` when the planner's current choice differs from the stamp.
+commit = os.environ.get("GL_COMMIT", "unknown")
+
+
+def planner_kernel(w):
+    try:
+        for ln in open(os.path.join(out, w + "_A.log")):
+            if ln.startswith("{") and '"roofline"' in ln:
+                return json.loads(ln)["roofline"].get("kernel")
+    except Exception:
+        pass
+    return None
+
+
+traffic["_stamp"] = {}
+util = {"_stamp": {}, "_note": "matrix-pipe busy share of the SIMD cycles at the clock the kernel ran at (SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 x 1024)), "
                  "effective clock in GHz, VALU instructions per MFMA; eager launches under rocprofv3 --pmc"}
 for da in sorted(glob.glob(os.path.join(out, "*_A"))):
     w = os.path.basename(da)[:-2]
@@ -74,6 +90,7 @@ for da in sorted(glob.glob(os.path.join(out, "*_A"))):
             b += write_kib / w16 * 1024
         traffic[w] = int(b)
     traffic.setdefault("_detail", {})[w] = rec
+    traffic["_stamp"][w] = util["_stamp"][w] = {"kernel": planner_kernel(w), "commit": commit}
     busy, mf, dur = med(cs.get("SQ_BUSY_CYCLES", [])), med(cs.get("SQ_VALU_MFMA_BUSY_CYCLES", [])), med(cs["_dur_ns"])
     if busy and dur:
         cyc = busy / 32.0
