@@ -495,11 +495,13 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
         // (tuning[1] = 1 / 2 column tiles per block), tuning[3] & 65536 keeps the round-4 choice (A/B runs).
         if (x16 && (a.W_nbits == 4 || a.W_nbits == 2) && (mt == GEMLITE_MATMUL_AUTO || mt == GEMLITE_MATMUL_GEMM_SPLITK || (mt == GEMLITE_MATMUL_GEMM && a.tuning[0] == 9)) &&
             !(a.tuning[3] & 65536) && (a.tuning[0] == 9 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && a.M >= 2))) {
-            // nothing but the coverage kernel behind this one: 2-bit groups of 32 and N % 64 != 0 at any M.  4-bit groups of 32 over N % 64 == 0
-            // DO have a kernel behind them — gemm_wn_stream_kernel (64-column tiles, any M along grid.z; round 4's choice) — so the rows kernel
-            // takes those only up to its 64 rows per block: beyond, its N / 16 x M / 32 blocks would re-stream the weights once per row block
-            // (M = 2048 over 4096^2: 16384 blocks, 64 x the weight bytes)
-            const bool only_here = (p.gs_shift == 5 && (a.W_nbits == 2 || a.M <= 64)) || a.N % 64 != 0;
+            // nothing FASTER behind this one.  2-bit groups of 32 and N % 64 != 0: only the coverage kernel.  4-bit groups of 32 over N % 64 == 0 do have
+            // gemm_wn_stream_kernel behind them (round 4's choice) and ADVICE r5 asked to hand M > 64 back to it, because the rows kernel re-streams
+            // the weights once per 32-row block there — measured (round 6, profiles/r06/probe_g32_rows_vs_stream.log, layer(x) in us, rows / stream):
+            // 4096^2 M = 64 17.0 / 114, M = 128 31.9 / 184, M = 256 61.5 / 324, M = 1024 242 / 1242; 8192^2 M = 256 208 / 1244; 11008 x 4096 M = 256
+            // 172 / 926 — the rows kernel is 5 - 7 x faster at every M, so it keeps every group-32 layer.  (What these layers lack at M > 64 is a
+            // group-32 form of the MFMA tile kernel: 61.5 us against 16.8 for groups of 128 at 4096^2 M = 256.)
+            const bool only_here = p.gs_shift == 5 || a.N % 64 != 0;
             const bool in_budget = a.W_nbits == 4 ? rows5_pays(a.M, a.N, a.K, p.gs_shift) : rows5_pays_w2(a.M, a.N, a.K, p.gs_shift);
             if (a.tuning[0] == 9 || only_here || in_budget) {
                 WnParams pr = p;

@@ -222,7 +222,8 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         const int64_t tiles = (int64_t)(a.N / 64) * ((a.M + bm - 1) / bm);
         if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
         const bool f16 = tag_dt == GEMLITE_DT_FP16;
-        const void* fn = f16 ? mma_lookup_f16(6, nbits, v, xdt, 0) : mma_lookup_bf16(6, nbits, v, xdt, 0);
+        const int expv = (int)(((unsigned)a.tuning[3] >> 20) & 63u) << 8;  // (development builds: K-loop ablation, see mma_exp_lookup)
+        const void* fn = f16 ? mma_lookup_f16(6, nbits, v, xdt, expv) : mma_lookup_bf16(6, nbits, v, xdt, expv);
         if (!fn) return false;
         p.splitk = splitk;
         p.rows_per_slice = rows;
@@ -324,7 +325,8 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
     if ((uint64_t)splitk * bm * bn * 4 >= (1ull << 31)) return false;  // slab buffer descriptor range
     const bool f16 = tag_dt == GEMLITE_DT_FP16;
-    const void* fn = f16 ? mma_lookup_f16(wide ? 1 : 0, nbits, mi, xdt, 0) : mma_lookup_bf16(wide ? 1 : 0, nbits, mi, xdt, 0);
+    const int expv = (int)(((unsigned)a.tuning[3] >> 20) & 63u) << 8;  // (development builds: K-loop ablation, see mma_exp_lookup)
+    const void* fn = f16 ? mma_lookup_f16(wide ? 1 : 0, nbits, mi, xdt, expv) : mma_lookup_bf16(wide ? 1 : 0, nbits, mi, xdt, expv);
     // K-slice combine: reduce-scatter between the slices of a tile when they are certain to be co-resident (every block of the
     // launch fits on the device at once: <= one block per CU), the slices divide the tile's row blocks, and the variant exists
     // (4- / 2-bit words, 16-bit activations); else slabs + ticket.  From 4 slices on: with 2 slices the ticket protocol is as fast

@@ -69,40 +69,36 @@ __device__ __forceinline__ uint32_t word_of(const typename Vec<V>::W& w, int j) 
     if constexpr (V == 1) return w; else return w[j];
 }
 
-// Slot order of a lane's 8 (fp16 pairs) k-values.  4-bit word, fields q0..q7:
-//   fp16: d0 = w & 0x000F000F = (q0, q4), d1 = w & 0x00F000F0 = 16 (q1, q5), d2, d3 the same of w >> 8 -> (q2, q6), 16 (q3, q7)
-//         (subnormals: value * 2^-24; two fields per 16-bit half fit the 10-bit mantissa); x slots (x0,x4) (x1,x5)/16 (x2,x6) (x3,x7)/16
-//   bf16: d_i = ((w >> 4 i) & 0x000F000F) | 0x43004300 = (128 + q_i, 128 + q_{i+4}); x slots (x_i, x_{i+4}) unscaled
-// 2-bit word, fields q0..q15, two fragments f = 0, 1 (k-steps): pairs (q_a, q_{a+8}), a = 4 f + dd
-//   fp16: four fields per half fit: d = w & (0x00030003 << 2 a) -> 4^a (q_a, q_{a+8}); x slots (x_a, x_{a+8}) / 4^a ... a < 4,
-//         fragment 1 from w >> 8 (a - 4 < 4)
-//   bf16: ((w >> 2 a) & 0x00030003) | 0x43004300
+// B fragments (round 6: EXACT in fp16 — rounds 3-5 divided the matching x slots by 16 / 4^a in fp16, which lost mantissa bits of small
+// activations).  A lane (column c, k-quarter kg) holds the words wa, wb of TWO packed rows (4 apart) of its column; one MFMA
+// takes 8 of their k-values, chosen so that every code of the fragment sits at the SAME bit offset inside its 16-bit half:
+//   4-bit, plane 0: {wa, wa >> 8, wb, wb >> 8} & 0x000F000F = (q0,q4)(q2,q6) of row a, then of row b            [fp16: x 2^-24, exact subnormals]
+//          plane 1: the same & 0x00F000F0 = 16 (q1,q5)(q3,q7)                                                    [fp16: x 16 x 2^-24]
+//   2-bit, plane a = 0..3: {wa, wa >> 8, wb, wb >> 8} & (0x00030003 << 2a) = 4^a (q_a, q_{a+8})(q_{a+4}, q_{a+12})
+// fp16 keeps ONE fp32 accumulator per plane and applies the plane's 16^-a / 4^-a once to the sum — nothing is rounded before the matrix
+// core's fp32 accumulation.  bf16 (no subnormal trick: 8-bit mantissa): the fields shifted down and OR-ed into 128.0 (0x4300 | q = 128 + q,
+// exact), all planes into one accumulator, the 128 * sum(x) removed per group as before.  The A fragment of (row pair, plane, kg) is the
+// matching x pairs of the two rows, laid out by the staging lanes (below) so that it is ONE ds_read_b128.
 template <typename Tag, int NBITS>
-struct Unpack {
+struct Planes {
     static constexpr bool SUBN = F16Traits<Tag>::DT == GEMLITE_DT_FP16;
-    static constexpr int E = 32 / NBITS, HALF = E / 2;
-    // fragment f (k-step f of the word) -> 4 dwords
-    static __device__ __forceinline__ u32x4 frag(uint32_t w, int f) {
+    static constexpr int NA = NBITS == 4 ? 2 : 4;          // planes per row pair
+    static constexpr int FW = NBITS;                       // field width
+    static __device__ __forceinline__ u32x4 frag(uint32_t wa, uint32_t wb, int a) {
         u32x4 r;
         if constexpr (SUBN) {
-            if constexpr (NBITS == 4) {
-                const uint32_t w8 = w >> 8;
-                r[0] = w & 0x000F000Fu; r[1] = w & 0x00F000F0u; r[2] = w8 & 0x000F000Fu; r[3] = w8 & 0x00F000F0u;
-            } else {
-                const uint32_t v = f ? (w >> 8) : w;
-                r[0] = v & 0x00030003u; r[1] = v & 0x000C000Cu; r[2] = v & 0x00300030u; r[3] = v & 0x00C000C0u;
-            }
+            const uint32_t m = (((1u << FW) - 1u) * 0x00010001u) << (FW * a);
+            r[0] = wa & m; r[1] = (wa >> 8) & m; r[2] = wb & m; r[3] = (wb >> 8) & m;
         } else {
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                const int a = 4 * f + dd;
-                r[dd] = ((w >> (NBITS * a)) & (((1u << NBITS) - 1u) * 0x00010001u)) | F16Traits<Tag>::MAGIC2;
-            }
+            const uint32_t m = ((1u << FW) - 1u) * 0x00010001u;
+            r[0] = ((wa >> (FW * a)) & m) | F16Traits<Tag>::MAGIC2;
+            r[1] = ((wa >> (FW * a + 8)) & m) | F16Traits<Tag>::MAGIC2;
+            r[2] = ((wb >> (FW * a)) & m) | F16Traits<Tag>::MAGIC2;
+            r[3] = ((wb >> (FW * a + 8)) & m) | F16Traits<Tag>::MAGIC2;
         }
         return r;
     }
-    // power of two the stored x of slot dd is divided by (fp16 only)
-    static __device__ __forceinline__ constexpr int xshift(int dd) { return SUBN ? (NBITS == 4 ? 4 * (dd & 1) : 2 * dd) : 0; }
+    static __device__ __forceinline__ constexpr float inv_scale(int a) { return SUBN ? 1.0f / (float)(1 << (FW * a)) : 1.0f; }
 };
 
 }  // namespace gmf
@@ -112,24 +108,26 @@ struct Unpack {
 //
 // x never crosses waves: a wave needs exactly the x of ITS k range, 16 bytes per (row, packed row) = CPB <= 64 chunks per batch,
 // so lane L fetches chunk L of the batch (first request of the batch, ahead of the weights), pair-permutes / pre-scales it in
-// registers, drops it into the wave's private LDS slot and reads the A fragments back as broadcasts.  No block barrier before
+// registers, drops the pairs into the wave's private LDS slot in A-fragment order and reads the fragments back as broadcasts.  No block barrier before
 // the arithmetic: the first version staged all of x per BLOCK, and its barrier waited 3.3 us — the x requests of the later
 // waves queue in the CU's in-order memory path behind the weight requests of the earlier ones (profiles/r03/timeline_decode_v2.log).
 template <typename Tag, int NBITS, int V, int NW, int MB, int GB, int SPG>
 __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p) {
     using namespace gmf;
     using TR = F16Traits<Tag>;
-    using UP = Unpack<Tag, NBITS>;
+    using PL = Planes<Tag, NBITS>;
     using WT = typename Vec<V>::W;
     using MT = typename Vec<V>::M;
-    constexpr bool SUBN = UP::SUBN;
-    constexpr int E = 32 / NBITS, NF = E / 8;  // NF k-steps per packed word
+    constexpr bool SUBN = PL::SUBN;
+    constexpr int E = 32 / NBITS;
     static_assert(NBITS == 4 || NBITS == 2, "x staging below: 4-bit words (one chunk per packed row) or 2-bit words (two)");
     constexpr int TN = 16 * V, NT = NW * 64;
-    constexpr int RSTEPS = SPG / NF;           // wave loads (4 packed rows each) per group unit
+    constexpr int RSTEPS = SPG * 8 / E;        // wave loads (4 packed rows = 4 E k each) per group unit: 4 / 2 (4-bit), 2 (2-bit)
+    constexpr int P = RSTEPS / 2;              // row pairs per lane and unit
+    constexpr int NA = PL::NA, NACC = SUBN ? NA : 1;
     constexpr int CPG = 4 * SPG;               // x chunks (8 k) per group unit
     constexpr int CPB = GB * CPG;              // ... per batch: one per lane
-    static_assert(SPG % NF == 0 && RSTEPS >= 1 && CPB <= 64, "a batch's x chunks are dealt one per lane");
+    static_assert(RSTEPS >= 2 && RSTEPS % 2 == 0 && CPB <= 64 && GB * P * NA * 64 <= 1024, "a batch's x chunks are dealt one per lane; its fragments fill <= 1 KiB per row");
     constexpr float QSCALE = SUBN ? 16777216.0f : 1.0f;
     constexpr float OFF = SUBN ? 0.0f : TR::OFF;
 
@@ -179,6 +177,12 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
     const uint32_t xvoff = lane >= CPB ? 0x80000000u  // (lanes past CPB: no request)
                            : (NBITS == 4 ? (uint32_t)(((wave + NW * xgi) * CPG + xwi) * 16)
                                          : (uint32_t)((wave + NW * xgi) * CPG * 16 + (((xwi >> 3) * 4 + (xwi & 3)) * 32) + ((xwi >> 2) & 1) * 8));
+    // where this lane's pairs go: fragment (unit gi, row pair t, plane a, quarter kq) at ((((gi P + t) NA + a) 4 + kq) 16 bytes; the first 8 bytes
+    // belong to the pair's first row, the last 8 to its second
+    //   4-bit chunk = packed row rs 4 + kq (rs = xwi >> 2): t = rs >> 1, second row if rs & 1; pairs (x0,x4)(x2,x6) -> plane 0, (x1,x5)(x3,x7) -> plane 1
+    //   2-bit chunk (row rs 4 + kq, half f): t = 0, second row if rs; pair i = (x_{4f+i}, x_{4f+i+8}) -> plane i, dword f of the row's 8 bytes
+    const int st_rs = NBITS == 4 ? (xwi >> 2) : (xwi >> 3), st_kq = xwi & 3, st_f = (xwi >> 2) & 1;
+    const uint32_t st_base = (uint32_t)((((xgi * P + (NBITS == 4 ? (st_rs >> 1) : 0)) * NA) * 4 + st_kq) * 16 + (st_rs & 1) * 8 + (NBITS == 4 ? 0 : st_f * 4));
     const int my_units = (ngroups - wave + NW - 1) / NW;
 
     struct Batch { u32x4 x[MB]; WT w[GB][RSTEPS]; MT s[GB], z[GB]; };
@@ -221,15 +225,16 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
         float sm = 0.f;
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) sm = TR::dot2(q[dd], TR::ONES2, sm);
-        if constexpr (SUBN) {
+        if (lane < CPB) {
+            unsigned char* dst = xw + (size_t)(buf * MB + r) * 1024 + st_base;
+            if constexpr (NBITS == 4) {
+                *(u32x2*)(dst) = (u32x2){q[0], q[2]};
+                *(u32x2*)(dst + 64) = (u32x2){q[1], q[3]};
+            } else {
 #pragma unroll
-            for (int dd = 0; dd < 4; ++dd)
-                if (UP::xshift(dd)) {
-                    const _Float16 sc = (_Float16)(1.0f / (float)(1 << UP::xshift(dd)));
-                    q[dd] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2_t, q[dd]) * (h2_t){sc, sc});
-                }
+                for (int i = 0; i < 4; ++i) *(uint32_t*)(dst + i * 64) = q[i];
+            }
         }
-        *(u32x4*)(xw + (size_t)(buf * MB + r) * 1024 + (size_t)lane * 16) = (u32x4){q[0], q[1], q[2], q[3]};
         sm += gmf::dppf<0xB1>(sm);   // quad_perm [1,0,3,2]
         sm += gmf::dppf<0x4E>(sm);   // quad_perm [2,3,0,1]: every lane holds its quad's sum
         sm += gmf::dppf<0x141>(sm);  // row_half_mirror: + the other quad of the 8-lane half
@@ -257,37 +262,38 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
         }
     };
     auto compute = [&](const Batch& b, int i0, int buf) {
-        f32x4 acc[GB][V];
-        float live[GB];
-#pragma unroll
-        for (int gi = 0; gi < GB; ++gi) live[gi] = i0 + gi < my_units ? 1.f : 0.f;
         const unsigned char* xa = xw + (size_t)(buf * MB + mrow) * 1024 + (size_t)kg * 16;
-        // k-step-major over the GB group units: consecutive MFMAs go to different accumulators
-#pragma unroll
-        for (int rs = 0; rs < RSTEPS; ++rs)
-#pragma unroll
-            for (int f = 0; f < NF; ++f)
-#pragma unroll
-                for (int gi = 0; gi < GB; ++gi) {
-                    const u32x4 a = *(const u32x4*)(xa + (gi * CPG + (rs * NF + f) * 4) * 16);  // chunk (unit gi, k-step rs NF + f, quarter kg)
-#pragma unroll
-                    for (int j = 0; j < V; ++j) {
-                        const u32x4 bf = UP::frag(word_of<V>(b.w[gi][rs], j), f);
-                        const f32x4 cin = (rs == 0 && f == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[gi][j];
-                        acc[gi][j] = mfma16<Tag>(a, bf, cin);
-                    }
-                }
 #pragma unroll
         for (int gi = 0; gi < GB; ++gi) {
+            f32x4 acc[V][NACC];
+#pragma unroll
+            for (int t = 0; t < P; ++t)
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    const u32x4 af = *(const u32x4*)(xa + (((gi * P + t) * NA + a) * 4) * 16);  // fragment (unit gi, pair t, plane a, quarter kg)
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        const u32x4 bf = PL::frag(word_of<V>(b.w[gi][2 * t], j), word_of<V>(b.w[gi][2 * t + 1], j), a);
+                        const int ai = SUBN ? a : 0;
+                        const bool first = t == 0 && (SUBN || a == 0);
+                        acc[j][ai] = mfma16<Tag>(af, bf, first ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[j][ai]);
+                    }
+                }
+            const float live = i0 + gi < my_units ? 1.f : 0.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const float s = need_s ? TR::to_float(gmf::meta_of<V>(b.s[gi], j)) : 1.f;
                 const float z = need_z ? TR::to_float(gmf::meta_of<V>(b.z[gi], j)) : scalar_zero;
-                const float a = s * QSCALE * live[gi];
-                const float bb = (bz * z * (b_times_s ? s : 1.f) - s * OFF) * live[gi];
+                const float a = s * QSCALE * live;
+                const float bb = (bz * z * (b_times_s ? s : 1.f) - s * OFF) * live;
                 // C layout: rows 4 kg + r — the tile's rows (< MB <= 4) live in the registers of the kg = 0 lanes
 #pragma unroll
-                for (int r = 0; r < MB; ++r) tot[j][r] += a * acc[gi][j][r] + bb * gs[r][gi];
+                for (int r = 0; r < MB; ++r) {
+                    float v = acc[j][0][r];
+#pragma unroll
+                    for (int ai = 1; ai < NACC; ++ai) v = __builtin_fmaf(acc[j][ai][r], PL::inv_scale(ai), v);
+                    tot[j][r] += a * v + bb * gs[r][gi];
+                }
             }
         }
     };

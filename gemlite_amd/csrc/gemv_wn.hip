@@ -35,6 +35,61 @@ namespace gl {
 
 const void* gemv_w4_decode3_fn(int tag, bool nt);  // gemv_decode.hip
 
+// Round 6 ("GEMV family onto counted asm loads"): the chunk requests of gemv_wn_kernel are inline-asm global loads
+// retired with hand-counted s_waitcnt (gl_async.h has the reasoning; scripts/isa_asmloads.py replays the generated code).  With the loads
+// left to hipcc, every instantiation carried a full `s_waitcnt vmcnt(0)` at the head of its two-chunk loop: the chunk requested a moment
+// before was waited for in full before the arithmetic on the OLDER chunk could start — one memory latency per loop iteration with nothing
+// overlapped.  Uniform base + 32-bit byte offset per lane, as before.
+namespace gvw {
+template <bool NT>
+__device__ __forceinline__ void gld128(u32x4& d, const char* base, uint32_t voff) {
+    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gld64(u32x2& d, const char* base, uint32_t voff) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <typename T>
+__device__ __forceinline__ void tie(T& v) { asm volatile("" : "+v"(v)); }
+
+// Two chunk buffers A / B, one chunk in flight while the other is computed on.  NLC = requests per chunk.  On entry A holds chunk 0 and B
+// chunk 1 (requested by the caller, those that exist).  Steady state: unconditional requests, ONE wait value ("everything but the newest
+// chunk has landed": loads return in order); the last one to three chunks are peeled, their waits picked by uniform branches.
+template <int NLC, typename Buf, typename Issue, typename Tie, typename Compute>
+__device__ __forceinline__ void ring2_run(int n, Buf& A, Buf& B, Issue&& issue, Tie&& tie_buf, Compute&& compute) {
+    int i = 0;
+#pragma unroll 1
+    for (; i + 4 <= n; i += 2) {
+        wait_vm<NLC>();
+        tie_buf(A);
+        compute(A, i);
+        issue(A, i + 2);
+        wait_vm<NLC>();
+        tie_buf(B);
+        compute(B, i + 1);
+        issue(B, i + 3);
+    }
+    const int rem = n - i;  // 0 (no chunk at all), 1, 2 or 3
+    if (rem >= 1) {
+        if (rem >= 2) wait_vm<NLC>(); else wait_vm<0>();
+        tie_buf(A);
+        compute(A, i);
+        if (rem >= 2) {
+            if (rem == 3) { issue(A, i + 2); wait_vm<NLC>(); } else wait_vm<0>();
+            tie_buf(B);
+            compute(B, i + 1);
+            if (rem == 3) {
+                wait_vm<0>();
+                tie_buf(A);
+                compute(A, i + 2);
+            }
+        }
+    }
+}
+}  // namespace gvw
+
 // Unpack geometry.  One AND turns packed bits into two 16-bit floats q * 2^(NBITS*i) (i = position of the
 // element inside a WINDOW of consecutive bit fields that still fits the mantissa); the matching x pair is stored
 // pre-scaled by 2^-(NBITS*i) (an exact power of two), so only one shift per window (not per element) is needed.
@@ -70,10 +125,12 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
     constexpr int HALF = E / 2;      // (k, k+HALF) pairs per word == LDS dwords per packed row
     constexpr int WP = WN::WP;
     // fp16, 4-bit (two fields per 16-bit window): the field read 4 bits up gets its OWN fp32 accumulator and the 2^-4 is applied once to the sum
-    // (round 5; rounds 2-4 pre-scaled the matching x by 2^-4 in fp16: mantissa bits lost below |x| = 2^-10).  2- and 1-bit words
-    // (four / eight fields per window) keep the pre-scaled x: 4 / 8 accumulator sets do not fit
+    // (round 5; rounds 2-4 pre-scaled the matching x by 2^-4 in fp16: mantissa bits lost below |x| = 2^-10).
     // (A/B on one box, scripts/r5/run_j_ab_gemv_split.sh: 16384^2 M = 1 27.9 vs 28.3 us in the single-workload bench — no cost)
-    constexpr bool SPLIT = SUBN && NBITS == 4 && WP == 2;
+    // Round 6: 2- and 1-bit words too — four / eight accumulator sets, one per field position, combined per chunk with
+    // 2^-(NBITS * position): one accuracy bound for every decode kernel (bf16 never needed it: its pre-scale by a power of two is exact over
+    // the whole fp32-sized exponent range).
+    constexpr bool SPLIT = SUBN && WP > 1;
     constexpr int NACC = SPLIT ? WP : 1;
     constexpr int G = 64 >> CQ;      // row sub-groups per wave
     constexpr int CHUNK = G * R;     // packed rows one wave consumes per step
@@ -84,8 +141,14 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
     static_assert(!XD || (NBITS == 4 && MB == 1), "direct x loads: one 16-byte x chunk per packed row");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the branches on a wave's chunk count are scalar branches)
     const int c = lane & ((1 << CQ) - 1), g = lane >> CQ;
+    // The scalar zero point is read — and waited for — HERE, ahead of every request of the K loop (round 6).  Left next to its first use
+    // inside the chunk arithmetic, it was what put the `s_waitcnt vmcnt(0)` at the head of the two-chunk loop in rounds 2-5: hipcc's
+    // waitcnt pass carries "this load may be outstanding" around the back edge and answers it with a full drain in EVERY iteration.
+    float scalar_zero = 0.f;
+    if (p.zero_is_scalar) scalar_zero = (float)__builtin_amdgcn_readfirstlane(((const int32_t*)p.zeros)[0]);
     int tile = blockIdx.x;
     if constexpr (CQ == 2) {  // adjacent half-line tiles on one XCD (speed only; any mapping is correct)
         const int nb = gridDim.x;
@@ -131,28 +194,61 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
     struct Chunk { u32x4 w[R]; u32x2 s, z; u32x4 x[XD ? R : 1]; };
     const uint16_t* xg = (const uint16_t*)p.x;
     const char* wb = (const char*)p.w;
-    auto load_chunk = [&](Chunk& ck, int chunk) {
+    constexpr int NLC = R + 2 + (XD ? R : 0);  // requests per chunk
+    // (8-bit words with 8 rows per lane: 32 weight registers per chunk buffer — with the asm requests the allocator spilled, and a spilled
+    //  destination of a request in flight is a wrong result; that one variant keeps the compiler-tracked loads and pipeline2_run)
+    constexpr bool ASMQ = !(NBITS == 8 && R == 8);
+    auto load_chunk = [&](Chunk& ck, int chunk) __attribute__((always_inline)) {
         const int row = row_s0 + row_w0 + chunk * CSTRIDE + g * R;
         const uint32_t mo = ((uint32_t)group_of(row * E, p.gs_shift) * mstride + (uint32_t)n0) * 2u;
+        if constexpr (!ASMQ) {
+            const uint32_t co = (uint32_t)(chunk * CSTRIDE) * sw4;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const u32x4* src = (const u32x4*)(wb + (wo[i] + co));
+                ck.w[i] = GL_GEMV_NT ? __builtin_nontemporal_load(src) : *src;
+            }
+            ck.s = *(const u32x2*)((const char*)sp + mo);
+            ck.z = *(const u32x2*)((const char*)zp + mo);
+            return;
+        }
         if constexpr (XD) {  // x first: it is the cheaper (cached) request and is needed together with w
             const uint32_t xc = xo + (uint32_t)(chunk * CSTRIDE) * (uint32_t)(E * 2);
 #pragma unroll
-            for (int i = 0; i < R; ++i) ck.x[i] = *(const u32x4*)((const char*)xg + (xc + (uint32_t)(i * E * 2)));
+            for (int i = 0; i < R; ++i) gvw::gld128<false>(ck.x[i], (const char*)xg, xc + (uint32_t)(i * E * 2));
         }
         const uint32_t co = (uint32_t)(chunk * CSTRIDE) * sw4;  // uniform
 #pragma unroll
-        for (int i = 0; i < R; ++i) {  // streamed once by one CU: non-temporal (guide row nt-weights; strip reads 23.6 -> 20.7 us at 16384^2 with R = 8)
-            const u32x4* src = (const u32x4*)(wb + (wo[i] + co));
-            ck.w[i] = GL_GEMV_NT ? __builtin_nontemporal_load(src) : *src;
+        for (int i = 0; i < R; ++i)  // streamed once by one CU: non-temporal (guide row nt-weights; strip reads 23.6 -> 20.7 us at 16384^2 with R = 8)
+            gvw::gld128<(GL_GEMV_NT != 0)>(ck.w[i], wb, wo[i] + co);
+        gvw::gld64(ck.s, (const char*)sp, mo);
+        gvw::gld64(ck.z, (const char*)zp, mo);
+    };
+    auto tie_chunk = [&](Chunk& ck) __attribute__((always_inline)) {
+        if constexpr (XD) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) gvw::tie(ck.x[i]);
         }
-        ck.s = *(const u32x2*)((const char*)sp + mo);
-        ck.z = *(const u32x2*)((const char*)zp + mo);
+#pragma unroll
+        for (int i = 0; i < R; ++i) gvw::tie(ck.w[i]);
+        gvw::tie(ck.s);
+        gvw::tie(ck.z);
     };
 
     // ---- x[k-slice] -> LDS.  task = (row m, 32-k span): 64 bytes in, 16 pair-permuted / pre-scaled dwords and
     //      the span sums out.  The first task's loads are issued AHEAD of the weight stream. ---------------------
     const int64_t k0 = (int64_t)row_s0 * E;
     const int ntasks = MB * nspans;
+    // the first task of every thread: four asm requests, unconditional (a task past the end re-reads the last one and is dropped by put_x), so
+    // that every wave's queue holds the same number of requests ahead of its first chunks
+    auto fetch_x_first = [&](u32x4 (&v)[4], int task) __attribute__((always_inline)) {
+        const int t2 = task < ntasks ? task : ntasks - 1;
+        const int m = t2 / nspans, spn = t2 - m * nspans;
+        const int m2 = m < p.M ? m : p.M - 1;
+        const uint32_t off = (uint32_t)(((int64_t)m2 * p.stride_xm + k0 + (int64_t)spn * 32) * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gvw::gld128<false>(v[q], (const char*)xg, off + (uint32_t)(16 * q));
+    };
     auto fetch_x = [&](u32x4 (&v)[4], int task) {
         if (task < ntasks) {
             const int m = task / nspans, spn = task - m * nspans;
@@ -220,14 +316,38 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
     stamp(0);
     Chunk A, B;
     if constexpr (XD) {
-        if (nchunks > 0) pipeline2_prime(nchunks, A, B, load_chunk);
+        if (nchunks > 0) load_chunk(A, 0);
+        if (nchunks > 1) load_chunk(B, 1);
     } else {
         u32x4 xv[4];
-        fetch_x(xv, tid);
-        if (nchunks > 0) pipeline2_prime(nchunks, A, B, load_chunk);
+        if constexpr (ASMQ) {
+            fetch_x_first(xv, tid);  // x FIRST in every wave's queue (requests return in order), then the first two chunks
+            if (nchunks > 0) load_chunk(A, 0);
+            if (nchunks > 1) load_chunk(B, 1);
+            // x has landed when only the chunk requests are outstanding
+            if (nchunks > 1) gvw::wait_vm<2 * NLC>();
+            else if (nchunks > 0) gvw::wait_vm<NLC>();
+            else gvw::wait_vm<0>();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gvw::tie(xv[q]);
+        } else {
+            fetch_x(xv, tid);
+            if (nchunks > 0) pipeline2_prime(nchunks, A, B, load_chunk);
+        }
         put_x(xv, tid);
         for (int task = tid + NT; task < ntasks; task += NT) {  // large K * MB only
-            fetch_x(xv, task);
+            if constexpr (ASMQ) {
+                // asm requests here too (their wait drains the first chunks as well — this path is rare): ONE compiler-tracked load ahead of the
+                // K loop is enough to bring the drain back — hipcc answers "that load may still be writing v[a:b]" with s_waitcnt vmcnt(0) in
+                // front of the first instruction of the loop that re-uses those registers, in every iteration (round 6: that, not the chunk
+                // requests themselves, was the vmcnt(0) rounds 3-5 could not get rid of)
+                fetch_x_first(xv, task);
+                gvw::wait_vm<0>();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gvw::tie(xv[q]);
+            } else {
+                fetch_x(xv, task);
+            }
             put_x(xv, task);
         }
         __syncthreads();
@@ -240,7 +360,6 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
 #pragma unroll
         for (int j = 0; j < 4; ++j) tot[m][j] = 0.f;
 
-    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
     // (a, b) of group_affine() without per-column branches: a = s (s == 1 when unused),
     // b = bz * z * (mode 3 ? s : 1) with bz = -1 (modes 1, 3), +1 (mode 4), 0 otherwise
     const float bz = (p.w_mode == 1 || p.w_mode == 3) ? -1.f : (p.w_mode == 4 ? 1.f : 0.f);
@@ -341,18 +460,19 @@ __global__ __launch_bounds__(NW * 64, ((MB * (16 / NBITS) >= 32 || R * MB >= 32 
                 const float a = s[j] * QSCALE;
                 const float b = bz * z[j] * (b_times_s ? s[j] : 1.f);
                 float v = acc[0][m][j];
-                if constexpr (SPLIT) v = __builtin_fmaf(acc[NACC - 1][m][j], 1.0f / 16.0f, v);
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int wi = 1; wi < NACC; ++wi) v = __builtin_fmaf(acc[wi][m][j], 1.0f / (float)(1 << (NBITS * wi)), v);
+                }
                 if constexpr (!SUBN) v -= TR::OFF * xst;
                 tot[m][j] += a * v + b * xt;
             }
         }
     };
 
-    if (nchunks > 0)
-        pipeline2_run(nchunks, A, B, load_chunk, [&](const Chunk& ck, int ch) {
-            compute(ck, ch);
-            if (ch == 0) stamp(2);  // first chunk consumed (its data had arrived)
-        });
+    // (no stamp inside the ring: a store is a vector-memory request and would shift the counted waits)
+    if constexpr (ASMQ) gvw::ring2_run<NLC>(nchunks, A, B, load_chunk, tie_chunk, compute);
+    else if (nchunks > 0) pipeline2_run(nchunks, A, B, load_chunk, compute);
     stamp(3);  // all chunks consumed
 
     // ---- reduce over the G row sub-groups of the wave (lane bits CQ..5) --------------------------------

@@ -18,7 +18,12 @@ import tempfile
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import isa_loops as L
 
-FAMILIES = ("gemm_wn_mma_kernel", "gemm_w4_rows_kernel")
+FAMILIES = ("gemm_wn_mma_kernel", "gemm_w4_rows_kernel", "gemv_wn_kernel")
+# gemv_wn_kernel (round 6: gvw::ring2_run): the prologue requests up to two chunks behind uniform branches and the last one to three chunks run in
+# straight-line code BEHIND the loop — replayed in address order (no branch is followed), prologue and tail included, every conditional request
+# issued and every run of alternative waits taken at its weakest member
+LINEAR_WITH_TAIL = ("gemv_wn_kernel",)
+ALTERNATIVE_WAITS = ("gemm_w4_rows_kernel", "gemv_wn_kernel")
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
 
@@ -139,7 +144,7 @@ def check():
                 body = lines[tgt:i + 1]
                 if any(x[1].startswith("s_endpgm") for x in body):
                     continue
-                hot = sum("v_mfma" in x[1] for x in body)
+                hot = sum(("v_mfma" in x[1] or "v_dot2" in x[1]) for x in body)
                 if hot >= 16 and (best is None or hot > best[2]):
                     best = (tgt, i, hot)
             if best is None:
@@ -147,11 +152,12 @@ def check():
             lo, hi, _ = best
             # first pass: straight-line from the top, following UNCONDITIONAL forward branches (hipcc rotates some loops: the preheader ends in an
             # s_branch into the middle of the body — the ring form of the rows kernel with four pieces per chunk); then full iterations
+            linear_tail = any(k in fn for k in LINEAR_WITH_TAIL)
             seq, i = [], 0
             while i <= hi:
                 seq.append(i)
                 m = re.match(r"s_branch\s+(\d+)", lines[i][1])
-                if m:
+                if m and not linear_tail:
                     offw = int(m.group(1))
                     tgt = index.get(lines[i][0] + 4 + offw * 4) if offw < 32768 else None
                     if tgt is not None and i < tgt <= hi:
@@ -159,7 +165,9 @@ def check():
                         continue
                 i += 1
             seq += list(range(lo, hi + 1)) + list(range(lo, hi + 1))
-            for (a, t, r) in replay(lines, seq, weakest_of_alternatives="gemm_w4_rows_kernel" in fn)[:4]:
+            if linear_tail:
+                seq += list(range(hi + 1, len(lines)))
+            for (a, t, r) in replay(lines, seq, weakest_of_alternatives=any(k in fn for k in ALTERNATIVE_WAITS))[:4]:
                 reports.append((fn, hex(a), t, r))
         for line in asm.split("\n"):
             m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)

@@ -114,8 +114,8 @@ def test_struct_abi_and_validation():
     (dict(M=9, tuning=(9, 1, 0, 0), N=8192, K=8192), "gemm_w4_rows_kernel<16x16>"),   # ... tuning[1] = 1: one
     (dict(M=200, tuning=(9, 0, 0, 0)), "gemm_w4_rows_kernel<64x16>"),                   # ... at any M: 64-row blocks along grid.y
     (dict(M=4, gs=32, N=8192, K=8192), "gemm_w4_rows_kernel<16x16>"),   # groups of 32 at M >= 2: nothing but the coverage kernel behind it on shapes the streaming kernel refuses
-    (dict(M=300, gs=32), "gemm_wn_stream_kernel"),                      # ... up to 64 rows only where N % 64 == 0: beyond, the round-4 streaming kernel (round 6, ADVICE r5: the rows kernel would re-stream the weights once per 32-row block)
-    (dict(M=300, gs=32, N=4112), "gemm_w4_rows_kernel<32x16>"),         # ... N % 64 != 0: still the only specialised kernel, any M (32-row blocks along grid.y)
+    (dict(M=300, gs=32), "gemm_w4_rows_kernel<32x16>"),                 # ... any M (32-row blocks along grid.y; round 6 measured the streaming kernel behind it 5 - 7 x slower: profiles/r06/probe_g32_rows_vs_stream.log)
+    (dict(M=300, gs=32, N=4112), "gemm_w4_rows_kernel<32x16>"),         # ... N % 64 != 0 too
     (dict(M=40, N=4112, K=4096), "gemm_w4_rows_kernel<48x16>"),         # N % 64 != 0 (N % 16 == 0)
     (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile64,8w>"),   # ... 64-column tiles x 2 where they still fill the chip
     (dict(M=8, N=6144, K=4096), "gemm_wn_direct_kernel<tile32>"),      # 192 blocks of 32 columns, unsplit: 4 waves
