@@ -537,7 +537,13 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
                 // (round 3 sweep over 22 LLM shapes: 4-bit M = 1 also wins on every 6144 <= N <= 12288 with K <= 8192 — 6144 x 4096 5.6
                 //  vs 7.0 us, 8192 x 3072 5.6 vs 6.2, 8960 x 1536 5.1 vs 5.5, 11008 x 4096 7.9 vs 8.5 — and loses on narrow N, K > 8192
                 //  under 64-column tiles, and N >= 13824)
-                const bool wins = a.M >= 2 ? (a.W_nbits != 4 || a.N < 12288) : (a.W_nbits == 4 ? (a.N >= 6144 && ((cols == 32 && a.K >= 8192 && a.K < 12288) || (a.N <= 12288 && a.K <= 8192))) : (cols <= 32 || a.K <= 8192));   // 2-bit: 64-column tiles too unless K is long (16384^2: 18.0 vs 17.4)
+                // Round 6: with gemv_wn_kernel on counted asm loads (no drain at the head of its chunk loop) the dot-product family is ahead at ONE row
+                // on 20 of 22 LLM shapes for 4-bit words (8192^2 9.14 vs 9.86 us, 12288 x 4096 7.76 vs 8.56, 11008 x 4096 7.70 vs 7.98; 6144 x 4096
+                // 5.73 vs 5.49 the other way) and on 16 of 22 for 2-bit words (5120^2 5.65 vs 7.17, 13824 x 5120 7.26 vs 9.00, 28672 x 8192 16.2 vs 20.6,
+                // 8192^2 7.07 vs 7.87) — profiles/r06/probe_m1_shapes_w{4,2}.log.  The matrix-core GEMV keeps one row only for 2-bit words over a K that
+                // is not a multiple of 1024 (K = 8960 / 9728 / 11008: 7.26 vs 8.04, 7.84 vs 8.22, 8.29 vs 9.16), and 2 .. 4 rows as before.
+                (void)cols;
+                const bool wins = a.M >= 2 ? (a.W_nbits != 4 || a.N < 12288) : (a.W_nbits == 2 && a.K % 1024 != 0);
                 if ((a.tuning[3] & 1024) || a.tuning[0] != 0 || wins) { r.kind = K_GEMV_WN; r.wn = pm; r.lp = lm; return; }
             }
         }

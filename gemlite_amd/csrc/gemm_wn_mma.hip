@@ -223,7 +223,10 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
         const bool f16 = tag_dt == GEMLITE_DT_FP16;
         const int expv = (int)(((unsigned)a.tuning[3] >> 20) & 63u) << 8;  // (development builds: K-loop ablation, see mma_exp_lookup)
-        const void* fn = f16 ? mma_lookup_f16(6, nbits, v, xdt, expv) : mma_lookup_bf16(6, nbits, v, xdt, expv);
+        // round 6: the 64 x 64 tiles fetch their packed words through LDS (one DMA request per wave and step instead of four register loads per
+        // lane: cfgA M = 256 16.5 -> see profiles/r06/probe_mma_wl.log); tuning[3] & 131072 keeps the round-5 register path (A/B runs)
+        const bool wl = v == 0 && x16 && nbits == 4 && expv == 0 && !(a.tuning[3] & 131072);
+        const void* fn = f16 ? mma_lookup_f16(6, nbits, wl ? 4 : v, xdt, expv) : mma_lookup_bf16(6, nbits, wl ? 4 : v, xdt, expv);
         if (!fn) return false;
         p.splitk = splitk;
         p.rows_per_slice = rows;
@@ -233,7 +236,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         lp.name = xdt ? (nbits == 4 ? "gemm_a8w4_mma_kernel<64x64>" : "gemm_a8w2_mma_kernel<64x64>") : nn[nbits == 4 ? 0 : 1][vmi == 2 ? 0 : 1];
         lp.grid = dim3((unsigned)tiles, splitk, 1);
         lp.block = dim3(512, 1, 1);
-        const size_t stages = (size_t)V_NST[v] * bm * ks * (x16 ? 2 : 1);
+        const size_t stages = (size_t)V_NST[v] * (bm * ks * (x16 ? 2 : 1) + (wl ? 8192 : 0));
         const size_t xch = (size_t)3 * 2 * vmi * 4 * 64 * 16;  // K-part exchange: [kh - 1][cg][mi][e4][lane] float4
         const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * (64 + 4) * 4 + 16;
         lp.lds_bytes = stages > xch ? stages : xch;
@@ -337,6 +340,9 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
                      (splitk >= 4 || (a.tuning[3] & (2048 | 256))) &&
                      xdt == 0 && (nbits == 4 || nbits == 2) && tiles * splitk <= resident_block_limit();
     if (use_xch) fn = f16 ? mma_lookup_f16(4, nbits, mi, 0, 1) : mma_lookup_bf16(4, nbits, mi, 0, 1);
+    // round 6: the 128 x 128 tiles of 4-bit words under 16-bit activations fetch their packed words through LDS as well (slab + ticket combine)
+    const bool wl128 = !wide && !use_xch && mi == 4 && x16 && nbits == 4 && expv == 0 && !(a.tuning[3] & 131072);
+    if (wl128) fn = f16 ? mma_lookup_f16(7, nbits, mi, 0, 0) : mma_lookup_bf16(7, nbits, mi, 0, 0);
     if (!fn) return false;
     p.splitk = splitk;
     p.rows_per_slice = rows;  // ALL packed rows: the kernel derives each slice's step range itself
@@ -358,7 +364,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     lp.grid = dim3((unsigned)tiles, splitk, 1);
     lp.block = dim3(512, 1, 1);
     const int nst = mi == 8 ? 2 : (mi == 4 ? 3 : (nbits == 8 ? 2 : (mi == 2 ? 3 : 4)));  // LDS stages of x (mma_pick_mi)
-    const size_t stages = (size_t)nst * bm * ks * es;
+    const size_t stages = (size_t)nst * (bm * ks * es + (wl128 ? 8192 : 0));
     const size_t xch = (size_t)4 * mi * 4 * 64 * 16;  // K-half exchange: [cg][mi][e4][lane] float4
     const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * (bn + 4) * 4 + 16;
     lp.lds_bytes = stages > xch ? stages : xch;

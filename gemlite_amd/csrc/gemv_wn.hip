@@ -889,7 +889,7 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         // LDS-x path with 8 waves (tuning[2] == 8; auto when every wave still gets >= 4 chunks: the long-K shapes, where
         // one wave per SIMD spends ~2/3 of its time in unpack arithmetic that nothing overlaps with the weight stream)
         if (!xd && r == 4 && (cq >= 3 || a.tuning[2] == 8) && (nbits == 4 || nbits == 2) &&
-            (a.tuning[2] == 8 || (a.tuning[2] == 0 && GEMV_AUTO_8W && nbits == 2 && (units / splitk) >= 32)))
+            (a.tuning[2] == 8 || (a.tuning[2] == 0 && GEMV_AUTO_8W && (units / splitk) >= (nbits == 2 ? 32 : 128))))  // (round 6, counted asm loads: 4-bit 16384^2 24.5 vs 25.0 us with 8 waves)
             nw = 8;
         const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, xd, nw)
                                                            : pick_bits<bf16_tag>(nbits, mb, cq, r, xd, nw);
@@ -978,8 +978,13 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
     // against 8.9 / 7.8 for 32-column tiles with K slices).  A long K over a narrow N (K >= 12288, fewer than 160 tiles of 64 columns)
     // takes 64-column tiles with the fewest K slices that give 160 blocks: 8192 x 28672 23.1 vs 26.2 us, 4096 x 14336 10.6 vs 12.2,
     // 5120 x 13824 12.9 vs 13.6.
-    const int64_t want_blocks = nbits == 4 ? 160 : 256;
-    if (nbits == 4 && sk == 0 && a.N < 2048 && a.K <= 12288 && try_plan(2, 1)) return true;
+    // Round 6 (profiles/r06/probe_m1_shapes_w2.log): 2-bit words follow the same rule — the widest tile with >= 160 blocks (128 over a short K:
+    // 8960 x 1536 64-column tiles 4.41 / 4.75 us for 2- / 4-bit against 5.05 / 6.54 for 32-column ones) — 5120^2 5.65 (32-column) vs 6.54 us,
+    // 13824 x 5120 7.26 vs 10.3, 28672 x 8192 16.2 vs 21.9; and narrow layers up to N = 3072 over a long K take 16-column tiles unsplit
+    // (2048 x 8192: 5.44 / 6.78 vs 6.5 / 7.2; 3072 x 8192: 5.56 / 6.95 vs 6.5 / 7.8).
+    const int64_t want_blocks = (nbits == 4 || nbits == 2) ? (a.K <= 2048 ? 128 : 160) : 256;
+    const bool narrow16 = a.N < 2048 || (a.N <= 3072 && a.K >= 8192 && a.K % 2048 == 0);   // (2560 x 9728 keeps 32-column tiles x 2 slices: 7.88 vs 8.96)
+    if ((nbits == 4 || (nbits == 2 && a.K % 2048 == 0)) && sk == 0 && narrow16 && a.K <= 12288 && try_plan(2, 1)) return true;
     if (nbits == 4 && sk == 0 && a.K >= 12288 && a.N % 64 == 0 && a.N / 64 < 160 && a.N / 64 >= 40) {
         int lsk = 2;
         while ((a.N / 64) * lsk < 160) lsk *= 2;
