@@ -91,7 +91,7 @@ def test_struct_abi_and_validation():
     (dict(M=1, N=8192, K=8192), "gemv_wn_kernel<tile32>"),   # round 6: the dot-product family on counted asm loads (9.14 us) is ahead of the matrix-core GEMV (9.86) at one row
     (dict(M=1, N=8192, K=8192, tuning=(0, 0, 0, 512)), "gemv_wn_kernel<tile32>"),   # tuning[3] & 512: the dot-product family
     (dict(M=1, tuning=(0, 0, 0, 1024)), "gemv_mfma_kernel<tile16>"),   # tuning[3] & 1024: the matrix-core kernel wherever it applies
-    (dict(M=1, N=16384, K=16384), "gemv_wn_kernel<tile64>"),
+    (dict(M=1, N=16384, K=16384), "gemv_wn_kernel<tile64,8w>"),   # round 6: 8 waves from 128 chunks per block (24.5 vs 25.0 us on counted asm loads)
     (dict(M=2), "gemv_mfma_kernel<tile16,rows4>"),    # 2..4 rows: the decode MFMA kernel (x staged once per wave in LDS)
     (dict(M=4), "gemv_mfma_kernel<tile16,rows4>"),
     (dict(M=4, tuning=(0, 0, 0, 512)), "gemm_wn_direct_kernel<tile16>"),   # 2 <= M <= 32: registers-only MFMA kernel, K not split
