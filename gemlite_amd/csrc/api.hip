@@ -501,9 +501,13 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
             // 4096^2 M = 64 17.0 / 114, M = 128 31.9 / 184, M = 256 61.5 / 324, M = 1024 242 / 1242; 8192^2 M = 256 208 / 1244; 11008 x 4096 M = 256
             // 172 / 926 — the rows kernel is 5 - 7 x faster at every M, so it keeps every group-32 layer.  (What these layers lack at M > 64 is a
             // group-32 form of the MFMA tile kernel: 61.5 us against 16.8 for groups of 128 at 4096^2 M = 256.)
-            const bool only_here = p.gs_shift == 5 || a.N % 64 != 0;
+            // Round 6, later: groups of 32 also have the 32-row tiles of the 8-wave kernel (template parameter NGS = 2, gemm_wn_mma.hip) — for M > 32
+            // over N % 128 == 0, K % 256 == 0 they win (4096^2, rows / tiles: M = 128 31.4 / 17.6, M = 256 61.6 / 25.4, M = 1024 244 / 89.9 us;
+            // profiles/r06/probe_g32_w4.log), so the rows kernel keeps groups of 32 up to its 32 rows per block and wherever the tiles do not apply.
+            const bool g32_tiles = p.gs_shift == 5 && a.M > 32 && a.N % 128 == 0 && a.K % 256 == 0;
+            const bool only_here = (p.gs_shift == 5 && !g32_tiles) || a.N % 64 != 0;
             const bool in_budget = a.W_nbits == 4 ? rows5_pays(a.M, a.N, a.K, p.gs_shift) : rows5_pays_w2(a.M, a.N, a.K, p.gs_shift);
-            if (a.tuning[0] == 9 || only_here || in_budget) {
+            if (a.tuning[0] == 9 || only_here || (in_budget && !g32_tiles)) {
                 WnParams pr = p;
                 LaunchPlan lr{};
                 if (plan_gemm_wn_rows(a, pr, lr)) { r.kind = K_STREAM_WN; r.wn = pr; r.lp = lr; return; }

@@ -154,7 +154,10 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_wn_direct_kernel(const WnPara
 #pragma unroll
         for (int j = 0; j < V; ++j) tot[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
+    // (read into a scalar register and waited for HERE: a vector load left pending into the K loop is answered with `s_waitcnt vmcnt(0)` at its
+    //  first use in EVERY iteration — the loop-head drain of rounds 3-5, see gemv_wn.hip)
+    float scalar_zero = 0.f;
+    if (p.zero_is_scalar) scalar_zero = (float)__builtin_amdgcn_readfirstlane(((const int32_t*)p.zeros)[0]);
     const float bz = (p.w_mode == 1 || p.w_mode == 3) ? -1.f : (p.w_mode == 4 ? 1.f : 0.f);
     const bool b_times_s = p.w_mode == 3;
     constexpr float QSCALE = SUBN ? 16777216.0f : 1.0f;  // 2^24: undo the subnormal interpretation

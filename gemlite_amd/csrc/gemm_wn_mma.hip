@@ -172,7 +172,48 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if ((a.stride_xm * es) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte LDS-DMA pieces
     const int oal = a.output_dtype == GEMLITE_DT_FP32 ? 16 : 8;  // 4 outputs per store
     if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
-    if (p.group_size % 64 != 0) return false;  // one (scale, zero) pair per column and 64-k sub-block
+    if (p.group_size % 64 != 0) {
+        // Groups of 32 (round 6): 32-row tiles with TWO (scale, zero) pairs per column and 64-k sub-block (template parameter NGS = 2).
+        // What reaches this: 1- and 8-bit packed words and fp8 activations x 4- / 2-bit words at M >= 2 (4- / 2-bit words under 16-bit activations
+        // have the rows kernel in front) — shapes that ran on the coverage kernel until round 5 (4096^2 M = 64: ~3.8 ms).
+        if (p.group_size != 32 || a.K % 256 != 0 || a.N % mma::BN != 0 || xdt == GEMLITE_DT_INT8) return false;
+        if (a.tuning[0] != 0 || a.tuning[2] != 0) return false;
+        const int rows = (int)(a.K / e), units = (int)(a.K / 256);
+        const int64_t tiles = (int64_t)(a.N / mma::BN) * ((a.M + 31) / 32);
+        int splitk = 0;
+        if (a.tuning[1] > 0) splitk = a.tuning[1];
+        else {
+            for (int sk = 1; sk <= units && sk <= 32; ++sk) {
+                if (sk > 1 && units / sk < 4) continue;
+                splitk = sk;
+                if (tiles * sk >= 224) break;
+            }
+            if (!splitk) splitk = 1;
+        }
+        if (splitk > units) return false;
+        if ((int64_t)rows * a.stride_wk * 4 >= (1ll << 31) || ((int64_t)a.M * a.stride_xm + a.K) * es >= (1ll << 31)) return false;
+        if (((int64_t)(a.K / 32) * p.stride_meta_g + a.N) * 2 >= (1ll << 31)) return false;
+        if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
+        const bool f16 = tag_dt == GEMLITE_DT_FP16;
+        const void* fn = f16 ? mma_lookup_f16(8, nbits, 1, xdt, 0) : mma_lookup_bf16(8, nbits, 1, xdt, 0);
+        if (!fn) return false;
+        p.splitk = splitk;
+        p.rows_per_slice = rows;
+        p.combine = 0;
+        lp.fn = fn;
+        static const char* g32_names[4] = {"gemm_w4_mma_kernel<32x128,g32>", "gemm_w2_mma_kernel<32x128,g32>", "gemm_w1_mma_kernel<32x128,g32>", "gemm_w8_mma_kernel<32x128,g32>"};
+        lp.name = xdt ? (nbits == 4 ? "gemm_a8w4_mma_kernel<32x128,g32>" : "gemm_a8w2_mma_kernel<32x128,g32>") : g32_names[nbits == 4 ? 0 : (nbits == 2 ? 1 : (nbits == 1 ? 2 : 3))];
+        lp.grid = dim3((unsigned)tiles, splitk, 1);
+        lp.block = dim3(512, 1, 1);
+        const size_t stages = (size_t)2 * 32 * 256 * es;
+        const size_t xch = (size_t)4 * 1 * 4 * 64 * 16;
+        const size_t c_b = (size_t)32 * mma::C_PITCH * 4 + 16;
+        lp.lds_bytes = stages > xch ? stages : xch;
+        if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
+        lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * 32 * mma::BN * 4 : 0;
+        lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
+        return true;
+    }
     // Tile rows (32 MI) and K slices.  A dequantised fragment feeds MI MFMAs, so tall tiles need the least unpack arithmetic
     // per MFMA; short tiles and K slices fill the 256 CUs (one 8-wave block each) — but every K slice costs slab traffic
     // through memory (the XCD L2s are not coherent) plus a serial tail in the last block to arrive, and narrow row tiles

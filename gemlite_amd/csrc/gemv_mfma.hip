@@ -245,7 +245,10 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_mfma_kernel(const WnParams p)
     f32x4 tot[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) tot[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float scalar_zero = p.zero_is_scalar ? (float)((const int32_t*)p.zeros)[0] : 0.f;
+    // (read into a scalar register and waited for HERE: a vector load left pending into the K loop is answered with `s_waitcnt vmcnt(0)` at its
+    //  first use in EVERY iteration — the loop-head drain of rounds 3-5, see gemv_wn.hip)
+    float scalar_zero = 0.f;
+    if (p.zero_is_scalar) scalar_zero = (float)__builtin_amdgcn_readfirstlane(((const int32_t*)p.zeros)[0]);
     const float bz = (p.w_mode == 1 || p.w_mode == 3) ? -1.f : (p.w_mode == 4 ? 1.f : 0.f);
     const bool b_times_s = p.w_mode == 3;
     const int mrow = MB == 1 ? 0 : (c < MB ? c : MB - 1);  // A row of this lane (rows past the tile repeat the last one; never stored)

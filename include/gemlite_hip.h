@@ -164,7 +164,9 @@ typedef struct gemlite_hip_forward_args {
     int64_t stride_meta_g, stride_meta_n;
     int64_t stride_sx_m;
 
-    /* Planner overrides (0 = library default everywhere; what helper.autotune_layer() searches and the tuning table
+    /* Planner overrides — the named values are the enums GEMLITE_T0_* / GEMLITE_T2_* / GEMLITE_TF_* below this struct (round 6, VERDICT r5 #9:
+     * the numbers of rounds 1-5 stay valid, the names are what new callers should write).
+     * (0 = library default everywhere; what helper.autotune_layer() searches and the tuning table
      * stores — the counterpart of the reference's per-shape Triton autotune configs).  Meaning per kernel family:
      *   packed GEMV (M = 1)        [0] 2/3/4 = 16-/32-/64-column tiles   [1] K slices   [2] 4/8/16 waves per block
      *                              (82 = 8 waves, 2 rows per lane; 48 = 4 waves, 8 rows per lane)   [3] & 3: 1 = x through LDS,
@@ -215,11 +217,59 @@ typedef struct gemlite_hip_forward_args {
      *                              7 = the streaming GEMV of rounds 2-3 up to 4 rows
      *   unpacked 8-bit under 16-bit x (A16W8)   [0] 4 = the 16-column rows kernel at any M (default for 2..64 rows; above: the 8-wave
      *                              tile kernel, [1] K slices, [2] tile rows / 32), 7 = the streaming kernel of rounds 1-3
+     *   tiled, round 6             [3] & 131072 = the packed words of the 64 x 64 / 128 x 128 4-bit tiles as register loads (the round-5 path; default:
+     *                              through LDS-DMA, one request per wave and step); groups of 32 run on 32-row tiles with two metadata pairs per
+     *                              sub-block ("<32x128,g32>": [1] K slices, [0] and [2] must be 0)
      *   [3] & 4: development timeline stamps (needs a workspace)   [3] & 8: XCD-aware (tile, K slice) map (opt-in).
+     *   [3] >> 20: K-loop ablation of development builds (make MMA_EXTRA=-DGL_MMA_EXPERIMENTS); ignored by the shipped library.
      *   A value that does not apply to the shape makes the planner fall through to its own choice or to another family;
      *   it never produces a wrong result. */
     int32_t tuning[4];
 } gemlite_hip_forward_args;
+
+/* ---- names for the tuning[] values (per kernel family; the comment inside the struct has what each one selects) ------------------------- */
+enum gemlite_hip_tuning0 {                 /* tuning[0]: which kernel of the family */
+    GEMLITE_T0_AUTO = 0,
+    /* packed words, one row (dot-product GEMV family): tile width */
+    GEMLITE_T0_GEMV_TILE16 = 2, GEMLITE_T0_GEMV_TILE32 = 3, GEMLITE_T0_GEMV_TILE64 = 4,
+    /* packed words, matrix-core GEMV (1 .. 4 rows): tile width */
+    GEMLITE_T0_MFMA_GEMV_TILE16 = 21, GEMLITE_T0_MFMA_GEMV_TILE32 = 22, GEMLITE_T0_MFMA_GEMV_TILE64 = 24,
+    /* packed words, 2 .. 32 rows (registers-only MFMA kernel): tile width; 3 = the 8-wave tile kernel instead */
+    GEMLITE_T0_FEWROWS_TILE16 = 1, GEMLITE_T0_FEWROWS_TILE32 = 2, GEMLITE_T0_FEWROWS_TILE64 = 4, GEMLITE_T0_FEWROWS_USE_TILES = 3,
+    /* packed 4- / 2-bit words, 2 .. 64 rows: the decode-shaped rows kernel at any M it takes */
+    GEMLITE_T0_ROWS_KERNEL = 9,
+    /* packed words, many rows: 1 = LDS-staged streaming kernel, 2 = the 4-wave tile kernel of round 1 */
+    GEMLITE_T0_TILED_STREAM = 1, GEMLITE_T0_TILED_ROUND1 = 2,
+    /* unpacked 8-bit (A8W8) */
+    GEMLITE_T0_A8W8_STREAM = 1, GEMLITE_T0_A8W8_ROUND1 = 2, GEMLITE_T0_A8W8_ROWS = 4, GEMLITE_T0_A8W8_SQ64 = 5, GEMLITE_T0_A8W8_ROUND3 = 6,
+    GEMLITE_T0_A8W8_M1_ROUND2 = 7, GEMLITE_T0_A8W8_M1_DECODE_FP8_WIDE = 8, GEMLITE_T0_A8W8_SQ128 = 10,
+    /* block-scaled (MX / NVFP4) */
+    GEMLITE_T0_MX_COVERAGE = 1, GEMLITE_T0_MX_TILES = 2, GEMLITE_T0_MX_TILES_256 = 3, GEMLITE_T0_MX_ROWS = 4, GEMLITE_T0_MX_STREAM = 5, GEMLITE_T0_MX_SQ64 = 6,
+    /* 8-bit activations x packed words (A8Wn, BitNet int8); unpacked 8-bit weights under 16-bit activations (A16W8) */
+    GEMLITE_T0_A8WN_ROWS = 4, GEMLITE_T0_A8WN_GEMV = 7, GEMLITE_T0_A16W8_ROWS = 4, GEMLITE_T0_A16W8_STREAM = 7
+};
+enum gemlite_hip_tuning2 {                 /* tuning[2]: tile geometry of the 8-wave tile kernel (other families: waves per block, see the struct) */
+    GEMLITE_T2_AUTO = 0,
+    GEMLITE_T2_ROWS32 = 1, GEMLITE_T2_ROWS64 = 2, GEMLITE_T2_ROWS128 = 4, GEMLITE_T2_ROWS256 = 8,        /* x 128 columns */
+    GEMLITE_T2_WIDE_128x256 = 20, GEMLITE_T2_WIDE_256x256 = 24,                                              /* 256-column tiles */
+    GEMLITE_T2_NARROW_64x64 = 32, GEMLITE_T2_NARROW_64x64_K512 = 33, GEMLITE_T2_NARROW_128x64 = 34, GEMLITE_T2_NARROW_128x64_RING6 = 35,
+    GEMLITE_T2_GEMV_8WAVES_2ROWS = 82, GEMLITE_T2_GEMV_4WAVES_8ROWS = 48
+};
+enum gemlite_hip_tuning_flags {            /* tuning[3]: bit flags (A/B switches and test hooks; 0 = the shipped defaults) */
+    GEMLITE_TF_GEMV_X_THROUGH_LDS = 1, GEMLITE_TF_GEMV_X_DIRECT = 2,        /* (& 3) */
+    GEMLITE_TF_TIMELINE = 4,                     /* development stamps (needs a workspace) */
+    GEMLITE_TF_XCD_SLICE_MAP = 8,                /* XCD-aware (tile, K slice) map of the tile kernel */
+    GEMLITE_TF_GEMV_ROUND2_KERNEL = 16, GEMLITE_TF_GEMV_DEFAULT_POLICY_LOADS = 32,
+    GEMLITE_TF_A8W8_WEIGHTS_FROM_MEMORY = 64,
+    GEMLITE_TF_COMBINE_TICKET = 128, GEMLITE_TF_COMBINE_HANDOVER_TEST = 256,
+    GEMLITE_TF_NO_MFMA_GEMV = 512, GEMLITE_TF_FORCE_MFMA_GEMV = 1024,
+    GEMLITE_TF_COMBINE_REDUCE_SCATTER_2 = 2048,
+    GEMLITE_TF_GEMV_ROUND3_DECODE = 4096,
+    GEMLITE_TF_NO_NARROW_TILES = 16384,
+    GEMLITE_TF_QUANT_NO_PRODUCER_TEST = 32768,
+    GEMLITE_TF_NO_ROWS_KERNEL = 65536,           /* the round-4 choice for 2 .. 64 rows */
+    GEMLITE_TF_WORDS_AS_REGISTER_LOADS = 131072  /* round 6: the round-5 weight path of the 64 x 64 / 128 x 128 4-bit tiles */
+};
 
 /* Library / ABI identification (host only, no device access). */
 int gemlite_hip_abi_version(void);

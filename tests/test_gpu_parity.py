@@ -1793,3 +1793,72 @@ def test_rows5_kernel_is_deterministic_graph_capturable_and_linear():
     assert torch.count_nonzero(f(torch.zeros_like(x))) == 0
     y2 = f(x * 2)
     assert torch.allclose(y2.float(), 2 * y0.float(), rtol=2e-3, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------ round 6: groups of 32 on the tile kernel
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("nbits", [1, 2, 4, 8])
+def test_mma_kernel_groups_of_32(nbits, tdt):
+    """Round 6: groups of 32 on the 8-wave MFMA kernel — two (scale, zero) pairs per column and 64-k sub-block, 32-row
+    tiles (template parameter NGS = 2).  1- / 8-bit packed words at M >= 2 ran on the coverage kernel until round 5 (and 2-bit words whose K is
+    not a multiple of 512); 4- / 2-bit words are forced onto it here (matmul_type GEMM + tuning[3] & 65536 skips the rows kernel).  Ragged M,
+    several row and column tiles, K of 5 steps (uneven slices), forced split-K, every W_group_mode — against the float64 oracle."""
+    from gemlite_amd.core import _hip_matmul
+    N, K = 256, 1280
+    for zeros_kind, fma in (("tensor", True), ("tensor", False), ("none", True)):
+        lin = _make_layer(N, K, nbits, 32, tdt, seed=50 + nbits, zeros_kind=zeros_kind, fma=fma)
+        for M in (2, 29, 64, 100, 300):
+            x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
+            y_or = _oracle_from_layer(lin, x)
+            for sk in (0, 1, 3):
+                tuning = (0, sk, 0, 65536)
+                name = _kernel_name(lin, x, 4, tuning)
+                assert name == f"gemm_w{nbits}_mma_kernel<32x128,g32>", name
+                y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), 4, tuning)
+                torch.cuda.synchronize()
+                _compare(f"mma_g32/w{nbits}/{str(tdt)[6:]}/{zeros_kind}{int(fma)}/M{M}/sk{sk}", y, y_or, lin.output_dtype.value,
+                         abs_gate=None if nbits == 8 else 1e-3, extra=dict(kernel=name))
+    # what the planner does by default with these layers at M >= 2: no coverage kernel
+    lin = _make_layer(512, 1024, nbits, 32, tdt, seed=3)
+    for M in (2, 16, 64, 200):
+        x = torch.from_numpy(O.gen_x(M, 1024, seed=M).astype(np.float32)).to(tdt).to(DEV)
+        name = _kernel_name(lin, x)
+        assert "generic" not in name, (M, name)
+        y = lin(x)
+        torch.cuda.synchronize()
+        _compare(f"mma_g32/default/w{nbits}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x), lin.output_dtype.value,
+                 abs_gate=None if nbits == 8 else 1e-3, extra=dict(kernel=name))
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_a8wn_fp8_activations_groups_of_32(nbits):
+    """A8Wn dynamic with groups of 32 (coverage kernel until round 5 above the rows kernel's 64 rows): fp8 e4m3 activations x packed words with
+    two metadata pairs per sub-block, against the float64 oracle on the same fp8-rounded operands."""
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    tdt = torch.float16
+    N, K = 512, 1280
+    out_code = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+    W_q, sc, zr = O.gen_data(N, K, nbits, 32, seed=90 + nbits)
+    lin = H.A8Wn_HQQ_INT_dynamic(device=DEV, dtype=tdt, post_scale=False, W_nbits=nbits).from_weights(
+        torch.from_numpy(W_q), torch.from_numpy(sc).to(tdt), torch.from_numpy(zr).to(tdt))
+    for M in (70, 100, 300):
+        x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
+        xq_t, sx_t = scale_activations_per_token(x, w_dtype=torch.float8_e4m3fn)
+        xq, sx = O.scale_activations_per_token(x, O.FP8E4)
+        y_or = O.forward_packed(xq, lin.W_q.data.cpu().numpy(), O.to_f64(lin.scales.data), O.to_f64(lin.zeros.data), W_nbits=nbits,
+                                group_size=lin.group_size, W_group_mode=lin.W_group_mode,
+                                channel_scale_mode=lin.channel_scale_mode, scales_x=sx, weight_cast_code=O.FP8E4)
+        for sk in (0, 2):
+            tuning = (0, sk, 0, 0)
+            a = gemlite_amd.core._static_args(lin.W_q, lin.scales, lin.zeros, lin.get_meta_args())
+            a.matmul_type, a.M, a.x, a.out, a.scales_x = -1, M, 0x1000, 0x1000, 0x1000
+            a.stride_xm, a.stride_xk, a.stride_om, a.stride_on = K, 1, N, 1
+            a.input_dtype = lin.input_dtype.value
+            for i in range(4):
+                a.tuning[i] = tuning[i]
+            name = _hip.load().gemlite_hip_kernel_name(_hip.C.byref(a)).decode()
+            assert name == f"gemm_a8w{nbits}_mma_kernel<32x128,g32>", name
+            y = _hip_matmul(xq_t, lin.W_q, lin.scales, lin.zeros, sx_t, lin.get_meta_args(), -1, tuning)
+            torch.cuda.synchronize()
+            _compare(f"a8wn_g32/w{nbits}/M{M}/sk{sk}", y, y_or, out_code, abs_gate=None, extra=dict(kernel=name))

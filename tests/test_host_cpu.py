@@ -114,7 +114,8 @@ def test_struct_abi_and_validation():
     (dict(M=9, tuning=(9, 1, 0, 0), N=8192, K=8192), "gemm_w4_rows_kernel<16x16>"),   # ... tuning[1] = 1: one
     (dict(M=200, tuning=(9, 0, 0, 0)), "gemm_w4_rows_kernel<64x16>"),                   # ... at any M: 64-row blocks along grid.y
     (dict(M=4, gs=32, N=8192, K=8192), "gemm_w4_rows_kernel<16x16>"),   # groups of 32 at M >= 2: nothing but the coverage kernel behind it on shapes the streaming kernel refuses
-    (dict(M=300, gs=32), "gemm_w4_rows_kernel<32x16>"),                 # ... any M (32-row blocks along grid.y; round 6 measured the streaming kernel behind it 5 - 7 x slower: profiles/r06/probe_g32_rows_vs_stream.log)
+    (dict(M=300, gs=32), "gemm_w4_mma_kernel<32x128,g32>"),             # ... above 32 rows (round 6): the 32-row tiles of the 8-wave kernel with two metadata pairs per sub-block (61.6 -> 25.4 us at M = 256) ...
+    (dict(M=24, gs=32), "gemm_w4_rows_kernel<32x16>"),                  # ... the rows kernel up to its 32 rows per block
     (dict(M=300, gs=32, N=4112), "gemm_w4_rows_kernel<32x16>"),         # ... N % 64 != 0 too
     (dict(M=40, N=4112, K=4096), "gemm_w4_rows_kernel<48x16>"),         # N % 64 != 0 (N % 16 == 0)
     (dict(M=8, N=8192, K=8192), "gemm_wn_direct_kernel<tile64,8w>"),   # ... 64-column tiles x 2 where they still fill the chip
@@ -149,8 +150,12 @@ def test_struct_abi_and_validation():
     (dict(M=200, nbits=8), "gemm_w8_mma_kernel<64x128>"),   # tallest tile with >= 128 tiles: at most two K slices
     (dict(M=48, tuning=(1, 0, 0, 0)), "gemm_wn_stream_kernel"),          # tuning[0] = 1: LDS-staged streaming kernel
     (dict(M=48, tuning=(2, 0, 0, 0)), "gemm_w4_tiled_kernel<128x128>"),  # tuning[0] = 2: the 4-wave kernel of round 1
-    (dict(M=48, gs=32, tuning=(0, 0, 0, 65536)), "gemm_wn_stream_kernel"),     # group size 32: two groups per 64-k sub-block (the round-4 choice)
-    (dict(M=48, gs=32), "gemm_w4_rows_kernel<32x16>"),
+    (dict(M=48, gs=32, tuning=(0, 0, 0, 65536)), "gemm_w4_mma_kernel<32x128,g32>"),     # group size 32 above 32 rows: the tile kernel's g32 form (round 6) whether or not the rows kernel is switched off
+    (dict(M=8, nbits=1, gs=32), "gemm_w1_mma_kernel<32x128,g32>"),             # round 6: 1- and 8-bit packed words with groups of 32 at M >= 2 leave the coverage kernel
+    (dict(M=200, nbits=8, gs=32), "gemm_w8_mma_kernel<32x128,g32>"),
+    (dict(M=8, nbits=2, gs=32, K=4352), "gemm_w2_mma_kernel<32x128,g32>"),     # ... and 2-bit words whose K is not a multiple of 512 (the rows kernel's chunk)
+    (dict(M=256, nbits=2, gs=32, in_dt=3, out_dt=2, meta_dt=2, zeros_dt=2, w_mode=4, c_mode=2), "gemm_a8w2_mma_kernel<32x128,g32>"),   # ... fp8 activations x packed words
+    (dict(M=48, gs=32), "gemm_w4_mma_kernel<32x128,g32>"),   # round 6: groups of 32 above 32 rows on the tile kernel
     # K = 11008 / 8960 (Llama-2-7B down_proj, Qwen2.5-1.5B): specialised kernels at every M, never the coverage kernel
     (dict(M=1, N=4096, K=11008), "gemv_w4_decode3_kernel<tile16,16w>"),
     (dict(M=1, N=4096, K=11008, gs=64), "gemv_w4_decode3_kernel<tile16,16w>"),
