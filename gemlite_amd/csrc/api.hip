@@ -504,7 +504,10 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
             // Round 6, later: groups of 32 also have the 32-row tiles of the 8-wave kernel (template parameter NGS = 2, gemm_wn_mma.hip) — for M > 32
             // over N % 128 == 0, K % 256 == 0 they win (4096^2, rows / tiles: M = 128 31.4 / 17.6, M = 256 61.6 / 25.4, M = 1024 244 / 89.9 us;
             // profiles/r06/probe_g32_w4.log), so the rows kernel keeps groups of 32 up to its 32 rows per block and wherever the tiles do not apply.
-            const bool g32_tiles = p.gs_shift == 5 && a.M > 32 && a.N % 128 == 0 && a.K % 256 == 0;
+            // (profiles/r06/probe_g32_w4_m33_64.log, rows / tiles: 4096^2 M = 40 .. 64 16.8 .. 17.3 / 13.2; 8192^2 M = 40 .. 64 52 / 27 and M = 24 / 32
+            //  27.5 / 18.3; 11008 x 4096 M = 40 .. 64 47.5 / 30 — from 17 rows where the rows kernel's N / 16 blocks need more than one round)
+            const bool g32_tiles = p.gs_shift == 5 && a.N % 128 == 0 && a.K % 256 == 0 &&
+                                   (a.M > 32 || (a.M > 16 && a.K >= 2048 && a.N / 16 > gl::resident_block_limit()));
             const bool only_here = (p.gs_shift == 5 && !g32_tiles) || a.N % 64 != 0;
             const bool in_budget = a.W_nbits == 4 ? rows5_pays(a.M, a.N, a.K, p.gs_shift) : rows5_pays_w2(a.M, a.N, a.K, p.gs_shift);
             if (a.tuning[0] == 9 || only_here || (in_budget && !g32_tiles)) {

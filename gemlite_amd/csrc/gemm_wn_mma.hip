@@ -15,6 +15,13 @@ const void* mma_lookup_bf16(int kind, int nbits, int mi, int xdt, int xch);
 //     the L2 -> LDS path is the limit: 4096 x 11008 M = 256, 344 MB, 33.3 -> 36.5; below 192 tiles too many CUs idle);
 //   * 96 <= t64 <= 128 (one row tile with K <= 8192: from 64): TWO K slices (<= 256 blocks: one round; 4096^2 M = 128: 15.4 -> 13.7);
 //   * the 128-row narrow tiles never beat the 128-column choice by more than 1 %: forced variants only.
+// LDS of the round-6 epilogue of blocks whose K is not split over blocks: the KH partial tiles [KH][BM][BN + 4] fp32 (the kernel takes that
+// path when they fit 144 KiB — DIRECT_EPI in gemm_wn_mma_kernel.inc)
+static size_t direct_epi_bytes(int splitk, int kh, int bm, int bn) {
+    const size_t b = (size_t)kh * bm * (bn + 4) * 4;
+    return (splitk == 1 && kh >= 2 && b <= 144 * 1024) ? b : 0;
+}
+
 static int narrow_auto(int64_t M, int64_t N, int64_t K, int es) {
     if (M <= 32 || N % 64 != 0 || K % 256 != 0) return 0;
     const int64_t t64 = (N / 64) * ((M + 63) / 64);
@@ -77,6 +84,7 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         const size_t xch = (size_t)3 * 2 * 2 * 4 * 64 * 16;  // K-part exchange: [kh - 1][cg][mi][e4][lane] float4
         const size_t c_b = (size_t)64 * (64 + 4) * 4 + 16;
         lp.lds_bytes = stages > xch ? stages : xch;
+        { const size_t de = direct_epi_bytes(splitk, 4, 64, 64); if (lp.lds_bytes < de) lp.lds_bytes = de; }
         if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
         lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * 64 * 64 * 4 : 0;
         lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
@@ -141,6 +149,7 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     const size_t xch = (size_t)4 * mi * 4 * 64 * 16;
     const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * mma::C_PITCH * 4 + 16;
     lp.lds_bytes = stages > xch ? stages : xch;
+    { const size_t de = direct_epi_bytes(splitk, 2, bm, mma::BN); if (lp.lds_bytes < de) lp.lds_bytes = de; }
     if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
     lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * mma::BN * 4 : 0;
     lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
@@ -209,6 +218,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         const size_t xch = (size_t)4 * 1 * 4 * 64 * 16;
         const size_t c_b = (size_t)32 * mma::C_PITCH * 4 + 16;
         lp.lds_bytes = stages > xch ? stages : xch;
+        { const size_t de = direct_epi_bytes(splitk, 2, 32, mma::BN); if (lp.lds_bytes < de) lp.lds_bytes = de; }
         if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
         lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * 32 * mma::BN * 4 : 0;
         lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
@@ -281,6 +291,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         const size_t xch = (size_t)3 * 2 * vmi * 4 * 64 * 16;  // K-part exchange: [kh - 1][cg][mi][e4][lane] float4
         const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * (64 + 4) * 4 + 16;
         lp.lds_bytes = stages > xch ? stages : xch;
+        { const size_t de = direct_epi_bytes(splitk, 4, bm, 64); if (lp.lds_bytes < de) lp.lds_bytes = de; }
         if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
         lp.slab_bytes = splitk > 1 ? (uint64_t)tiles * splitk * bm * 64 * 4 : 0;
         lp.ws_bytes = splitk > 1 ? COUNTER_BYTES + lp.slab_bytes : 0;
@@ -409,6 +420,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     const size_t xch = (size_t)4 * mi * 4 * 64 * 16;  // K-half exchange: [cg][mi][e4][lane] float4
     const size_t c_b = (size_t)(bm < mma::C_ROWS ? bm : mma::C_ROWS) * (bn + 4) * 4 + 16;
     lp.lds_bytes = stages > xch ? stages : xch;
+    { const size_t de = direct_epi_bytes(splitk, wide ? 1 : 2, bm, bn); if (lp.lds_bytes < de) lp.lds_bytes = de; }
     if (lp.lds_bytes < c_b) lp.lds_bytes = c_b;
     if (p.combine == 1) {  // output staging tile of the owned rows + the S - 1 inbound copies of them
         const size_t owb = (size_t)mi / splitk;

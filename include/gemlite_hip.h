@@ -268,7 +268,8 @@ enum gemlite_hip_tuning_flags {            /* tuning[3]: bit flags (A/B switches
     GEMLITE_TF_NO_NARROW_TILES = 16384,
     GEMLITE_TF_QUANT_NO_PRODUCER_TEST = 32768,
     GEMLITE_TF_NO_ROWS_KERNEL = 65536,           /* the round-4 choice for 2 .. 64 rows */
-    GEMLITE_TF_WORDS_AS_REGISTER_LOADS = 131072  /* round 6: the round-5 weight path of the 64 x 64 / 128 x 128 4-bit tiles */
+    GEMLITE_TF_WORDS_AS_REGISTER_LOADS = 131072, /* round 6: the round-5 weight path of the 64 x 64 / 128 x 128 4-bit tiles */
+    GEMLITE_TF_ROUND5_TILE_EPILOGUE = 262144     /* round 6: the two-barrier K-part join of the unsplit tiles instead of the direct one */
 };
 
 /* Library / ABI identification (host only, no device access). */

@@ -16,7 +16,7 @@ bench.WORKLOADS.update({"a16w4_4096_m128": (4096, 4096, 4, 128, 128, "bf16", 32,
                         "a16w4_11008_m256": (11008, 4096, 4, 128, 256, "bf16", 12, "mfma"), "a16w4_4096x11008_m256": (4096, 11008, 4, 128, 256, "bf16", 12, "mfma")})
 for name in sys.argv[1:] or ["a16w4_4096_m256", "a16w4_8192_m256", "a16w4_4096_m128", "a16w4_4096_m192", "a16w4_8192_m128", "a16w4_4096_m256_f16", "a16w4_11008_m256", "a16w4_4096x11008_m256", "a16w4_8192_m2048"]:
     ref = None
-    for label, t in (("wl", (0, 0, 0, 0)), ("regs", (0, 0, 0, 131072))):
+    for label, t in (("wl", (0, 0, 0, 0)), ("regs", (0, 0, 0, 131072)), ("wl_r5_epilogue", (0, 0, 0, 262144)), ("wl", (0, 0, 0, 0)), ("r5", (0, 0, 0, 131072 + 262144))):
         core.TUNING_OVERRIDE = t if any(t) else None
         try:
             r = bench.Runner(name, dev, lib, layers=4 if "2048" in name else None)

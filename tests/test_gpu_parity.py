@@ -1618,11 +1618,12 @@ def test_small_magnitude_fp16_activations_on_the_decode_kernels(amp):
             (4, 4096, 4096, 1, (0, 0, 0, 4096), "gemv_w4_decode_kernel", 4e-4),       # round 5: split accumulators there too
             (4, 4096, 4096, 1, (0, 0, 0, 16), "gemv_wn_kernel<tile16,xdirect,16w>", 4e-4),   # ... and in the 4-bit forms of gemv_wn_kernel: x direct,
             (4, 4096, 8192, 1, (0, 0, 0, 512), "gemv_wn_kernel<tile16>", 4e-4),              #     x staged through LDS
-            (4, 8192, 4096, 1, (0, 0, 0, 0), "gemv_mfma_kernel", 4e-4),                      # round 6: exact planes on the matrix core
-            (4, 8192, 8192, 1, (0, 0, 0, 0), "gemv_mfma_kernel", 4e-4),                      #     (the 8192^2 decode shape of the bench line)
+            (4, 8192, 4096, 1, (0, 0, 0, 1024), "gemv_mfma_kernel", 4e-4),                   # round 6: exact planes on the matrix core (forced: one row of
+            (4, 8192, 8192, 1, (0, 0, 0, 1024), "gemv_mfma_kernel", 4e-4),                   #     4-bit words defaults to the dot-product family since round 6)
+            (4, 8192, 8192, 1, (0, 0, 0, 0), "gemv_wn_kernel<tile32>", 4e-4),                #     ... the default of the 8192^2 decode shape of the bench line
             (4, 1024, 4096, 3, (0, 0, 0, 0), "gemv_mfma_kernel", 4e-4),                      #     2 .. 4 rows
             (4, 16384, 4096, 1, (24, 0, 0, 1024), "gemv_mfma_kernel<tile64>", 4e-4),         #     64-column tiles
-            (2, 1024, 4096, 1, (0, 0, 0, 0), "gemv_w2_mfma_kernel", 4e-4),                   #     2-bit words: four planes
+            (2, 1024, 4096, 1, (0, 0, 0, 1024), "gemv_w2_mfma_kernel", 4e-4),                #     2-bit words: four planes
             (2, 4096, 8192, 1, (24, 0, 0, 1024), "gemv_w2_mfma_kernel<tile64>", 4e-4),
             (2, 4096, 8192, 1, (0, 0, 0, 512), "gemv_wn_kernel", 4e-4),                      # round 6: four accumulator sets (BASELINE configs[4]'s decode kernel)
             (1, 4096, 4096, 1, (0, 0, 0, 0), "gemv_wn_kernel", 4e-4)):                       # ... eight (1-bit words)
@@ -1684,7 +1685,10 @@ def test_rows5_kernel_two_bit_words(gs, tdt):
             torch.cuda.synchronize()
             _compare(f"rows5-w2/{N}x{K}g{gs}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x), lin.output_dtype.value, extra=dict(kernel=name))
             if gs == 32 or N % 64 != 0:
-                assert _kernel_name(lin, x).startswith("gemm_w2_rows_kernel<"), (M, _kernel_name(lin, x))
+                # (round 6: groups of 32 above 32 rows over N % 128 == 0 run on the tile kernel's g32 form)
+                g32_tiles = gs == 32 and M > 32 and N % 128 == 0 and K % 256 == 0
+                want = "gemm_w2_mma_kernel<32x128,g32>" if g32_tiles else "gemm_w2_rows_kernel<"
+                assert _kernel_name(lin, x).startswith(want), (M, _kernel_name(lin, x))
 
 
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
@@ -1765,7 +1769,8 @@ def test_rows5_kernel_shapes_strides_and_defaults(N, K, gs):
     if gs == 32 or N % 64 != 0:
         for M in (2, 16, 200):
             xm = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
-            assert _kernel_name(lin, xm).startswith("gemm_w4_rows_kernel<"), (M, _kernel_name(lin, xm))
+            g32_tiles = gs == 32 and M > 32 and N % 128 == 0 and K % 256 == 0   # round 6: the tile kernel's g32 form above 32 rows
+            assert _kernel_name(lin, xm).startswith("gemm_w4_mma_kernel<32x128,g32>" if g32_tiles else "gemm_w4_rows_kernel<"), (M, _kernel_name(lin, xm))
             y = lin(xm)
             torch.cuda.synchronize()
             _compare(f"rows5-only-here/{N}x{K}g{gs}/M{M}", y, _oracle_from_layer(lin, xm), 1)
