@@ -731,20 +731,14 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
     typedef typename std::conditional<INT, int, float>::type word_t;
     typedef word_t word4 __attribute__((ext_vector_type(4)));
     constexpr int C_PITCH = BN + 4;
-    {
-        acc_t* xch = (acc_t*)smem;  // [rb][cb][lane]
-        if (kh == 1) xch[(rb * 2 + cb) * 64 + lane] = acc;
-        __syncthreads();
-        if (kh == 0) acc += xch[(rb * 2 + cb) * 64 + lane];
-        __syncthreads();
-    }
-    word_t* ct = (word_t*)smem;  // [64][C_PITCH]
-    if (kh == 0) {
+    // (round 6: BOTH K halves drop their partial tile into LDS in output order and every thread adds the two while it reads its 16-byte row segment
+    //  — one barrier; rounds 4-5 handed the second half to the first in fragment order, added, transposed: three barriers with half of the block
+    //  idle.  Same addition, same order: bit-identical.)
+    word_t* ct = (word_t*)smem;  // [2 K halves][64][C_PITCH]
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            ct[r * C_PITCH + cb * 32 + col] = acc[e];
-        }
+    for (int e = 0; e < 16; ++e) {
+        const int r = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        ct[(kh * 64 + r) * C_PITCH + cb * 32 + col] = acc[e];
     }
     __syncthreads();
 #pragma unroll
@@ -752,7 +746,8 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
         const int u = tid + 512 * i, r = u >> 4, c4 = (u & 15) * 4;
         const int m = m0 + r;
         if (m < p.M) {
-            const word4 v = *(const word4*)(ct + r * C_PITCH + c4);
+            const word4 v0 = *(const word4*)(ct + r * C_PITCH + c4), v1 = *(const word4*)(ct + (64 + r) * C_PITCH + c4);
+            const word4 v = v0 + v1;
             store_out4_any(p.epi, (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, m, (int64_t)nt * BN + c4);
         }
     }
@@ -1012,7 +1007,7 @@ bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, Laun
     lp.grid = dim3((unsigned)tiles, 1, 1);
     lp.block = dim3(512, 1, 1);
     lp.lds_bytes = (size_t)nst * (64 + 64) * 256;
-    if (lp.lds_bytes < 64 * 68 * 4) lp.lds_bytes = 64 * 68 * 4;
+    if (lp.lds_bytes < 2 * 64 * 68 * 4) lp.lds_bytes = 2 * 64 * 68 * 4;  // (the two K halves of the epilogue)
     lp.ws_bytes = 0;
     lp.slab_bytes = 0;
     return true;

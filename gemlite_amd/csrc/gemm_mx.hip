@@ -1533,20 +1533,13 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_mx_sq_kernel(con
 
     // ---- epilogue: add the two K halves, transpose through LDS, 4 outputs per store
     constexpr int C_PITCH = BN + 4;
-    {
-        f32x16* xch = (f32x16*)smem;  // [rb][cb][lane]
-        if (kh == 1) xch[(rb * 2 + cb) * 64 + lane] = acc;
-        __syncthreads();
-        if (kh == 0) acc += xch[(rb * 2 + cb) * 64 + lane];
-        __syncthreads();
-    }
-    float* ct = (float*)smem;  // [64][C_PITCH]
-    if (kh == 0) {
+    // (round 6: both K halves drop their partial tile into LDS in output order, ONE barrier, every thread adds the two while it reads its row
+    //  segment — see gemm_a8w8_sq_kernel; same addition, same order: bit-identical to the three-barrier form of rounds 4-5)
+    float* ct = (float*)smem;  // [2 K halves][64][C_PITCH]
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            ct[r * C_PITCH + cb * 32 + col] = acc[e];
-        }
+    for (int e = 0; e < 16; ++e) {
+        const int r = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        ct[(kh * 64 + r) * C_PITCH + cb * 32 + col] = acc[e];
     }
     __syncthreads();
     const float post = p.mx_post;
@@ -1555,7 +1548,7 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_mx_sq_kernel(con
         const int u = tid + 512 * i, r = u >> 4, c4 = (u & 15) * 4;
         const int m = m0 + r;
         if (m < p.M) {
-            const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4);
+            const f32x4 v = *(const f32x4*)(ct + r * C_PITCH + c4) + *(const f32x4*)(ct + (64 + r) * C_PITCH + c4);
             store_out4_any(p.epi, v * (f32x4){post, post, post, post}, m, (int64_t)n0 + c4);
         }
     }
@@ -1603,7 +1596,7 @@ bool plan_gemm_mx_sq(const gemlite_hip_forward_args& a, GenericParams& g, Launch
     lp.block = dim3(512, 1, 1);
     const size_t stage = (size_t)64 * ((f4 ? 128 : 256) + (f8 ? 256 : 128)) + 1024;
     lp.lds_bytes = (size_t)nst * stage;
-    if (lp.lds_bytes < 64 * 68 * 4) lp.lds_bytes = 64 * 68 * 4;
+    if (lp.lds_bytes < 2 * 64 * 68 * 4) lp.lds_bytes = 2 * 64 * 68 * 4;  // (the two K halves of the epilogue)
     lp.ws_bytes = 0;
     lp.slab_bytes = 0;
     return true;
