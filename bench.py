@@ -20,7 +20,7 @@ secondary figure only (`event_us`; an EMPTY kernel reads ~4 us through them: `ev
   roofline        — M=1 (the `value` workload): algorithmic bytes per launch / time per launch of the TIMED REGION.
   roofline.m256   — cfgA (4096^2) and cfgB (8192^2, BASELINE configs[2]) at M=256 in bf16: TFLOP/s against the dense bf16 MFMA peak;
                     `mfma_util` = matrix-pipe busy share from the committed SQ counter passes (profiles/mfma_util.json), or null.
-  roofline.cfg4   — BASELINE configs[3]: A8W8 int8 4096^2 at M = 1 / 16 / 256: the matmul alone (x pre-quantised outside the timed
+  roofline.cfg4   — BASELINE configs[3]: A8W8 int8 4096^2 at M = 1 / 16 / 256 (+ 32 / 64, round 6): the matmul alone (x pre-quantised outside the timed
                     region) AND `*_layer_e2e`: layer(x) with the dynamic activation quantisation inside the timed region (round 4).
   roofline.cfg5   — BASELINE configs[4]: A16W2 g128 and FP8 x FP8 16384^2 at M = 1 / 256 (+ `*_layer_e2e` for FP8).
   roofline.m1_bf16, roofline.rotation_ab — the bf16 twin of the headline; the headline step over 32 (286 MB) vs 64 (572 MB) distinct layers.
@@ -77,6 +77,8 @@ WORKLOADS = {
     # BASELINE config 4: A8W8 int8 dynamic (x pre-quantised per token outside the timed matmul; group = K: channel-wise)
     "a8w8_4096_m1": (4096, 4096, 8, 4096, 1, "int8", 32, "hbm"),
     "a8w8_4096_m16": (4096, 4096, 8, 4096, 16, "int8", 32, "hbm"),
+    "a8w8_4096_m32": (4096, 4096, 8, 4096, 32, "int8", 32, "hbm"),   # (round 6: the decode batches between the named 16 and 256 — VERDICT r5 item 5)
+    "a8w8_4096_m64": (4096, 4096, 8, 4096, 64, "int8", 32, "hbm"),
     "a8w8_4096_m256": (4096, 4096, 8, 4096, 256, "int8", 32, "mfma"),
     # BASELINE config 5, second half: FP8 x FP8 (e4m3, per-token x per-channel scales), 16384 x 16384
     "fp8_16384_m1": (16384, 16384, 8, 16384, 1, "fp8w8", 2, "hbm"),
@@ -566,8 +568,8 @@ def main():
                                     **{w + "_layer_e2e": block(w, e2e=True) for w in ("mx_a8w8_4096_m256", "mx_a4w4_4096_m256")}})
         # BASELINE configs[3]: A8W8 int8 channel-wise 4096^2, M in {1, 16, 256}: the matmul alone on a pre-quantised x, and
         # (`*_layer_e2e`) layer(x) as the product runs it, dynamic activation quantisation included
-        guarded("cfg4", lambda: {**{f"a8w8_int8_4096_m{m}": block(f"a8w8_4096_m{m}") for m in (1, 16, 256)},
-                                 **{f"a8w8_int8_4096_m{m}_layer_e2e": block(f"a8w8_4096_m{m}", e2e=True) for m in (1, 16, 256)}})
+        guarded("cfg4", lambda: {**{f"a8w8_int8_4096_m{m}": block(f"a8w8_4096_m{m}") for m in (1, 16, 32, 64, 256)},
+                                 **{f"a8w8_int8_4096_m{m}_layer_e2e": block(f"a8w8_4096_m{m}", e2e=True) for m in (1, 16, 32, 64, 256)}})
         # BASELINE configs[4]: A16W2 g128 and FP8 x FP8, 16384^2, M in {1, 256}
         guarded("cfg5", lambda: {"a16w2_16384_m1": block("a16w2_16384_m1"), "a16w2_16384_m256": block("a16w2_16384_m256"),
                                  "fp8_16384_m1": block("fp8_16384_m1"), "fp8_16384_m256": block("fp8_16384_m256"),

@@ -27,6 +27,7 @@ bool plan_gemm_a8w8(const gemlite_hip_forward_args& a, LaunchPlan& lp);
 bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq = false);
 bool plan_a16w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp);
+bool a16w8_rows_lds_pays(const gemlite_hip_forward_args& a);
 bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_a8w8_sq128(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp);
 bool plan_gemm_wn_tiled(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp);
@@ -713,6 +714,8 @@ coverage:
         // in registers); the per-channel pre-scale becomes the epilogue's channel scale.  tuning[0] = 4 keeps the rows kernel.
         // (rows vs tile, profiles/r04/probe_rows_vs_tiles*.log: the crossover sits at M N K ~ 850 M — 4096^2: M = 52, 8192^2: 13 (M = 64 there:
         //  67.6 vs 29.1 us), 14336 x 4096: 12, 4096 x 14336: 19)
+        //  round 6: the rows kernel with x through LDS first where IT is the faster one — a16w8_rows_lds_pays(), gemm_a8w8.hip)
+        if (a.tuning[0] == 0 && a16w8_rows_lds_pays(a) && plan_a16w8_rows(a, r.lp)) return;
         if ((a.tuning[0] == 2 || ((a.M > 64 || (a.M >= 2 && (int64_t)a.M * a.N * a.K > 850000000ll)) && a.tuning[0] == 0)) &&
             !(a.W_group_mode == 2 && a.channel_scale_mode != 0)) {
             WnParams p{};
@@ -976,7 +979,10 @@ int gemlite_hip_forward(const gemlite_hip_forward_args* args, void* stream) {
         return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
     }
     void* kargs[] = {(void*)&r.gp};
-    if (r.lp.lds_bytes > 65536) return GEMLITE_ERR_UNSUPPORTED;
+    {  // (round 6: w8_rows_lds_kernel stages x in up to 128 KB)
+        const int e = ensure_lds(r.lp.fn, r.lp.lds_bytes, dev);
+        if (e != GEMLITE_OK) return e;
+    }
     return launch(r.lp.fn, r.lp.grid, r.lp.block, kargs, r.lp.lds_bytes, st);
 }
 

@@ -16,10 +16,16 @@
 #include "gl_common.h"
 #include "gl_async.h"
 #include "gl_coopquant.h"
+#include "gl_w8cvt.h"
 
 #include <type_traits>
 
 namespace gl {
+
+bool plan_w8_rows_lds(const gemlite_hip_forward_args& a, LaunchPlan& lp, int mt, bool two);  // gemm_w8_rows.hip
+// row tiles per block of that kernel and whether the two-blocks-per-CU form applies: layers with more 16-column blocks than CUs, up to 32 rows
+static inline int w8_lds_mt(int64_t M) { return M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 48 ? 3 : 4)); }
+static inline bool w8_lds_two(const gemlite_hip_forward_args& a) { return a.N / 16 > resident_block_limit() && a.M <= 32; }
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -1280,6 +1286,22 @@ bool plan_a8w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp, bool fq) 
     if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || a.stride_xm % 16 != 0 || a.stride_wn % 16 != 0) return false;
     if ((int64_t)a.M * a.stride_xm + a.K >= (1ll << 31) || (int64_t)a.N * a.stride_wn + a.K >= (1ll << 31)) return false;
     const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+    // round 6: x through LDS in whole cache lines (gemm_w8_rows.hip; tuning[3] & 524288 keeps the register-fed kernel of round 3 below).  Measured
+    // on 4096^2, 8192^2, 14336 x 4096, 4096 x 14336, int8 and fp8, `layer(x)` (profiles/r06/probe_w8_rows_lds_*.log):
+    //   * layers whose 16-column blocks are ONE resident round (N <= 4096 on 256 CUs): ahead of the round-3 kernel from 2 rows (4096^2 M = 2 / 16 /
+    //     32 / 64: 9.2 / 10.8 / 12.6 / 17.2 -> 8.6 / 9.7 / 11.7 / 13.7 us) and ahead of every tile kernel while the blocks' re-reads of x stay below
+    //     256 MiB (4096 x 14336 M = 32 / 64 — 117 / 235 MB: 31.3 / 37.7 -> 25.7 / 31.9 us; the round-3 kernel's budget was 88 MB);
+    //   * more blocks than CUs: the 64-KB form, two blocks per CU, from 4 rows (8192^2 M = 4 / 8 / 16: 20.5 / 22.1 / 23.8 (tiles) -> 19.9 / 20.6 /
+    //     22.0); not on layers with 192 or more 64-column tiles, where the unsplit tiles take over from 5 rows (14336 x 4096 M = 8: 18.2 vs 19.8)
+    //     and the round-3 kernel is ahead below (M = 2 / 4: 17.8 / 18.6 vs 18.7 / 19.4).
+    if (!fq && !(a.tuning[3] & 524288) && a.K % 256 == 0) {
+        const int64_t blocks = a.N / 16;
+        const bool forced = a.tuning[0] == 4;
+        bool lds;
+        if (blocks <= resident_block_limit()) lds = (a.M >= 2 || forced) && (forced || (int64_t)a.M * a.K * blocks <= (256ll << 20));
+        else lds = a.M <= 32 && (forced ? a.M >= 2 : (a.M >= 4 && a.M <= 16 && a.N / 64 < 192));
+        if (lds && plan_w8_rows_lds(a, lp, w8_lds_mt(a.M), w8_lds_two(a))) return true;
+    }
     // every block re-reads its M rows of x from L2: M K bytes x N / 16 blocks.  Up to ~90 MB of that the 16-column blocks beat the
     // 8-wave tiles (4096^2: 7.5 / 8.8 / 13.4 us at M = 17 / 32 / 64 against 16.9 / 17.4 / 18.3; 8192^2 M = 17: 21.3 vs 24.7), beyond
     // they lose (8192^2 M = 32: 28.1 vs 24.9; M = 64: 43.9 vs 27.7) — profiles/r03/probe_a8w8_rows_mt.log.  tuning[0] = 4 forces them.
@@ -1372,37 +1394,10 @@ __global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) 
             xb[slot][t][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvoff[t], xo + 16u, 0);
         }
     };
-    // 8 weight bytes (two dwords) -> one B fragment: 8 values of the activation type
+    // 8 weight bytes (two dwords) -> one B fragment: 8 values of the activation type (gl_w8cvt.h: shared with w8_rows_lds_kernel)
     auto convert = [&](uint32_t lo, uint32_t hi) __attribute__((always_inline)) -> u32x4 {
-        u32x4 f = {0u, 0u, 0u, 0u};
-        const uint32_t d[2] = {lo, hi};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if constexpr (WDT == GEMLITE_DT_INT8) {
-                if constexpr (TR::DT == GEMLITE_DT_FP16) {
-                    const uint32_t u = d[h] ^ 0x80808080u;  // b + 128 as an unsigned byte
-                    const h2_t off = {(_Float16)1152.0f, (_Float16)1152.0f};
-                    // {0x64, u.b1, 0x64, u.b0} / {0x64, u.b3, 0x64, u.b2}: 1024 + (b + 128)
-                    const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, u, 0x04010400u), p1 = __builtin_amdgcn_perm(0x64646464u, u, 0x04030402u);
-                    f[2 * h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2_t, p0) - off);
-                    f[2 * h + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2_t, p1) - off);
-                } else {
-                    const int v = (int)d[h];
-                    const b2_t a = {(__bf16)(float)(int8_t)(v & 0xFF), (__bf16)(float)(int8_t)((v >> 8) & 0xFF)};
-                    const b2_t b = {(__bf16)(float)(int8_t)((v >> 16) & 0xFF), (__bf16)(float)(int8_t)((v >> 24) & 0xFF)};
-                    f[2 * h] = __builtin_bit_cast(uint32_t, a);
-                    f[2 * h + 1] = __builtin_bit_cast(uint32_t, b);
-                }
-            } else if constexpr (!MXW) {
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                constexpr bool E5 = WDT == GEMLITE_DT_FP8E5;
-                const f32x2 a = E5 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)d[h], false) : __builtin_amdgcn_cvt_pk_f32_fp8((int)d[h], false);
-                const f32x2 b = E5 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)d[h], true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)d[h], true);
-                f[2 * h] = (uint32_t)TR::from_float(a[0]) | ((uint32_t)TR::from_float(a[1]) << 16);
-                f[2 * h + 1] = (uint32_t)TR::from_float(b[0]) | ((uint32_t)TR::from_float(b[1]) << 16);
-            }
-        }
-        return f;
+        if constexpr (!MXW) return w8_to_frag<Tag, WDT>(lo, hi);
+        else return (u32x4){0u, 0u, 0u, 0u};
     };
     // block-scaled rows: 8 values (k = 8 h .. 8 h + 7 of the lane's 16) with the block scale applied by the converter
     auto convert_mx = [&](int slot, int h) __attribute__((always_inline)) -> u32x4 {
@@ -1486,6 +1481,19 @@ __global__ __launch_bounds__(512) void a16w8_rows_kernel(const GenericParams p) 
     }
 }
 
+// Where w8_rows_lds_kernel runs AHEAD of the 8-bit weight-only tile kernel (api.hip asks before its M N K > 850 M rule; measured `layer(x)`,
+// profiles/r06/probe_w8_rows_lds_*.log, A16W8_INT8 / _FP8):
+//   * one resident round of 16-column blocks (N <= 4096 on 256 CUs), 4 .. 64 rows, while the blocks' re-reads of x stay below 256 MiB:
+//     4096^2 M = 64 (134 MB) 17.0 (tile) -> 12.7 us; 4096 x 14336 M = 16 / 32 (117 / 235 MB) 26.0 / 26.8 -> 20.2 / 25.3, M = 64 (470 MB) 29.6 vs 34.3;
+//   * more blocks than CUs (the 64-KB form, two blocks per CU): up to 16 rows — 8192^2 M = 16: 24.4 -> 21.7, 14336 x 4096 M = 16: 23.0 -> 21.7;
+//     M = 24: 25.3 (tile) vs 25.6.
+bool a16w8_rows_lds_pays(const gemlite_hip_forward_args& a) {
+    if ((a.tuning[3] & 524288) || a.K % 256 != 0 || a.N % 16 != 0 || a.M < 4 || a.M > 64) return false;
+    const int64_t blocks = a.N / 16;
+    if (blocks <= resident_block_limit()) return (int64_t)a.M * a.K * 2 * blocks <= (256ll << 20);
+    return a.M <= 16;
+}
+
 // (block-scaled weight-only layers: input_dtype MXFP16 / MXBF16, W_nbits 8 (fp8 bytes) or 4 (two e2m1 codes per byte), group 32)
 bool plan_a16w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
     const bool mx = a.input_dtype == GEMLITE_DT_MXFP16 || a.input_dtype == GEMLITE_DT_MXBF16;
@@ -1501,6 +1509,10 @@ bool plan_a16w8_rows(const gemlite_hip_forward_args& a, LaunchPlan& lp) {
     if (a.stride_wk != 1 || a.stride_xk != 1 || a.N % 16 != 0 || a.K % 64 != 0) return false;
     if (((uintptr_t)a.x | (uintptr_t)a.w_q) % 16 != 0 || (a.stride_xm * 2) % 16 != 0 || a.stride_wn % 16 != 0) return false;
     if (((int64_t)a.M * a.stride_xm + a.K) * 2 >= (1ll << 31) || (int64_t)a.N * a.stride_wn + a.K >= (1ll << 31)) return false;
+    // round 6: x through LDS in whole cache lines (gemm_w8_rows.hip; tuning[3] & 524288 keeps the register-fed kernel of round 4 below) from 4
+    // rows — at 2 / 3 rows the two tie on one-round layers and the round-4 kernel leads on the others (a16w8_rows_lds_pays() has the numbers)
+    if (!mx && !(a.tuning[3] & 524288) && a.K % 256 == 0 && (a.M >= 4 || (a.tuning[3] & 1048576)) && (a.N / 16 <= resident_block_limit() || a.M <= 32) &&
+        plan_w8_rows_lds(a, lp, w8_lds_mt(a.M), w8_lds_two(a))) return true;
     const int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
     typedef void (*fn_t)(const GenericParams);
     fn_t fn = nullptr;

@@ -269,7 +269,10 @@ enum gemlite_hip_tuning_flags {            /* tuning[3]: bit flags (A/B switches
     GEMLITE_TF_QUANT_NO_PRODUCER_TEST = 32768,
     GEMLITE_TF_NO_ROWS_KERNEL = 65536,           /* the round-4 choice for 2 .. 64 rows */
     GEMLITE_TF_WORDS_AS_REGISTER_LOADS = 131072, /* round 6: the round-5 weight path of the 64 x 64 / 128 x 128 4-bit tiles */
-    GEMLITE_TF_ROUND5_TILE_EPILOGUE = 262144     /* round 6: the two-barrier K-part join of the unsplit tiles instead of the direct one */
+    GEMLITE_TF_ROUND5_TILE_EPILOGUE = 262144,    /* round 6: the two-barrier K-part join of the unsplit tiles instead of the direct one */
+    GEMLITE_TF_W8_ROWS_X_FROM_REGISTERS = 524288, /* round 6: the round-3 / round-4 few-row kernels of unpacked 8-bit weights (a8w8_rows_kernel / a16w8_rows_kernel)
+                                                    instead of w8_rows_lds_kernel (x through LDS in whole cache lines) */
+    GEMLITE_TF_W8_ROWS_LDS_BELOW_4_ROWS = 1048576 /* A16W8: take w8_rows_lds_kernel at 1 .. 3 rows too (default: from 4) */
 };
 
 /* Library / ABI identification (host only, no device access). */

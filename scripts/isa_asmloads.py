@@ -18,12 +18,12 @@ import tempfile
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import isa_loops as L
 
-FAMILIES = ("gemm_wn_mma_kernel", "gemm_w4_rows_kernel", "gemv_wn_kernel")
+FAMILIES = ("gemm_wn_mma_kernel", "gemm_w4_rows_kernel", "gemv_wn_kernel", "w8_rows_lds_kernel")
 # gemv_wn_kernel (round 6: gvw::ring2_run): the prologue requests up to two chunks behind uniform branches and the last one to three chunks run in
 # straight-line code BEHIND the loop — replayed in address order (no branch is followed), prologue and tail included, every conditional request
 # issued and every run of alternative waits taken at its weakest member
 LINEAR_WITH_TAIL = ("gemv_wn_kernel",)
-ALTERNATIVE_WAITS = ("gemm_w4_rows_kernel", "gemv_wn_kernel")
+ALTERNATIVE_WAITS = ("gemm_w4_rows_kernel", "gemv_wn_kernel", "w8_rows_lds_kernel")
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
 
@@ -145,7 +145,7 @@ def check():
                 if any(x[1].startswith("s_endpgm") for x in body):
                     continue
                 hot = sum(("v_mfma" in x[1] or "v_dot2" in x[1]) for x in body)
-                if hot >= 16 and (best is None or hot > best[2]):
+                if hot >= 16 and (best is None or hot > best[2] or (hot == best[2] and tgt == best[0])):  # (same head, later back edge: the longer body — a loop whose request block sits behind a conditional back edge)
                     best = (tgt, i, hot)
             if best is None:
                 return
@@ -163,10 +163,34 @@ def check():
                     if tgt is not None and i < tgt <= hi:
                         i = tgt
                         continue
+                # round 6 (w8_rows_lds_kernel): hipcc moves a conditional prologue request ("if (npieces > 1) issue_x(1, 1)") OUT of line — a
+                # conditional forward branch to a block behind the loop that issues the requests and branches back to the instruction after
+                # its origin.  The steady-state path takes it: splice the block in where it executes.
+                m = re.match(r"s_cbranch_\w+\s+(\d+)", lines[i][1])
+                if m and not linear_tail and int(m.group(1)) < 32768:
+                    tgt = index.get(lines[i][0] + 4 + int(m.group(1)) * 4)
+                    if tgt is not None and tgt > hi:
+                        blk, e = [], tgt
+                        while e < len(lines) and not lines[e][1].startswith(("s_cbranch", "s_branch", "s_endpgm")):
+                            blk.append(e)
+                            e += 1
+                        mb = re.match(r"(?:s_cbranch_\w+|s_branch)\s+(\d+)", lines[e][1]) if e < len(lines) else None
+                        has_req = any(lines[x][1].split()[0].startswith(("buffer_load", "global_load")) for x in blk)
+                        if mb and has_req and int(mb.group(1)) >= 32768:
+                            back = index.get(lines[e][0] + 4 + (int(mb.group(1)) - 65536) * 4)
+                            if back is not None and i < back <= i + 4:
+                                seq += blk
+                                i = back
+                                continue
                 i += 1
             seq += list(range(lo, hi + 1)) + list(range(lo, hi + 1))
             if linear_tail:
                 seq += list(range(hi + 1, len(lines)))
+            if os.environ.get("ISA_DEBUG") and os.environ["ISA_DEBUG"] in fn:
+                for x in seq:
+                    t0 = lines[x][1]
+                    if t0.split()[0].startswith(("buffer_", "global_", "s_waitcnt", "s_cbranch", "s_branch")):
+                        print("   ", hex(lines[x][0]), t0[:90])
             for (a, t, r) in replay(lines, seq, weakest_of_alternatives=any(k in fn for k in ALTERNATIVE_WAITS))[:4]:
                 reports.append((fn, hex(a), t, r))
         for line in asm.split("\n"):

@@ -39,7 +39,7 @@ HOT = ("gemm_wn_mma_kernel", "gemm_a8w8_lds_kernel", "gemm_a8w8_mma_kernel", "ge
        "gemv_w4_decode_kernel", "gemm_wn_direct_kernel", "a8w8_rows_kernel",
        # round 4 kernels (the list had not been extended) and round 5
        "gemv_w4_decode3_kernel", "a8w8_decode_kernel", "a16w8_decode_kernel", "a16w8_rows_kernel", "a8wn_rows_kernel", "gemm_a8w8_sq_kernel",
-       "gemm_mx_sq_kernel", "gemm_mx_tile_kernel", "mx_rows_kernel", "nvfp4_rows_kernel", "gemv_a8wn_kernel", "gemm_w4_rows_kernel",
+       "gemm_mx_sq_kernel", "gemm_mx_tile_kernel", "mx_rows_kernel", "nvfp4_rows_kernel", "gemv_a8wn_kernel", "gemm_w4_rows_kernel", "w8_rows_lds_kernel",
        "gemm_a8w8_sq128_kernel")
 # MFMA tile kernels with a known drain (baseline file, see its header): reported, not fatal; anything outside it fails the build.
 KNOWN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "isa_loops_known.txt")

@@ -550,7 +550,7 @@ def test_a8w8_mfma_kernel_matches_streaming_kernel_and_is_selected():
         assert torch.equal(y, y2), t
     for M in (2, 5, 16, 17, 31, 40, 64):  # few rows: 16-column blocks with 1 / 2 / 4 row tiles (round 3: up to 64 rows at this size)
         xs = (torch.randn(M, 4096) / 10).half().to(DEV)
-        want = "a8w8_rows_kernel<16x16>" if M <= 16 else ("a8w8_rows_kernel<32x16>" if M <= 32 else "a8w8_rows_kernel<64x16>")
+        want = "a8w8_rows_lds_kernel<%dx16>" % (16 if M <= 16 else (32 if M <= 32 else (48 if M <= 48 else 64)))   # (round 6; rounds 3-5: a8w8_rows_kernel)
         assert _kernel_name(lin, torch.empty(M, 4096, dtype=torch.int8)) == want
         ya = lin(xs)
         gemlite_amd.core.TUNING_OVERRIDE = (1, 0, 0, 0)
@@ -637,8 +637,8 @@ def test_a8w8_rows_kernel(kind):
         for M in (2, 3, 7, 16, 17, 29, 32, 33, 50, 64) + ((1,) if N == 512 else ()):
             x = (torch.randn(M, K, generator=g) / 10).half().to(DEV)
             xq, sx = scale_activations_per_token(x, qdt)
-            tun = (4, 0, 0, 0) if (M == 1 or M > 16) else None   # (forced: the x re-read rule sends 256 x 16384 at M > 21 elsewhere)
-            name = _kernel_name(lin, xq, -1, tun or (0, 0, 0, 0))
+            tun = (4 if (M == 1 or M > 16) else 0, 0, 0, 524288)   # (forced: the x re-read rule sends 256 x 16384 at M > 21 elsewhere; & 524288: round 6 moved these shapes to gemm_w8_rows.hip)
+            name = _kernel_name(lin, xq, -1, tun)
             assert name == ("a8w8_rows_kernel<16x16>" if M <= 16 else ("a8w8_rows_kernel<32x16>" if M <= 32 else "a8w8_rows_kernel<64x16>")), (M, name)
             y = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, tun)
             torch.cuda.synchronize()
@@ -723,7 +723,7 @@ def test_remaining_helper_processors_against_the_oracle(M):
                       ("a16w8-fp8", H.A16W8_FP8(device=DEV).from_weights(W))):
         y = lin(x)
         torch.cuda.synchronize()
-        assert _kernel_name(lin, x).startswith(("a16w8_rows_kernel", "a16w8_decode_kernel")), _kernel_name(lin, x)
+        assert _kernel_name(lin, x).startswith(("a16w8_rows_kernel", "a16w8_rows_lds_kernel", "a16w8_decode_kernel")), _kernel_name(lin, x)
         _compare(f"helpers/{name}/M{M}", y, _oracle_from_layer(lin, x), 1, abs_gate=5e-3, extra=dict(kernel=_kernel_name(lin, x)))
     W_q, sc, zr = O.gen_data(N, K, 4, 128, seed=3)
     Wt = torch.randint(-1, 2, (N, K)).half()
@@ -1122,6 +1122,117 @@ def test_a16w8_rows_kernel_against_the_oracle_and_the_streaming_kernel(proc, tdt
         _compare(f"a16w8-rows/{proc}/{str(tdt)[6:]}/M{M}", y, y_or, out_code, abs_gate=5e-3)
         rel = float((y.float() - y_old.float()).abs().mean() / y_old.float().abs().mean())
         assert rel < (2e-3 if tdt == torch.float16 else 8e-3), (proc, M, rel)
+
+
+ROUND4_W8_ROWS, W8_ROWS_LDS_FROM_1 = 524288, 1048576  # tuning[3]: keep the register-fed rows kernels / take the x-through-LDS one below 17 rows too
+
+
+def _w8_lds_name(fam, M):
+    return "%s_rows_lds_kernel<%dx16>" % (fam, 16 if M <= 16 else (32 if M <= 32 else (48 if M <= 48 else 64)))
+
+
+@pytest.mark.parametrize("kind", ["int8", "fp8e4", "fp8e5"])
+def test_a8w8_rows_lds_kernel(kind):
+    """Round 6: A8W8 at 1 .. 64 rows on w8_rows_lds_kernel (gemm_w8_rows.hip; replaces gemm_splitK_kernels.py:277-450 for BASELINE config 4's
+    decode batches): x through LDS in whole cache lines (every row-tile height = every piece geometry), weights in 256-k chunks dealt over
+    8 waves — K = 256 (seven waves idle), 256 * 9 (uneven deal), 16384 (eight chunks per wave), ragged M; against the oracle on the kernel's
+    own quantised inputs, and for int8 BIT-EXACT against the register-fed kernel of round 3."""
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    code = {"int8": O.INT8, "fp8e4": O.FP8E4, "fp8e5": O.FP8E5}[kind]
+    qdt = {"int8": torch.int8, "fp8e4": torch.float8_e4m3fn, "fp8e5": torch.float8_e5m2}[kind]
+    ran = set()
+    for (N, K) in ((512, 4096), (48, 256 * 9), (256, 16384), (64, 256), (32, 768)):
+        g = torch.Generator().manual_seed(N + K)
+        W = (torch.randn(N, K, generator=g) / 30).half()
+        proc = H.A8W8_int8_dynamic(device=DEV, dtype=torch.float16) if kind == "int8" else \
+            H.A8W8_dynamic(device=DEV, dtype=torch.float16, fp8=qdt)
+        lin = proc.from_weights(W)
+        for M in (1, 2, 7, 16, 17, 29, 32, 33, 48, 50, 64):
+            x = (torch.randn(M, K, generator=g) / 10).half().to(DEV)
+            xq, sx = scale_activations_per_token(x, qdt)
+            tun = (4, 0, 0, 0)  # (tuning[0] = 4: one row too, and past the x re-read budget)
+            name = _kernel_name(lin, xq, -1, tun)
+            assert name == _w8_lds_name("a8w8", M), (M, name)
+            ran.add(name)
+            y = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, tun)
+            y_r4 = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, (4, 0, 0, ROUND4_W8_ROWS))
+            torch.cuda.synchronize()
+            assert _kernel_name(lin, xq, -1, (4, 0, 0, ROUND4_W8_ROWS)).startswith("a8w8_rows_kernel<")
+            xq_o, sx_o = O.scale_activations_per_token(x, code)
+            y_or = (xq_o @ O.to_f64(lin.W_q.data)) * (sx_o.astype(np.float64) * O.to_f64(lin.scales.data).reshape(1, -1))
+            _compare(f"a8w8_rows_lds/{kind}/{N}x{K}/M{M}", y, y_or, 1, abs_gate=5e-3, extra=dict(kernel=name))
+            if kind == "int8":
+                assert torch.equal(y, y_r4), (N, K, M)
+            else:
+                assert float((y.float() - y_r4.float()).abs().mean() / y_r4.float().abs().mean()) < 1e-3, (N, K, M)
+    assert len(ran) == 4, ran
+    # the default from 2 rows (no tuning) on a layer whose 16-column blocks are one resident round
+    lin = H.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights((torch.randn(4096, 4096) / 30).half())
+    for M, want in ((2, "a8w8_rows_lds_kernel<16x16>"), (17, "a8w8_rows_lds_kernel<32x16>"), (40, "a8w8_rows_lds_kernel<48x16>"), (64, "a8w8_rows_lds_kernel<64x16>")):
+        assert _kernel_name(lin, torch.empty(M, 4096, dtype=torch.int8)) == want, (M, _kernel_name(lin, torch.empty(M, 4096, dtype=torch.int8)))
+    # more blocks than CUs: the 64-KB form (two blocks per CU), 4 .. 16 rows by default, up to 32 when forced — bit-exact against the round-3 kernel
+    g = torch.Generator().manual_seed(5)
+    lin = H.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights((torch.randn(8192, 1024, generator=g) / 30).half())
+    for M, tun, want in ((4, (0, 0, 0, 0), "a8w8_rows_lds_kernel<16x16,2/cu>"), (16, (0, 0, 0, 0), "a8w8_rows_lds_kernel<16x16,2/cu>"), (27, (4, 0, 0, 0), "a8w8_rows_lds_kernel<32x16,2/cu>")):
+        x = (torch.randn(M, 1024, generator=g) / 10).half().to(DEV)
+        xq, sx = scale_activations_per_token(x, torch.int8)
+        assert _kernel_name(lin, xq, -1, tun) == want, (M, _kernel_name(lin, xq, -1, tun))
+        y = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, tun)
+        y_r4 = _hip_matmul(xq, lin.W_q, lin.scales, lin.zeros, sx, lin.get_meta_args(), -1, (4, 0, 0, ROUND4_W8_ROWS))
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_r4), M
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("proc", ["A16W8_INT8", "A16W8_INT8_post", "A16W8_FP8", "A16W8_FP8e5"])
+def test_a16w8_rows_lds_kernel(proc, tdt):
+    """Round 6: 8-bit weight-only layers (helper.py:88-171) at 1 .. 64 rows (and 64-row blocks along grid.y above) on w8_rows_lds_kernel: 16-bit x
+    through LDS (the lane's sixteen k = two adjacent 16-byte slots: the permuted-k A fragments), int8 / e4m3 / e5m2 weights converted in
+    registers exactly as a16w8_rows_kernel does (gl_w8cvt.h), pre- and post-scale; against the float64 oracle and the round-4 kernel."""
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    torch.manual_seed(47)
+    out_code = gemlite_amd.dtypes.TORCH_TO_DTYPE[tdt].value
+    ran = set()
+    for N, K, Ms in ((1024, 2048 + 256, (1, 2, 16, 17, 33, 48, 49, 64, 65, 200)), (64, 256, (5, 20, 40, 64)), (48, 768, (3, 31, 47, 63)), (128, 8192, (16, 32, 48, 64))):
+        W = (torch.randn(N, K) / 30).to(tdt)
+        W[3, :] *= 6.0  # a column whose int8 codes use the whole range
+        if proc == "A16W8_FP8e5":
+            sc = (W.float().abs().amax(dim=1, keepdim=True) / 57344.0).clamp_(min=1e-6)
+            lin = H.A16W8(device=DEV, dtype=tdt).from_weights((W.float() / sc).to(torch.float8_e5m2), scales=sc)
+        else:
+            mk = {"A16W8_INT8": lambda: H.A16W8(device=DEV, dtype=tdt), "A16W8_INT8_post": lambda: H.A16W8(device=DEV, dtype=tdt, post_scale=True),
+                  "A16W8_FP8": lambda: H.A16W8_FP8(device=DEV, dtype=tdt)}[proc]
+            lin = mk().from_weights(W)
+        for M in Ms:
+            x = (torch.randn(M, K, device=DEV) / 10).to(tdt)
+            tun = (4, 0, 0, W8_ROWS_LDS_FROM_1 if M < 4 else 0)   # (by default from 4 rows)
+            name = _kernel_name(lin, x, -1, tun)
+            assert name == _w8_lds_name("a16w8", M), (M, name)
+            ran.add(name)
+            y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tun)
+            y_r4 = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, (4, 0, 0, ROUND4_W8_ROWS))
+            torch.cuda.synchronize()
+            assert _kernel_name(lin, x, -1, (4, 0, 0, ROUND4_W8_ROWS)).startswith("a16w8_rows_kernel<")
+            _compare(f"a16w8-rows-lds/{proc}/{str(tdt)[6:]}/{N}x{K}/M{M}", y, _oracle_from_layer(lin, x), out_code, abs_gate=5e-3)
+            rel = float((y.float() - y_r4.float()).abs().mean() / y_r4.float().abs().mean())
+            assert rel < (2e-3 if tdt == torch.float16 else 8e-3), (proc, M, rel)
+    assert len(ran) == 4, ran
+    # more blocks than CUs: the 64-KB form (two blocks per CU; 256- / 128-byte row pieces)
+    N, K = 8192, 1024
+    W = (torch.randn(N, K) / 30).to(tdt)
+    if proc == "A16W8_FP8e5":
+        sc = (W.float().abs().amax(dim=1, keepdim=True) / 57344.0).clamp_(min=1e-6)
+        lin = H.A16W8(device=DEV, dtype=tdt).from_weights((W.float() / sc).to(torch.float8_e5m2), scales=sc)
+    else:
+        lin = mk().from_weights(W)
+    for M, tun, want in ((4, (0, 0, 0, 0), "a16w8_rows_lds_kernel<16x16,2/cu>"), (16, (0, 0, 0, 0), "a16w8_rows_lds_kernel<16x16,2/cu>"), (29, (4, 0, 0, 0), "a16w8_rows_lds_kernel<32x16,2/cu>")):
+        x = (torch.randn(M, K, device=DEV) / 10).to(tdt)
+        assert _kernel_name(lin, x, -1, tun) == want, (M, _kernel_name(lin, x, -1, tun))
+        y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tun)
+        torch.cuda.synchronize()
+        _compare(f"a16w8-rows-lds-2cu/{proc}/{str(tdt)[6:]}/M{M}", y, _oracle_from_layer(lin, x), out_code, abs_gate=5e-3)
 
 
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])

@@ -202,18 +202,28 @@ def test_struct_abi_and_validation():
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_decode_kernel<tile16,16w>"),  # round 4: one wave per column, the row in flight at once
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(7, 0, 0, 0)), "kmajor_matmul_kernel"),
     (dict(M=1, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, K=4096 + 512), "kmajor_matmul_kernel"),  # K % 1024 != 0
-    (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),  # A8W8 int8, 2..16 rows: 16-column blocks
-    (dict(M=2, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),
-    (dict(M=17, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<32x16>"),  # round 3: 2 / 4 row tiles while the x re-reads stay < 88 MB
-    (dict(M=32, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<32x16>"),
-    (dict(M=8, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),
+    # A8W8 int8 / fp8, 2 .. 64 rows: 16-column blocks.  Round 6: x through LDS in whole cache lines (gemm_w8_rows.hip); tuning[3] & 524288 = the round-3 kernel
+    (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_lds_kernel<16x16>"),
+    (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 0, 524288)), "a8w8_rows_kernel<16x16>"),
+    (dict(M=2, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_lds_kernel<16x16>"),
+    (dict(M=2, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, K=4096 + 64), "a8w8_rows_kernel<16x16>"),   # K % 256 != 0
+    (dict(M=17, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_lds_kernel<32x16>"),
+    (dict(M=17, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 0, 524288)), "a8w8_rows_kernel<32x16>"),  # round 3: 2 / 4 row tiles while the x re-reads stay < 88 MB
+    (dict(M=32, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_lds_kernel<32x16>"),
+    (dict(M=8, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_lds_kernel<16x16,2/cu>"),   # more blocks than CUs: 64 KB of LDS, two blocks per CU
+    (dict(M=3, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),            # ... from 4 rows
+    (dict(M=16, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_lds_kernel<16x16,2/cu>"),  # ... up to 16 (23.8 (tiles) -> 22.0 us)
+    (dict(M=4, N=14336, K=4096, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<16x16>"),           # >= 192 column tiles of 64: round-3 kernel, then the tiles
     (dict(M=17, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),  # round 4: M N K > 800 M with >= 128 column tiles: the unsplit 64 x 64 tiles
     (dict(M=32, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),
     (dict(M=32, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_mma_kernel<32x128>"),  # (round 3: the 8-wave MFMA kernel)
-    (dict(M=40, N=4096, K=14336, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # 64 column tiles, long K: past the rows budget the 8-wave kernel
+    (dict(M=40, N=4096, K=14336, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_lds_kernel<48x16>"),  # one round of blocks, 147 MB of x re-reads (budget 256 MB; 4096 x 14336 M = 32: 31.3 -> 25.7 us)
+    (dict(M=40, N=4096, K=14336, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 0, 524288)), "gemm_a8w8_mma_kernel<32x128>"),  # (round 3: past the 88-MB budget the 8-wave kernel)
+    (dict(M=64, N=4096, K=28672, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_mma_kernel<32x128>"),  # 470 MB: tiles
     (dict(M=16, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 1, 0)), "gemm_a8w8_mma_kernel<32x128>"),
-    (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<64x16>"),
-    (dict(M=64, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_kernel<64x16>"),
+    (dict(M=48, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_lds_kernel<48x16>"),
+    (dict(M=64, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "a8w8_rows_lds_kernel<64x16>"),   # (4096^2 M = 64: 17.2 -> 13.7 us with the quantiser launch)
+    (dict(M=64, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 0, 524288)), "a8w8_rows_kernel<64x16>"),
     (dict(M=64, N=8192, K=8192, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # round 4 (39.5 -> 30.0 us)
     (dict(M=65, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # round 4: unsplit 64 x 64 tiles while they fit
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),  # one round of CUs (config 4: 21.7 -> 13.6 us) ...
@@ -233,11 +243,18 @@ def test_struct_abi_and_validation():
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_decode_kernel<tile16,16w>"),   # A16W8 int8, pre-scale, one row (round 4)
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(4, 0, 0, 0)), "a16w8_rows_kernel<16x16>"),
     (dict(M=2, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<16x16>"),   # from 2 rows: MFMA, weights converted in registers
-    (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "a16w8_rows_kernel<16x16>"),  # fp8 W, bf16 x
-    (dict(M=40, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_kernel<64x16>"),
+    (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "a16w8_rows_lds_kernel<16x16>"),  # fp8 W, bf16 x; round 6: from 4 rows x through LDS (gemm_w8_rows.hip)
+    (dict(M=8, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096, tuning=(0, 0, 0, 524288)), "a16w8_rows_kernel<16x16>"),
+    (dict(M=40, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_lds_kernel<48x16>"),
+    (dict(M=64, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "a16w8_rows_lds_kernel<64x16>"),   # ahead of the tile kernel while the x re-reads stay < 256 MB (17.0 -> 12.7 us)
+    (dict(M=64, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(0, 0, 0, 524288)), "gemm_a16w8_kernel<64x64>"),
+    (dict(M=64, N=4096, K=14336, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=14336), "gemm_a16w8_kernel<64x128>"),   # 470 MB: the tile kernel (29.6 vs 34.3 us)
+    (dict(M=16, N=8192, K=8192, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=8192), "a16w8_rows_lds_kernel<16x16,2/cu>"),  # more blocks than CUs: up to 16 rows ahead of the tiles (24.4 -> 21.7 us)
+    (dict(M=24, N=8192, K=8192, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=8192), "gemm_a16w8_kernel<32x128>"),
     (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "gemm_a16w8_kernel<64x128>"),  # above 64 rows: the MFMA tile kernel
     (dict(M=65, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "gemm_a16w8_kernel<64x64>"),  # round 4, late: narrow 64 x 64 tiles where narrow_auto() fires
-    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(4, 0, 0, 0)), "a16w8_rows_kernel<64x16>"),  # 64-row tiles along grid.y
+    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(4, 0, 0, 0)), "a16w8_rows_lds_kernel<64x16>"),  # 64-row tiles along grid.y
+    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(4, 0, 0, 524288)), "a16w8_rows_kernel<64x16>"),
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(7, 0, 0, 0)), "kmajor_w8a16_kernel"),  # A/B switch: rounds 1-3
     (dict(M=1, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096 + 16, K=4096 + 16), "kmajor_w8a16_kernel"),    # K % 64 != 0
     (dict(M=1, N=1000), "generic_matmul_kernel"),    # N not a multiple of 64

@@ -212,8 +212,11 @@ def _coded_a8w8(N, K, kind, tdt):
     return lin, (vals * s).t().contiguous()
 
 
-A8_FAMILIES = [("streaming", 1, (1, 0, 0, 0)), ("rows_m1", 1, (4, 0, 0, 0)), ("rows", 2, (0, 0, 0, 0)), ("rows", 16, (0, 0, 0, 0)),
-               ("rows32", 17, (0, 0, 0, 0)), ("rows32", 32, (0, 0, 0, 0)), ("rows64", 33, (0, 0, 0, 0)), ("rows64", 64, (4, 0, 0, 0)),
+A8_FAMILIES = [("streaming", 1, (1, 0, 0, 0)), ("rows_m1", 1, (4, 0, 0, 524288)), ("rows", 2, (0, 0, 0, 524288)), ("rows", 16, (0, 0, 0, 524288)),
+               ("rows32", 17, (0, 0, 0, 524288)), ("rows32", 32, (0, 0, 0, 524288)), ("rows64", 33, (0, 0, 0, 524288)), ("rows64", 64, (4, 0, 0, 524288)),
+               # round 6: x through LDS (gemm_w8_rows.hip) — the default from 2 rows; tuning[3] & 524288 = the round-3 kernel above
+               ("rows_lds16", 1, (4, 0, 0, 0)), ("rows_lds16", 9, (0, 0, 0, 0)), ("rows_lds32", 17, (0, 0, 0, 0)), ("rows_lds32", 32, (0, 0, 0, 0)), ("rows_lds48", 40, (0, 0, 0, 0)),
+               ("rows_lds64", 64, (4, 0, 0, 0)),
                ("mfma_r1", 64, (2, 0, 0, 0)), ("mma32", 29, (0, 1, 1, 0)), ("mma64_sk3", 64, (0, 3, 2, 0)),
                ("mma128", 128, (0, 1, 4, 0)), ("mma128_direct_b", 128, (0, 2, 4, 64)), ("mma256_sk5", 256, (0, 5, 8, 0)),
                ("auto_m1", 1, (0, 0, 0, 0)), ("auto_m100", 100, (0, 0, 0, 0)), ("auto_m256", 256, (0, 0, 0, 0))]
@@ -237,7 +240,40 @@ def test_a8w8_families_one_hot_times_position_coded_is_exact(kind, tdt):
         _exact(f"a8w8 {kind} {label} [{name}] {tdt}", Y, E)
         ran.append(name)
     assert {"a8w8_rows_kernel<16x16>", "a8w8_rows_kernel<32x16>", "a8w8_rows_kernel<64x16>"} <= set(ran), ran
-    assert any("lds" in r for r in ran) and any("mma" in r for r in ran), ran
+    assert {"a8w8_rows_lds_kernel<16x16>", "a8w8_rows_lds_kernel<32x16>", "a8w8_rows_lds_kernel<48x16>", "a8w8_rows_lds_kernel<64x16>"} <= set(ran), ran
+    assert any("gemm_a8w8_lds" in r for r in ran) and any("mma" in r for r in ran), ran
+
+
+@pytest.mark.parametrize("tdt", TDTS, ids=IDS)
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+def test_a16w8_rows_families_one_hot_times_position_coded_is_exact(kind, tdt):
+    """8-bit weight-only layers (round 6): one-hot 16-bit activations x position-coded int8 / e4m3 weights with power-of-two channel scales —
+    every output is ONE weight times one scale, exactly; a wrong k -> slot map of the permuted A fragments of w8_rows_lds_kernel (or a wrong
+    swizzle of a piece geometry) shows as a wrong row."""
+    N, K = 256, 1280
+    k = torch.arange(K).view(1, K)
+    n = torch.arange(N).view(N, 1)
+    s = torch.pow(2.0, ((n % 4) - 2).float())
+    if kind == "int8":
+        Wq = (((k * 3 + n * 5 + (k >> 6)) % 255) - 127).to(torch.int8)
+        lin = H.A16W8(device=DEV, dtype=tdt).from_weights(Wq.to(DEV), scales=s.to(tdt).to(DEV))
+    else:
+        b = ((k * 3 + n * 5 + (k >> 6)) % 256).to(torch.uint8)
+        b[(b & 0x7F) == 0x7F] = 0x3A
+        Wq = b.view(torch.float8_e4m3fn)
+        lin = H.A16W8_FP8(device=DEV, dtype=tdt).from_weights(Wq.to(DEV), scales=s.to(tdt).to(DEV))
+    E = (Wq.float() * s).t().contiguous()
+    if tdt == torch.bfloat16:
+        E = E.to(tdt).float()  # (the output's own rounding: |w| <= 127 * 2 fits 8 bits, e4m3 has 4)
+    ran = []
+    for M, tuning in ((2, (4, 0, 0, 1048576)), (5, (0, 0, 0, 0)), (16, (0, 0, 0, 524288)), (17, (0, 0, 0, 0)), (32, (0, 0, 0, 0)), (40, (0, 0, 0, 0)), (64, (4, 0, 0, 0)), (100, (4, 0, 0, 0)),
+                      (17, (0, 0, 0, 524288)), (64, (4, 0, 0, 524288))):
+        name = _name(lin, M, -1, tuning)
+        Y = _sweep(lambda x: _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning), M, K, tdt)
+        _exact(f"a16w8 {kind} M={M} [{name}] {tdt}", Y, E)
+        ran.append(name)
+    assert {"a16w8_rows_lds_kernel<16x16>", "a16w8_rows_lds_kernel<32x16>", "a16w8_rows_lds_kernel<48x16>", "a16w8_rows_lds_kernel<64x16>",
+            "a16w8_rows_kernel<16x16>", "a16w8_rows_kernel<32x16>", "a16w8_rows_kernel<64x16>"} <= set(ran), ran
 
 
 @pytest.mark.parametrize("tdt", TDTS, ids=IDS)
