@@ -628,7 +628,11 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_lds_kernel(const GenericPara
 // counted wait + one barrier per step, the DMAs of the stage just freed go out right behind the barrier.  The four blocks that
 // share a weight column tile sit on ONE XCD (block b runs on XCD b % 8; speed only) so that three of them read it from L2.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, int NST>
+// ILV (round 6): the step's four DMA requests are issued BETWEEN its MFMAs, behind the LDS reads of the step, and int8 alternates two
+// accumulators — a step is one barrier-to-barrier chain per wave (all eight waves in lockstep), and with the requests in front of the reads
+// (rounds 4-5) that chain was ~4 x 100 cycles of request issue + the LDS latency + four dependent MFMAs; the number of stages does not matter
+// beyond three (profiles/r06/probe_a8w8_sq_stages.log: 13.2 / 13.3 / 13.7 us with 3 / 4 / 5), the length of the chain does
+template <int DT, int NST, bool ILV = false>
 __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(const GenericParams p) {
     using namespace async;
     using AC = A8Acc<DT>;
@@ -698,6 +702,11 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
         fb[g] = (BM + rw) * PITCH + ((slot ^ (rw & 15)) << 4);
     }
     acc_t acc = AC::zero();
+    acc_t acc1 = AC::zero();  // (ILV, int8: the odd k slices)
+    auto request_piece = [&](int j, int stage, uint32_t so) __attribute__((always_inline)) {
+        if (j < PX) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], so);
+        else req_lds16(rsW, ldsw + (uint32_t)(stage * STAGE + (j - PX) * 1024), wvoff[j - PX], so);
+    };
 
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st) request(st, st < nsteps ? st : nsteps - 1);
@@ -706,6 +715,38 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
         wait_vm<(NST - 2) * PT>();  // this step's pieces have landed (the later stages' stay in flight)
         __builtin_amdgcn_s_barrier();  // ... everybody's have, and everybody is done reading the stage refilled next
         asm volatile("" ::: "memory");
+        if constexpr (ILV) {
+            u32x4 a[NS], b[NS];
+#pragma unroll
+            for (int g = 0; g < NS; ++g) {
+                a[g] = *(const u32x4*)(smem + stage * STAGE + fa[g]);
+                b[g] = *(const u32x4*)(smem + stage * STAGE + fb[g]);
+            }
+            const int fstep = step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1;  // past the end: repeat the last step (never consumed)
+            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(fstep * KSTEP);
+            if constexpr (INT) {
+#pragma unroll
+                for (int g = 0; g < NS; ++g) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    request_piece(g, stage_fill, so);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g & 1) acc1 = AC::mma(a[g], b[g], acc1);
+                    else acc = AC::mma(a[g], b[g], acc);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < NS; g += 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    request_piece(g, stage_fill, so);
+                    request_piece(g + 1, stage_fill, so);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = AC::mma64(a[g], a[g + 1], b[g], b[g + 1], acc);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            return;
+        }
         request(stage_fill, step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1);  // past the end: repeat the last step (never consumed)
         u32x4 a[NS], b[NS];
 #pragma unroll
@@ -731,6 +772,7 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
     };
     for (int s0 = 0; s0 < nsteps; s0 += NST) chain(chain, std::integral_constant<int, 0>{}, s0);
     wait_vm<0>();
+    if constexpr (ILV && INT) acc += acc1;
     __syncthreads();
 
     // ---- epilogue: add the two K halves (raw accumulator words: int32 stays exact), transpose through LDS, 16-byte output rows
@@ -998,10 +1040,12 @@ bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, Laun
     // tuning[2] = 2 / 3: two (64 KB of LDS: two blocks per CU) / three stages (development A/B); default four
     // (one round of tiles: 4 stages in flight per block; two rounds: 2 stages = 64 KB of LDS, two co-resident blocks per CU cover each
     //  other's prologue and epilogue — 4096^2 int8 M = 384: 24.4 us with 4 stages, 19.3 with 2; M = 256: 13.6 vs 17.9)
-    const int nst = (a.tuning[0] == 5 && (a.tuning[2] == 2 || a.tuning[2] == 3 || a.tuning[2] == 4)) ? a.tuning[2] : (tiles <= 256 ? 4 : 2);
+    const int nst = (a.tuning[0] == 5 && (a.tuning[2] >= 2 && a.tuning[2] <= 4)) ? a.tuning[2] : (tiles <= 256 ? 4 : 2);
     fn_t fn = nullptr;
     auto pick = [&](auto dt) -> fn_t {
         constexpr int DT = decltype(dt)::value;
+        // (tuning[3] & 2097152: the round-4 order of a step — requests first — for A/B runs)
+        if (!(a.tuning[3] & 2097152)) return nst == 2 ? gemm_a8w8_sq_kernel<DT, 2, true> : (nst == 3 ? gemm_a8w8_sq_kernel<DT, 3, true> : gemm_a8w8_sq_kernel<DT, 4, true>);
         return nst == 2 ? gemm_a8w8_sq_kernel<DT, 2> : (nst == 3 ? gemm_a8w8_sq_kernel<DT, 3> : gemm_a8w8_sq_kernel<DT, 4>);
     };
     fn = a.input_dtype == GEMLITE_DT_INT8 ? pick(std::integral_constant<int, GEMLITE_DT_INT8>{})

@@ -925,3 +925,61 @@ def test_rows_kernel_bit_tricks_restate_natural_k_order():
             else:             # bf16: 0x4300 | q = 128 + q exactly (the upper half of the fp32 pattern)
                 assert np.array_equal((lo.astype(np.uint32) << 16).view(np.float32).astype(np.float64), 128.0 + q0)
                 assert np.array_equal((hi.astype(np.uint32) << 16).view(np.float32).astype(np.float64), 128.0 + q1)
+
+
+def test_w8_rows_lds_layout():
+    """The LDS image of an x piece in w8_rows_lds_kernel (gemm_w8_rows.hip), restated in numpy for every geometry the planner can pick
+    (x bytes 2 / 1, row tiles 1 .. 4, 8-KB and 4-KB buffers): (i) an A fragment read back through the XOR swizzle holds exactly the k-values
+    the weight register of the same lane faces — 16-bit x: the lane's sixteen k as the two 16-byte slots 2 kb + e; 8-bit x: slot kb — and (ii)
+    every ds_read_b128 is conflict-free: its four lane groups (MI355X_MICROARCH.md, section LDS) touch sixteen distinct 16-byte slots of the
+    256-byte bank row."""
+    GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+              list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)), list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+
+    def fswz(ppr, a16, j):
+        if ppr >= 16:
+            return j & 15
+        return (((j >> 1) & 7) ^ ((((j + 4) >> 3) & 1) << 1)) if a16 else ((j >> 1) & 7)
+
+    seen = set()
+    for xb in (2, 1):
+        a16 = xb == 2
+        for mt, bufcap in ((1, 8192), (2, 8192), (3, 8192), (4, 8192), (1, 4096), (2, 4096)):
+            per = bufcap // (16 * mt)
+            cap = 512 if per >= 512 else (256 if per >= 256 else 128)
+            rowb = min(256 * xb, cap)
+            bpp, ppr, rpi = rowb // (64 * xb), rowb // 16, 1024 // rowb
+            dpi = 16 * mt // rpi
+            assert bpp >= 1 and 4 % bpp == 0 and dpi * rpi == 16 * mt and dpi * 1024 <= bufcap
+            seen.add((xb, rowb, dpi))
+            rows = 16 * mt
+            # x piece: element value = row * 4096 + k (k counted in ELEMENTS inside the piece); 16-byte slot s of a row = elements [s * 16 / xb, ...)
+            eps = 16 // xb  # elements per slot
+            lds = np.full(dpi * 1024 // 16, -1, dtype=np.int64)  # per 16-byte slot: (row, logical slot) encoded
+            for q in range(dpi):
+                for lane in range(64):
+                    r, pp = q * rpi + lane // ppr, lane % ppr
+                    logical = pp ^ fswz(ppr, a16, r & 15)
+                    assert 0 <= logical < ppr
+                    lds[(q * 1024 + lane * 16) // 16] = r * 1024 + logical
+            assert (lds >= 0).all() and len(set(lds.tolist())) == rows * ppr  # every (row, slot) exactly once
+            for t in range(mt):
+                for bq in range(bpp):
+                    for e in range(2 if a16 else 1):
+                        addrs = []
+                        for lane in range(64):
+                            j, kb = lane & 15, lane >> 4
+                            xbase = (t * 16 + j) * rowb + ((((2 if a16 else 1) * kb) ^ fswz(ppr, a16, j)) << 4)
+                            addr = xbase ^ (((8 * bq + e) if a16 else (4 * bq)) << 4)
+                            assert addr % 16 == 0 and addr < dpi * 1024
+                            got = lds[addr // 16]
+                            want_slot = (8 * bq + 2 * kb + e) if a16 else (4 * bq + kb)
+                            # the weight register of this lane: k = 64 bq + 16 kb .. + 15 -> x elements 64 bq + 16 kb + 8 e .. (16-bit) / 64 bq + 16 kb .. (8-bit)
+                            first_k = 64 * bq + 16 * kb + (8 * e if a16 else 0)
+                            assert want_slot * eps == first_k
+                            assert got == (t * 16 + j) * 1024 + want_slot, (xb, mt, bufcap, t, bq, e, lane)
+                            addrs.append(addr)
+                        for grp in GROUPS:
+                            banks = [(addrs[l] // 16) % 16 for l in grp]
+                            assert len(set(banks)) == 16, (xb, mt, bufcap, t, bq, e, sorted(banks))
+    assert len(seen) >= 7, seen
