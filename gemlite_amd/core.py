@@ -347,7 +347,7 @@ def _hip_matmul(x: Tensor, W_q: Tensor, scales: Tensor, zeros: Tensor, scales_x:
         if name and name.startswith((b"generic_matmul_kernel", b"mx_generic_kernel")):
             logger.warning(f"gemlite_amd: no specialised MI355X kernel for N={a.N} K={a.K} W_nbits={a.W_nbits} "
                            f"group_size={a.group_size} input_dtype={DType(a.input_dtype).name} M={M}: running on the coverage "
-                           "kernel (correct, slow).  Group sizes that are a power of two and N % 64 == 0 avoid it; block-scaled "
+                           "kernel (correct, slow).  Group sizes that are a multiple of 32 (K % 256 == 0 for odd multiples) and N % 64 == 0 avoid it; block-scaled "
                            "layers need a K-contiguous W_q (as pack() lays it out), N % 128 == 0 and K % 128 == 0.")
     return out
 

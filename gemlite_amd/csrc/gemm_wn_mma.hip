@@ -185,7 +185,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         // Groups of 32 (round 6): 32-row tiles with TWO (scale, zero) pairs per column and 64-k sub-block (template parameter NGS = 2).
         // What reaches this: 1- and 8-bit packed words and fp8 activations x 4- / 2-bit words at M >= 2 (4- / 2-bit words under 16-bit activations
         // have the rows kernel in front) — shapes that ran on the coverage kernel until round 5 (4096^2 M = 64: ~3.8 ms).
-        if (p.group_size != 32 || a.K % 256 != 0 || a.N % mma::BN != 0 || xdt == GEMLITE_DT_INT8) return false;
+        if (p.group_size % 32 != 0 || a.K % 256 != 0 || a.N % mma::BN != 0 || xdt == GEMLITE_DT_INT8) return false;  // (odd multiples of 32 above 32: gs_magic, api.hip)
         if (a.tuning[0] != 0 || a.tuning[2] != 0) return false;
         const int rows = (int)(a.K / e), units = (int)(a.K / 256);
         const int64_t tiles = (int64_t)(a.N / mma::BN) * ((a.M + 31) / 32);

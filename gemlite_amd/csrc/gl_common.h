@@ -365,7 +365,9 @@ struct WnParams {
     int flags;           // experiment switches forwarded from tuning[3] (kernel-specific)
     int gs_shift;        // log2(group_size); 31 when one metadata row spans all of K; -1 (not a power of two)
                          // sends the problem to the coverage kernel — an integer division per metadata load costs
-                         // ~50 VALU instructions and a branch in kernels that have ~300 per chunk
+                         // ~50 VALU instructions and a branch in kernels that have ~300 per chunk — except in the 8-wave tile kernel
+                         // (round 6), whose metadata row index is wave-uniform: k / group = mulhi(k / 32, gs_magic) on the scalar unit
+    uint32_t gs_magic;   // ceil(2^32 / (group_size / 32)) for a group size that is a multiple of 32 and not a power of two, else 0
 };
 
 __device__ __forceinline__ int group_of(int k, int gs_shift) { return k >> gs_shift; }

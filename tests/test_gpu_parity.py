@@ -1946,6 +1946,32 @@ def test_mma_kernel_groups_of_32(nbits, tdt):
                  abs_gate=None if nbits == 8 else 1e-3, extra=dict(kernel=name))
 
 
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("nbits", [4, 2, 1, 8])
+def test_group_sizes_that_are_not_a_power_of_two(nbits, tdt):
+    """Round 6: the reference admits any group size that divides K (core.py:253-271; per-block scale loads
+    gemm_splitK_kernels.py:391-405).  Multiples of 32 that are not a power of two ran on the coverage kernel until round 5; now the 8-wave tile kernel
+    takes them at every M — the metadata row of a slice is k / group by one scalar multiply-high.  Groups of 96 / 160 (odd multiples of 32: two
+    metadata pairs per 64-k sub-block, 32-row tiles) and 192 / 384 / 768 (one pair per sub-block, every tile height and the narrow tiles), ragged M,
+    forced split-K, every W_group_mode; against the float64 oracle."""
+    from gemlite_amd.core import _hip_matmul
+    for gs, N, K in ((96, 256, 1536), (160, 128, 1280), (192, 256, 1536), (384, 256, 3072), (768, 512, 3072)):
+        for zeros_kind, fma in (("tensor", True), ("tensor", False), ("none", True)):
+            lin = _make_layer(N, K, nbits, gs, tdt, seed=60 + nbits + gs, zeros_kind=zeros_kind, fma=fma)
+            for M in (1, 2, 29, 100, 300):
+                x = torch.from_numpy(O.gen_x(M, K, seed=M).astype(np.float32)).to(tdt).to(DEV)
+                y_or = _oracle_from_layer(lin, x)
+                for sk in ((0, 3) if M in (29, 300) else (0,)):
+                    tuning = (0, sk, 0, 0)
+                    name = _kernel_name(lin, x, -1, tuning)
+                    assert name.startswith(f"gemm_w{nbits}_mma_kernel<"), (gs, M, name)
+                    assert ("g32" in name) == (gs % 64 != 0), (gs, name)
+                    y = _hip_matmul(x, lin.W_q, lin.scales, lin.zeros, None, lin.get_meta_args(), -1, tuning)
+                    torch.cuda.synchronize()
+                    _compare(f"npot/w{nbits}/{str(tdt)[6:]}/g{gs}/{zeros_kind}{int(fma)}/M{M}/sk{sk}", y, y_or, lin.output_dtype.value,
+                             abs_gate=None if nbits == 8 else 1e-3, extra=dict(kernel=name))
+
+
 @pytest.mark.parametrize("nbits", [4, 2])
 def test_a8wn_fp8_activations_groups_of_32(nbits):
     """A8Wn dynamic with groups of 32 (coverage kernel until round 5 above the rows kernel's 64 rows): fp8 e4m3 activations x packed words with

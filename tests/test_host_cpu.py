@@ -983,3 +983,17 @@ def test_w8_rows_lds_layout():
                             banks = [(addrs[l] // 16) % 16 for l in grp]
                             assert len(set(banks)) == 16, (xb, mt, bufcap, t, bq, e, sorted(banks))
     assert len(seen) >= 7, seen
+
+
+def test_group_index_by_multiply_high():
+    """gs_magic (api.hip, round 6): the tile kernel finds the metadata row of a 32-k slice of a group size that is a multiple of 32 and not a power
+    of two as mulhi(k / 32, ceil(2^32 / (group / 32))).  Exact for every slice of every (K, group) pair the planner admits (K * group < 2^40)."""
+    rng = np.random.default_rng(9)
+    for gs in [96, 160, 192, 224, 288, 320, 384, 480, 768, 1056, 3 * 4096, 5 * 8192, 96 * 341]:
+        d = gs // 32
+        magic = ((1 << 32) + d - 1) // d
+        assert magic < (1 << 32)
+        kmax = min((1 << 40) // gs, 1 << 31)
+        q = np.concatenate([np.arange(0, min(kmax // 32, 1 << 16), dtype=np.uint64), rng.integers(0, kmax // 32, size=1 << 16, dtype=np.uint64),
+                            np.array([kmax // 32 - 1], dtype=np.uint64)])
+        assert np.array_equal((q * np.uint64(magic)) >> np.uint64(32), q // np.uint64(d)), gs
