@@ -483,6 +483,9 @@ static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
                 a.tuning[0] == 0 && (mt == GEMLITE_MATMUL_AUTO || mt == GEMLITE_MATMUL_GEMM || mt == GEMLITE_MATMUL_GEMM_SPLITK)) {
                 const uint32_t d = (uint32_t)(eff_group / 32);
                 p.gs_magic = (uint32_t)(((1ull << 32) + d - 1) / d);
+                // one row: the dot-product GEMV (a lane's 32-k span lies inside one group; the same multiply-high per lane and chunk) — the reference's
+                // GEMV runs a group of 96 at 4096 x 3072 in 7.9 us, the 32-row tile below needs 12.4 (profiles/r06/reference_triton_mi355x_r6.json)
+                if (want_gemv && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_gemv_wn(a, p, lp)) { r.kind = K_GEMV_WN; r.wn = p; r.lp = lp; return; }
                 if (plan_gemm_wn_mma(a, p, lp)) { r.kind = K_TILED_WN; r.wn = p; r.lp = lp; return; }
             }
             goto coverage;

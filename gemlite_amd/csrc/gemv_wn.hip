@@ -606,7 +606,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemv_w4_decode_kernel(const WnPara
     struct Chunk { u32x4 w[R]; u32x2 s, z; uint32_t xq[R]; };
     auto load_chunk = [&](Chunk& ck, int chunk) {
         const uint32_t row = row0 + (uint32_t)(chunk * CSTRIDE);
-        const uint32_t mo = ((uint32_t)group_of((int)row * 8, p.gs_shift) * mstride + (uint32_t)n0) * 2u;
+        const uint32_t mo = ((uint32_t)group_of((int)row * 8, p.gs_shift, p.gs_magic) * mstride + (uint32_t)n0) * 2u;
         const uint32_t xo = xo0 + (uint32_t)(chunk * CSTRIDE) * 16u;
 #pragma unroll
         for (int i = 0; i < R; ++i) ck.xq[i] = *(const uint32_t*)(xb + (xo + (uint32_t)i * 16u));
@@ -951,6 +951,9 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
             }
             return true;
         }
+        // group sizes that are not a power of two (gs_shift < 0, gs_magic): only gemv_w4_decode_kernel above finds the group by multiply-high —
+        // the same two instructions in gemv_wn_kernel's chunk loader pushed its counted-asm-load variants into spills (scripts/isa_guard.py)
+        if (p.gs_shift < 0) return false;
         lp.name = (xd && nw == 16) ? "gemv_wn_kernel<tile16,xdirect,16w>"
                   : (xd && nw == 8) ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect,8w>" : "gemv_wn_kernel<tile32,xdirect,8w>")
                   : xd ? (cq == 2 ? "gemv_wn_kernel<tile16,xdirect>" : (cq == 3 ? "gemv_wn_kernel<tile32,xdirect>" : "gemv_wn_kernel<tile64,xdirect>"))

@@ -371,6 +371,10 @@ struct WnParams {
 };
 
 __device__ __forceinline__ int group_of(int k, int gs_shift) { return k >> gs_shift; }
+// the same for kernels that also take group sizes that are multiples of 32 and not a power of two (k a multiple of 32; gs_magic: see WnParams)
+__device__ __forceinline__ int group_of(int k, int gs_shift, uint32_t gs_magic) {
+    return gs_shift >= 0 ? (k >> gs_shift) : (int)__umulhi((uint32_t)k >> 5, gs_magic);
+}
 
 // Two-buffer software pipeline over n >= 1 units (chunks / pieces of K): unit i + 2 is requested as soon as unit i
 // has been consumed, and nothing is requested twice — a clamped "re-request the last unit" tail would stream the

@@ -88,14 +88,14 @@ class A16W8:
         return out
 
 
-class A16W8_INT8(A16W8):
-    def __init__(self, device="cuda:0", dtype=None):
-        super().__init__(device=device, dtype=dtype, fp8=None)
+class A16W8_INT8(A16W8):  # (constructor arguments of the reference's aliases: helper.py:331-337)
+    def __init__(self, device="cuda:0", dtype=None, fp32_scale=True, post_scale=False):
+        super().__init__(device=device, dtype=dtype, fp8=None, fp32_scale=fp32_scale, post_scale=post_scale)
 
 
 class A16W8_FP8(A16W8):
-    def __init__(self, device="cuda:0", dtype=None):
-        super().__init__(device=device, dtype=dtype, fp8=default_fp8)
+    def __init__(self, device="cuda:0", dtype=None, fp8=default_fp8, fp32_scale=True, post_scale=False):
+        super().__init__(device=device, dtype=dtype, fp8=fp8, fp32_scale=fp32_scale, post_scale=post_scale)
 
 
 class A16Wn_HQQ_INT(A16Wn):

@@ -117,6 +117,20 @@ CASES_R5 = (
        ("cfgB_bf16_m1", case_int(8192, 8192, 4, 128, torch.bfloat16, 1, 3, 7), (1, 8192, 8192)),
        ("a16w2_4096_fp16_m1", case_int(4096, 4096, 2, 128, torch.float16, 1, 25, 29), (1, 4096, 4096))])
 
+# Round 6, second half: the territory of w8_rows_lds_kernel (gemm_w8_rows.hip: unpacked 8-bit weights at 2 .. 64 rows, x through LDS) and group sizes that
+# are not a power of two (tile kernel, gs_magic).  Written to fullsize_ref_r6.npz by `--which ref --only r6 --fixture fullsize_ref_r6.npz`.
+CASES_R6 = (
+    [(f"a8w8_int8_m{m}", case_helper("A8W8_int8_dynamic", 4096, 4096, m, 100 + m), (m, 4096, 4096)) for m in (4, 32, 64)]
+    + [(f"a8w8_fp8_m{m}", case_helper("A8W8_fp8_dynamic", 4096, 4096, m, 120 + m, fp8=torch.float8_e4m3fn), (m, 4096, 4096)) for m in (32, 64)]
+    + [(f"a16w8_int8_{tn}_m{m}", case_helper("A16W8_INT8", 4096, 4096, m, 140 + m, tdt), (m, 4096, 4096))
+       for m in (8, 32, 64) for tn, tdt in (("fp16", torch.float16), ("bf16", torch.bfloat16))]
+    + [("a16w8_fp8_fp16_m32", case_helper("A16W8_FP8", 4096, 4096, 32, 171, fp8=torch.float8_e4m3fn), (32, 4096, 4096)),
+       ("a8w8_int8_8192_m8", case_helper("A8W8_int8_dynamic", 8192, 8192, 8, 181), (8, 8192, 8192)),      # the two-blocks-per-CU form
+       ("a16w8_int8_8192_fp16_m8", case_helper("A16W8_INT8", 8192, 8192, 8, 182), (8, 8192, 8192)),
+       ("w4_g96_fp16_m16", case_int(4096, 3072, 4, 96, torch.float16, 16, 31, 32), (16, 4096, 3072)),      # odd multiple of 32: two metadata pairs per sub-block
+       ("w4_g192_bf16_m64", case_int(4096, 3072, 4, 192, torch.bfloat16, 64, 33, 34), (64, 4096, 3072)),
+       ("w4_g96_fp16_m1", case_int(4096, 3072, 4, 96, torch.float16, 1, 31, 35), (1, 4096, 3072))])
+
 CASES = [
     # name, builder, shape-for-flops
     ("cfgA_fp16_m1", case_int(4096, 4096, 4, 128, torch.float16, 1, 0, 1), (1, 4096, 4096)),
@@ -143,7 +157,7 @@ CASES = [
     ("mx_a4w4_m256", case_helper("A4W4_MXFP_dynamic", 2048, 4096, 256, 35, torch.bfloat16, True), (256, 2048, 4096)),
     ("mx_a16w4_m16", case_helper("A16W4_MXFP", 2048, 4096, 16, 36, torch.bfloat16, True), (16, 2048, 4096)),
     ("nvfp4_m16", case_helper("A4W4_NVFP_dynamic", 2048, 4096, 16, 37, torch.bfloat16, True), (16, 2048, 4096)),
-] + list(CASES_R4) + list(CASES_R5)
+] + list(CASES_R4) + list(CASES_R5) + list(CASES_R6)
 
 _FLUSH = None
 
@@ -199,7 +213,7 @@ def main():
     ap.add_argument("--tmp", default="/tmp/gemlite_ref_full")
     ap.add_argument("--budget-s", type=float, default=480.0)
     ap.add_argument("--fast-shapes", default="cfgA_fp16_m1,cfgA_bf16_m256,cfgB_bf16_m256")
-    ap.add_argument("--only", default="", help="comma-separated case names, or `r4` / `r5` = the round-4 / round-6 additions")
+    ap.add_argument("--only", default="", help="comma-separated case names, or `r4` / `r5` / `r6` = the additions of round 4 / round 6 (first, second half)")
     ap.add_argument("--fixture", default="fullsize_ref.npz", help="file name of the golden fixture written by --which ref")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -209,8 +223,9 @@ def main():
     info = {"device": torch.cuda.get_device_properties(0).name, "torch": torch.__version__, "which": args.which,
             "triton": __import__("triton").__version__, "method": "256 MiB flush + event pair per call (benchmark_triton.py:44-60)"}
     golden, report = {}, []
-    only = set(c[0] for c in CASES_R4) if args.only == "r4" else (set(c[0] for c in CASES_R5) if args.only == "r5" else set(filter(None, args.only.split(","))))
-    tag = "_r4" if args.only == "r4" else ("_r5" if args.only == "r5" else "")
+    rounds = {"r4": CASES_R4, "r5": CASES_R5, "r6": CASES_R6}
+    only = set(c[0] for c in rounds[args.only]) if args.only in rounds else set(filter(None, args.only.split(",")))
+    tag = "_" + args.only if args.only in rounds else ""
     out_json = os.path.join(args.out, f"reference_triton_mi355x{tag}.json" if args.which == "ref" else f"hip_same_method{tag}.json")
 
     def run_phase(mode, names, dump):

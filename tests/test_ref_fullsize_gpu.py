@@ -147,3 +147,45 @@ def test_round6_fixture_is_the_reference_run_recorded_in_profiles():
     rec = json.load(open(os.path.join(ROOT, "profiles", "r06", "reference_triton_mi355x_r5.json")))
     done = {r["case"] for r in rec["report"] if "us" in r and "error" not in r}
     assert set(BOUNDS_R5) <= done
+
+
+# ---- round 6, second half: the territory of w8_rows_lds_kernel (gemm_w8_rows.hip) and group sizes that are not a power of two -------------------
+# tests/golden/fullsize_ref_r6.npz = `python oracle/run_ref_gpu.py --which ref --only r6 --fixture fullsize_ref_r6.npz` on an MI355X (scripts/r6/run_u.sh;
+# timings + the distances measured on the spot: profiles/r06/reference_triton_mi355x_r6.json, hip_same_method_r6.json).
+#   * A8W8 (int8 and fp8 e4m3, per-token x per-channel scales) at 4 / 32 / 64 rows and the two-blocks-per-CU form at 8192^2: the distance measured was
+#     EXACTLY 0 — int32 (fp32) accumulation of the same products and the reference's epilogue order, bit for bit;
+#   * A16W8 (int8 / fp8 weights under fp16 / bf16): the reference rounds every scaled weight to the 16-bit type before tl.dot, the kernel converts the
+#     8-bit code exactly and applies the channel scale once to the fp32 sum: 2.1e-4 (fp16) / 1.6e-3 (bf16) of mean |y|, the reference's own rounding;
+#   * groups of 96 / 192 at 16 / 64 rows (the tile kernel, per-weight rounding like the reference): 2e-7 .. 4e-7; one row (dot-product GEMV against the
+#     reference's fp16-accumulating GEMV): 1.4e-3.
+GOLD_R6 = os.path.join(ROOT, "tests", "golden", "fullsize_ref_r6.npz")
+BOUNDS_R6 = {
+    **{f"a8w8_int8_m{m}": 1e-6 for m in (4, 32, 64)}, "a8w8_fp8_m32": 1e-6, "a8w8_fp8_m64": 1e-6, "a8w8_int8_8192_m8": 1e-6,
+    **{f"a16w8_int8_fp16_m{m}": 5e-4 for m in (8, 32, 64)}, **{f"a16w8_int8_bf16_m{m}": 4e-3 for m in (8, 32, 64)},
+    "a16w8_fp8_fp16_m32": 5e-4, "a16w8_int8_8192_fp16_m8": 5e-4,
+    "w4_g96_fp16_m16": 1e-4, "w4_g192_bf16_m64": 1e-4, "w4_g96_fp16_m1": 4e-3,
+}
+
+
+@pytest.mark.parametrize("name", sorted(BOUNDS_R6))
+def test_hip_matches_reference_outputs_from_the_mi355x_round6_second_half(name):
+    import gemlite_amd
+    from oracle.run_ref_gpu import COL0, COLSTEP
+    gold = np.load(GOLD_R6)
+    assert name in gold.files, f"{name} missing from the fixture"
+    layer, x = _cases()[name](gemlite_amd)
+    y = layer(x)
+    torch.cuda.synchronize()
+    dt = str(gold[name + "__dtype"])
+    ref = torch.from_numpy(gold[name]).view({"torch.float16": torch.float16, "torch.bfloat16": torch.bfloat16}[dt]).float().numpy().astype(np.float64)
+    got = y[:, COL0::COLSTEP].float().cpu().numpy().astype(np.float64)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    rel = np.abs(got - ref).mean() / np.abs(ref).mean()
+    assert rel < BOUNDS_R6[name], (name, rel, BOUNDS_R6[name])
+
+
+def test_round6_second_fixture_is_the_reference_run_recorded_in_profiles():
+    import json
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06", "reference_triton_mi355x_r6.json")))
+    done = {r["case"] for r in rec["report"] if "us" in r and "error" not in r}
+    assert set(BOUNDS_R6) <= done
