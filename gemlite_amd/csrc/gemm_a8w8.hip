@@ -685,8 +685,17 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
     }
     const uint32_t ldsx = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PX) * 1024u);
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(BM * PITCH) + (uint32_t)(wave * PW) * 1024u);
+    // K rotation (round 6): the row tiles that share a weight column tile start their K loops a quarter apart (mtiles = 4) — each of the sibling
+    // CUs then pulls a DIFFERENT part of the tile from HBM and finds the rest in its XCD's L2, instead of all of them waiting on the same cold
+    // lines in lockstep.  The order of the K steps changes per row tile: exact for int8; for fp8 the fp32 sums differ in the last bits between tiles.
+    // (measured, one box: 13.14 -> 12.05 us at int8 4096^2 M = 256, M = 128 13.1 -> 11.1, M = 512 21.5 -> 18.0, 2048 x 8192 M = 256 19.7 -> 15.0;
+    //  staggering the column tiles that share a row tile of x as well: nothing.  It pays only while the weight tiles an XCD works on at a time stay in
+    //  its L2 — the planner sets bit 30 of flags by that rule (k_rotation_pays() below: 4096 x 14336 M = 256, 7 MB per XCD, 34.4 -> 40.2 us).
+    //  profiles/r06/probe_a8w8_sq_k_rotation.log, probe_k_rotation_*.log; tuning[3] & 4194304 = never, for A/B runs)
+    const int rot = (p.flags & (1 << 30)) ? (mt * nsteps) / mtiles : 0;
+    auto kof = [&](int step) __attribute__((always_inline)) { const int k = step + rot; return k >= nsteps ? k - nsteps : k; };
     auto request = [&](int stage, int step) __attribute__((always_inline)) {
-        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP);
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(kof(step) * KSTEP);
 #pragma unroll
         for (int j = 0; j < PX; ++j) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], so);
 #pragma unroll
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
                 b[g] = *(const u32x4*)(smem + stage * STAGE + fb[g]);
             }
             const int fstep = step + NST - 1 < nsteps ? step + NST - 1 : nsteps - 1;  // past the end: repeat the last step (never consumed)
-            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(fstep * KSTEP);
+            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(kof(fstep) * KSTEP);
             if constexpr (INT) {
 #pragma unroll
                 for (int g = 0; g < NS; ++g) {
@@ -866,6 +875,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_sq128_kernel(const GenericPa
     }
     const uint32_t ldsx = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(wave * PX) * 1024u);
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)(BM * PITCH) + (uint32_t)(wave * PW) * 1024u);
+    // (K rotation between the row tiles of a column tile, which pays on the 64 x 64 tiles, LOSES here: FP8 16384^2 M = 256 94.5 -> 113 us, int8 8192^2
+    //  M = 512 46.6 -> 51.2, 4096^2 M = 1024 27.5 -> 28.0 — the sibling runs half of a 2-MB weight tile ahead, far more than an XCD's L2 keeps, and the
+    //  lockstep sharing of today is lost: profiles/r06/probe_k_rotation_sq128_slower.log)
     auto request = [&](int stage, int step) __attribute__((always_inline)) {
         const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP);
 #pragma unroll
@@ -1021,6 +1033,20 @@ bool plan_gemm_a8w8_sq128(const gemlite_hip_forward_args& a, GenericParams& g, L
     return true;
 }
 
+// K rotation of the unsplit 64 x 64 tiles (gemm_a8w8_sq_kernel, gemm_mx_sq_kernel): row tile mt of a weight column tile starts its K loop at step
+// mt nsteps / mtiles.  The row tiles of a column tile run on one XCD (block map of the kernels; needs N / 64 % 8 == 0), so each sibling CU pulls a different
+// part of the tile from HBM and the others find it in that XCD's L2 — IF it is still there: an XCD works on min(column tiles per XCD, CUs per XCD /
+// row tiles) weight tiles at a time, and the rotation pays while those fit its 4-MB L2 (2 MB: -8 .. -24 %; 4 MB: even; 7 MB: +17 %).
+bool k_rotation_pays(const gemlite_hip_forward_args& a, int64_t tile_bytes) {
+    if (a.tuning[3] & 4194304) return false;
+    const int64_t mtiles = (a.M + 63) / 64, ntiles = a.N / 64;
+    if (mtiles < 2 || (ntiles & 7) != 0) return false;
+    const int64_t cus_per_xcd = resident_block_limit() / 8 > 0 ? resident_block_limit() / 8 : 1;
+    const int64_t at_a_time = cus_per_xcd / mtiles > 0 ? cus_per_xcd / mtiles : 1;
+    const int64_t tiles_x = ntiles / 8 < at_a_time ? ntiles / 8 : at_a_time;
+    return tiles_x * tile_bytes <= (4ll << 20);
+}
+
 bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
     if (a.elements_per_sample != 1 || a.W_group_mode != 0 || a.M < 2) return false;
     if (a.w_dtype != a.input_dtype) return false;
@@ -1051,7 +1077,7 @@ bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, Laun
     fn = a.input_dtype == GEMLITE_DT_INT8 ? pick(std::integral_constant<int, GEMLITE_DT_INT8>{})
          : (a.input_dtype == GEMLITE_DT_FP8E4 ? pick(std::integral_constant<int, GEMLITE_DT_FP8E4>{}) : pick(std::integral_constant<int, GEMLITE_DT_FP8E5>{}));
     g.splitk = 1;
-    g.flags = a.tuning[3];
+    g.flags = (a.tuning[3] & ~(1 << 30)) | (k_rotation_pays(a, (int64_t)64 * a.K) ? (1 << 30) : 0);
     lp.fn = (const void*)fn;
     lp.name = "gemm_a8w8_sq_kernel<64x64>";
     lp.grid = dim3((unsigned)tiles, 1, 1);
