@@ -4,6 +4,9 @@
 
 namespace gl {
 
+bool k_rotation_pays(const gemlite_hip_forward_args& a, int64_t tile_bytes);  // gemm_a8w8.hip
+
+
 const void* mma_lookup_f16(int kind, int nbits, int mi, int xdt, int xch);
 const void* mma_lookup_bf16(int kind, int nbits, int mi, int xdt, int xch);
 
@@ -76,6 +79,9 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         p.w_mode = 2;
         p.gs_shift = 5;
         p.combine = 0;
+        // K rotation between the row tiles of a column tile (bit 30 of flags, gemm_wn_mma_kernel.inc): 8-bit weights, K unsplit, the L2 rule of the A8W8 tiles
+        p.flags &= ~(1 << 30);
+        if ((k8 || nb == mma::MXW8) && splitk == 1 && k_rotation_pays(a, (int64_t)64 * a.K)) p.flags |= (1 << 30);
         lp.fn = fn;
         lp.name = k8 ? "gemm_a16w8_kernel<64x64>" : (nv ? "gemm_nvfp4_f16_kernel<64x64>" : (nb == mma::MXW8 ? "gemm_a16w8_mxfp_kernel<64x64>" : "gemm_a16w4_mxfp_kernel<64x64>"));
         lp.grid = dim3((unsigned)tiles, splitk, 1);

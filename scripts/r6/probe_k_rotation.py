@@ -16,6 +16,7 @@ names = sys.argv[1:] or ["a16w4_4096_m256", "a16w4_8192_m256", "a16w4_8192_m2048
 bench.WORKLOADS.setdefault("a16w4_4096_m192", (4096, 4096, 4, 128, 192, "bf16", 32, "mfma"))
 bench.WORKLOADS.setdefault("a16w4_4096_m128", (4096, 4096, 4, 128, 128, "bf16", 32, "mfma"))
 bench.WORKLOADS.setdefault("a16w4_11008_m256", (11008, 4096, 4, 128, 256, "bf16", 16, "mfma"))
+bench.WORKLOADS.setdefault("a16w4_8192x4096_m256", (8192, 4096, 4, 128, 256, "bf16", 16, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_8192_m512", (8192, 8192, 8, 8192, 512, "int8", 8, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_4096_m1024", (4096, 4096, 8, 4096, 1024, "int8", 32, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_4096_m128", (4096, 4096, 8, 4096, 128, "int8", 32, "mfma"))
@@ -29,7 +30,7 @@ bench.WORKLOADS.setdefault("mx_a8w8_4096_m128", (4096, 4096, 8, 32, 128, "mxa8",
 for name in names:
     first = None
     for rep in range(2):
-        for t in ((0, 0, 0, 0), (0, 0, 0, 4194304), (0, 0, 0, 8388608)):
+        for t in ((0, 0, 0, 0), (0, 0, 0, 4194304), (0, 0, 0, 8388608), (0, 0, 0, 16777216), (0, 0, 0, 8388608 + 16777216)):
             core.TUNING_OVERRIDE = t if any(t) else None
             try:
                 r = bench.Runner(name, dev, lib)
