@@ -272,7 +272,9 @@ enum gemlite_hip_tuning_flags {            /* tuning[3]: bit flags (A/B switches
     GEMLITE_TF_ROUND5_TILE_EPILOGUE = 262144,    /* round 6: the two-barrier K-part join of the unsplit tiles instead of the direct one */
     GEMLITE_TF_W8_ROWS_X_FROM_REGISTERS = 524288, /* round 6: the round-3 / round-4 few-row kernels of unpacked 8-bit weights (a8w8_rows_kernel / a16w8_rows_kernel)
                                                     instead of w8_rows_lds_kernel (x through LDS in whole cache lines) */
-    GEMLITE_TF_W8_ROWS_LDS_BELOW_4_ROWS = 1048576 /* A16W8: take w8_rows_lds_kernel at 1 .. 3 rows too (default: from 4) */
+    GEMLITE_TF_W8_ROWS_LDS_BELOW_4_ROWS = 1048576, /* A16W8: take w8_rows_lds_kernel at 1 .. 3 rows too (default: from 4) */
+    GEMLITE_TF_A8W8_TILE_REQUESTS_FIRST = 2097152, /* round 6: the round-4 order of a K step of the 64 x 64 A8W8 tile (DMA requests in front of the LDS reads) */
+    GEMLITE_TF_NO_K_ROTATION = 4194304             /* round 6: every row tile of the unsplit 64 x 64 tiles of 8-bit weights starts its K loop at step 0 */
 };
 
 /* Library / ABI identification (host only, no device access). */
