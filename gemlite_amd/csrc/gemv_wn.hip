@@ -889,7 +889,9 @@ bool plan_gemv_wn(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan& lp
         // LDS-x path with 8 waves (tuning[2] == 8; auto when every wave still gets >= 4 chunks: the long-K shapes, where
         // one wave per SIMD spends ~2/3 of its time in unpack arithmetic that nothing overlaps with the weight stream)
         if (!xd && r == 4 && (cq >= 3 || a.tuning[2] == 8) && (nbits == 4 || nbits == 2) &&
-            (a.tuning[2] == 8 || (a.tuning[2] == 0 && GEMV_AUTO_8W && (units / splitk) >= (nbits == 2 ? 32 : 128))))  // (round 6, counted asm loads: 4-bit 16384^2 24.5 vs 25.0 us with 8 waves)
+            (a.tuning[2] == 8 || (a.tuning[2] == 0 && GEMV_AUTO_8W && (units / splitk) >= (nbits == 2 ? 32 : (cq == 4 ? 32 : 128)))))  // (round 6, counted asm loads: 4-bit 16384^2 24.5 vs 25.0 us with 8 waves;
+            // late round 6, 64-column tiles from 32 chunks per slice: 14336 x 4096 8.05 -> 7.72 us, 5120 x 13824 12.55 -> 11.58, 13824 x 5120 9.17 -> 8.75, 8192 x 28672 24.0 -> 22.5; 32-column tiles
+            // LOSE with 8 waves (8192^2 9.13 -> 9.79, 8192 x 4096 6.19 -> 6.72) and keep the 128-chunk rule: profiles/r06/probe_m1_8waves_w4.log)
             nw = 8;
         const void* fn = a.input_dtype == GEMLITE_DT_FP16 ? pick_bits<half_tag>(nbits, mb, cq, r, xd, nw)
                                                            : pick_bits<bf16_tag>(nbits, mb, cq, r, xd, nw);

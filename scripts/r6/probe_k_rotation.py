@@ -30,7 +30,7 @@ bench.WORKLOADS.setdefault("mx_a8w8_4096_m128", (4096, 4096, 8, 32, 128, "mxa8",
 for name in names:
     first = None
     for rep in range(2):
-        for t in ((0, 0, 0, 0), (0, 0, 0, 4194304), (0, 0, 0, 8388608), (0, 0, 0, 16777216), (0, 0, 0, 8388608 + 16777216)):
+        for t in ((0, 0, 0, 0), (0, 0, 0, 4194304), (0, 0, 0, 16777216)):
             core.TUNING_OVERRIDE = t if any(t) else None
             try:
                 r = bench.Runner(name, dev, lib)

@@ -162,10 +162,10 @@ def test_struct_abi_and_validation():
     (dict(M=1, N=1536, K=8960), "gemv_w4_decode3_kernel<tile16,16w>"),   # round 3: narrow N -> 16-column tiles unsplit (7.5 vs 9.4 us)
     (dict(M=1, N=1024, K=4096), "gemv_w4_decode3_kernel<tile16,16w>"),
     (dict(M=1, N=5120, K=5120), "gemv_wn_kernel<tile32>"),              # 160 blocks are enough (7.6 vs 8.9 us for 320 blocks of 16 columns)
-    (dict(M=1, N=14336, K=4096), "gemv_wn_kernel<tile64>"),
+    (dict(M=1, N=14336, K=4096), "gemv_wn_kernel<tile64,8w>"),   # (late round 6: 64-column tiles take 8 waves from 32 chunks per slice: 8.05 -> 7.72 us)
     (dict(M=1, N=6144, K=4096), "gemv_wn_kernel<tile32>"),              # round 6: no MFMA GEMV at one row of 4-bit words any more (20 of 22 shapes)
     (dict(M=1, N=8960, K=1536), "gemv_wn_kernel<tile64>"),
-    (dict(M=1, N=8192, K=28672), "gemv_wn_kernel<tile64>"),             # long K over a narrow N: 64-column tiles x 2 K slices (23.1 vs 25.8 us)
+    (dict(M=1, N=8192, K=28672), "gemv_wn_kernel<tile64,8w>"),             # long K over a narrow N: 64-column tiles x 2 K slices (23.1 vs 25.8 us)
     (dict(M=1, N=4096, K=14336), "gemv_wn_kernel<tile64>"),
     (dict(M=4, N=4096, K=11008), "gemm_w4_rows_kernel<16x16>"),   # round 5 (13.0 -> 12.3 us)
     (dict(M=8, N=4096, K=11008, tuning=(0, 0, 0, 65536)), "gemm_w4_mma_kernel<32x128>"),
@@ -178,8 +178,8 @@ def test_struct_abi_and_validation():
     (dict(M=1, nbits=2), "gemv_wn_kernel<tile16>"),   # round 6: 2-bit decode back on the dot-product family (4.47 vs 4.76 us) ...
     (dict(M=1, nbits=2, N=4096, K=11008), "gemv_w2_mfma_kernel<tile16>"),   # ... except over a K that is not a multiple of 1024 (8.29 vs 9.16 us)
     (dict(M=1, nbits=2, tuning=(0, 0, 0, 512)), "gemv_wn_kernel<tile16>"),
-    (dict(M=1, N=11008, K=4096), "gemv_wn_kernel<tile64>"),   # round 6: 64-column tiles (172 blocks) of the dot-product family: 7.70 vs 7.98 us
-    (dict(M=1, N=11008, K=4096, tuning=(0, 0, 0, 512)), "gemv_wn_kernel<tile64>"),
+    (dict(M=1, N=11008, K=4096), "gemv_wn_kernel<tile64,8w>"),   # round 6: 64-column tiles (172 blocks) of the dot-product family: 7.70 vs 7.98 us
+    (dict(M=1, N=11008, K=4096, tuning=(0, 0, 0, 512)), "gemv_wn_kernel<tile64,8w>"),
     (dict(M=1, nbits=8), "gemv_wn_kernel<tile64>"),
     (dict(M=1, N=16384, K=16384, nbits=2), "gemv_wn_kernel<tile64,8w>"),   # 2-bit, long K: two waves per SIMD
     (dict(M=16, tuning=(0, 0, 0, 65536)), "gemm_wn_direct_kernel<tile32,8w>"),
