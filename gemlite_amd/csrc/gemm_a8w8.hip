@@ -692,8 +692,7 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
     //  staggering the column tiles that share a row tile of x as well: nothing.  It pays only while the weight tiles an XCD works on at a time stay in
     //  its L2 — the planner sets bit 30 of flags by that rule (k_rotation_pays() below: 4096 x 14336 M = 256, 7 MB per XCD, 34.4 -> 40.2 us).
     //  profiles/r06/probe_a8w8_sq_k_rotation.log, probe_k_rotation_*.log; tuning[3] & 4194304 = never, for A/B runs)
-    const int rot = (p.flags & (1 << 30)) ? (mt * nsteps) / mtiles : 0;
-    auto kof = [&](int step) __attribute__((always_inline)) { const int k = step + rot; return k >= nsteps ? k - nsteps : k; };
+    auto kof = [&](int step) __attribute__((always_inline)) { return k_order(step, mt, mtiles, nsteps, p.flags); };
     auto request = [&](int stage, int step) __attribute__((always_inline)) {
         const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(kof(step) * KSTEP);
 #pragma unroll
@@ -879,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_sq128_kernel(const GenericPa
     //  M = 512 46.6 -> 51.2, 4096^2 M = 1024 27.5 -> 28.0 — the sibling runs half of a 2-MB weight tile ahead, far more than an XCD's L2 keeps, and the
     //  lockstep sharing of today is lost: profiles/r06/probe_k_rotation_sq128_slower.log)
     auto request = [&](int stage, int step) __attribute__((always_inline)) {
-        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(step * KSTEP);
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(k_order(step, mt, mtiles, nsteps, p.flags) * KSTEP);
 #pragma unroll
         for (int j = 0; j < PX; ++j) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], so);
 #pragma unroll
@@ -1022,7 +1021,12 @@ bool plan_gemm_a8w8_sq128(const gemlite_hip_forward_args& a, GenericParams& g, L
 #undef GL_SQ128
     if (lds < (size_t)128 * 132 * 4) lds = (size_t)128 * 132 * 4;
     g.splitk = 1;
-    g.flags = a.tuning[3];
+    // K order between the row tiles of a column tile (k_order(), gl_async.h): groups of ONE step for fp8 — FP8 16384^2 M = 256 94.7 -> 89.6 us, 8192^2 M = 512 45.1 -> 43.2 —
+    // and the plain order for int8 (8192^2 M = 512 46.3 -> 47.5, 4096^2 M = 1024 27.5 -> 28.1 with it); larger groups and the whole-K rotation lose on these
+    // 2-MB tiles (profiles/r06/probe_k_order_groups*.log, probe_k_rotation_sq128_slower.log).  tuning[3] bits 24 .. 27 force a group size, & 4194304 = plain.
+    g.flags = a.tuning[3] & ~((1 << 30) | 0x0F000000);
+    if (a.tuning[3] & 0x0F000000) g.flags |= (1 << 30) | (a.tuning[3] & 0x0F000000);
+    else if (!(a.tuning[3] & 4194304) && a.input_dtype != GEMLITE_DT_INT8 && (a.M + 127) / 128 >= 2 && ((a.N / 128) & 7) == 0) g.flags |= (1 << 30) | (1 << 24);
     lp.fn = (const void*)fn;
     lp.name = "gemm_a8w8_sq_kernel<128x128>";
     lp.grid = dim3((unsigned)tiles, 1, 1);
@@ -1045,6 +1049,21 @@ bool k_rotation_pays(const gemlite_hip_forward_args& a, int64_t tile_bytes) {
     const int64_t at_a_time = cus_per_xcd / mtiles > 0 ? cus_per_xcd / mtiles : 1;
     const int64_t tiles_x = ntiles / 8 < at_a_time ? ntiles / 8 : at_a_time;
     return tiles_x * tile_bytes <= (4ll << 20);
+}
+// The K-order bits of GenericParams::flags for the unsplit 64 x 64 tiles (k_order(), gl_async.h): whole-K rotation while the XCD's weight tiles stay well
+// inside its L2, else the GROUPED order with groups of one step — every tile leads on one step of each run of mtiles steps, so a line only has to survive
+// mtiles - 1 steps (late round 6, profiles/r06/probe_k_order_groups*.log: int8 4096 x 14336 M = 256, 7 MB per XCD: 34.5 -> 31.0 us where the whole rotation
+// cost +17 %; 4096 x 8192, 4 MB: whole 21.4 = none 21.6, grouped 20.1; MXFP8 4096 x 8192 28 .. 31 -> 25.4 whole -> 23.4 grouped; where the whole rotation
+// pays it stays ahead: 4096^2 M = 256 12.0 vs 12.8, 2048 x 8192 15.5 vs 17.9).  tuning[3] bits 24 .. 27 force a group size (1 + log2), & 4194304 = plain order.
+int k_order_flags(const gemlite_hip_forward_args& a, int64_t tile_bytes) {
+    if (a.tuning[3] & 4194304) return 0;
+    if (a.tuning[3] & 0x0F000000) return (1 << 30) | (a.tuning[3] & 0x0F000000);
+    const int64_t mtiles = (a.M + 63) / 64, ntiles = a.N / 64;
+    if (mtiles < 2 || (ntiles & 7) != 0) return 0;
+    const int64_t cus_per_xcd = resident_block_limit() / 8 > 0 ? resident_block_limit() / 8 : 1;
+    const int64_t at_a_time = cus_per_xcd / mtiles > 0 ? cus_per_xcd / mtiles : 1;
+    const int64_t tiles_x = ntiles / 8 < at_a_time ? ntiles / 8 : at_a_time;
+    return tiles_x * tile_bytes < (4ll << 20) ? (1 << 30) : ((1 << 30) | (1 << 24));
 }
 
 bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
@@ -1077,7 +1096,7 @@ bool plan_gemm_a8w8_sq(const gemlite_hip_forward_args& a, GenericParams& g, Laun
     fn = a.input_dtype == GEMLITE_DT_INT8 ? pick(std::integral_constant<int, GEMLITE_DT_INT8>{})
          : (a.input_dtype == GEMLITE_DT_FP8E4 ? pick(std::integral_constant<int, GEMLITE_DT_FP8E4>{}) : pick(std::integral_constant<int, GEMLITE_DT_FP8E5>{}));
     g.splitk = 1;
-    g.flags = (a.tuning[3] & ~(1 << 30)) | (k_rotation_pays(a, (int64_t)64 * a.K) ? (1 << 30) : 0);
+    g.flags = (a.tuning[3] & ~((1 << 30) | 0x0F000000)) | k_order_flags(a, (int64_t)64 * a.K);
     lp.fn = (const void*)fn;
     lp.name = "gemm_a8w8_sq_kernel<64x64>";
     lp.grid = dim3((unsigned)tiles, 1, 1);

@@ -1469,10 +1469,8 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_mx_sq_kernel(con
     // that each sibling CU pulls a different part of the HBM-cold weights and finds the rest in L2 (MXFP8 4096^2 M = 256 16.1 -> 12.3 us, MXFP4 9.5 ..
     // 10.6 -> 9.0, 4096 x 8192 27.8 -> 25.1: profiles/r06/probe_k_rotation_mx_and_int8_64x64.log).  The planner sets bit 30 of flags where the weight
     // tiles an XCD works on at a time fit its L2 (k_rotation_pays(), gemm_a8w8.hip); tuning[3] & 4194304 = never (A/B runs)
-    const int rot = (p.flags & (1 << 30)) ? (mt * nsteps) / mtiles : 0;
     auto request = [&](int stage, int step) __attribute__((always_inline)) {
-        step += rot;
-        if (step >= nsteps) step -= nsteps;
+        step = k_order(step, mt, mtiles, nsteps, p.flags);
 #pragma unroll
         for (int j = 0; j < PX; ++j) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * PA));
 #pragma unroll
@@ -1562,7 +1560,7 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_mx_sq_kernel(con
 }
 
 // 65 .. ~256 rows whose 64 x 64 tiles fill the chip about once (the caller's rule), fp8 x fp8 / fp4 x fp4 / fp8 x fp4; tuning[0] = 6 forces it
-bool k_rotation_pays(const gemlite_hip_forward_args& a, int64_t tile_bytes);  // gemm_a8w8.hip
+int k_order_flags(const gemlite_hip_forward_args& a, int64_t tile_bytes);  // gemm_a8w8.hip
 
 bool plan_gemm_mx_sq(const gemlite_hip_forward_args& a, GenericParams& g, LaunchPlan& lp) {
     if (g.mx_scale_e4m3 || g.group_size != 32 || a.M < 1) return false;
@@ -1599,7 +1597,7 @@ bool plan_gemm_mx_sq(const gemlite_hip_forward_args& a, GenericParams& g, Launch
     mx_kernel_fn_t f = f8 ? pick(F8{}, F8{}) : (f4 ? pick(F4{}, F4{}) : pick(F8{}, F4{}));
     g.splitk = 1;
     const int64_t wtile_bytes = (int64_t)64 * a.K / (g.mx_w == MX_FP4 ? 2 : 1);  // the weight bytes of a 64-column tile (fp8: K per column, fp4: K / 2)
-    g.flags = (a.tuning[3] & ~(1 << 30)) | (k_rotation_pays(a, wtile_bytes) ? (1 << 30) : 0);
+    g.flags = (a.tuning[3] & ~((1 << 30) | 0x0F000000)) | k_order_flags(a, wtile_bytes);
     lp.fn = (const void*)f;
     lp.name = f8 ? "gemm_mx_a8w8_sq_kernel<64x64>" : (f4 ? "gemm_mx_a4w4_sq_kernel<64x64>" : "gemm_mx_a8w4_sq_kernel<64x64>");
     lp.grid = dim3((unsigned)tiles, 1, 1);

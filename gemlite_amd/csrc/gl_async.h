@@ -63,6 +63,24 @@ __device__ __forceinline__ void req_lds4(srd_t rs, uint32_t lds_addr, uint32_t v
                  : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory", "m0");
 }
 #pragma clang diagnostic pop
+// K order of the row tiles that share a weight column tile (round 6; gemm_a8w8_sq_kernel has the reasoning).  flags bit 30 = on; bits 24 .. 27 = 0: row tile
+// mt starts at step mt nsteps / mtiles (whole-K rotation); = 1 + log2(G): the K steps form groups of G, and inside every run of mtiles groups row tile mt takes
+// them in the order mt, mt + 1, ... — each tile LEADS (pulls HBM-cold lines) on one group of the run and follows its siblings on the others, so the lines only have
+// to survive mtiles - 1 groups in L2 instead of a whole rotation.  A tail of fewer than mtiles groups keeps the plain order.  All operands are wave-uniform.
+__device__ __forceinline__ int k_order(int step, int mt, int mtiles, int nsteps, int flags) {
+    if (!(flags & (1 << 30)) || mtiles < 2) return step;
+    const int gm = (flags >> 24) & 15;
+    if (gm == 0) {
+        const int k = step + (mt * nsteps) / mtiles;
+        return k >= nsteps ? k - nsteps : k;
+    }
+    const int gsh = gm - 1;
+    int g = step >> gsh;
+    const int i = step & ((1 << gsh) - 1);
+    const int base = (g / mtiles) * mtiles;
+    if (base + mtiles <= (nsteps >> gsh)) g = base + (g - base + mt) % mtiles;
+    return (g << gsh) + i;
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void tie(uint32_t& v) { asm volatile("" : "+v"(v)); }

@@ -274,7 +274,8 @@ enum gemlite_hip_tuning_flags {            /* tuning[3]: bit flags (A/B switches
                                                     instead of w8_rows_lds_kernel (x through LDS in whole cache lines) */
     GEMLITE_TF_W8_ROWS_LDS_BELOW_4_ROWS = 1048576, /* A16W8: take w8_rows_lds_kernel at 1 .. 3 rows too (default: from 4) */
     GEMLITE_TF_A8W8_TILE_REQUESTS_FIRST = 2097152, /* round 6: the round-4 order of a K step of the 64 x 64 A8W8 tile (DMA requests in front of the LDS reads) */
-    GEMLITE_TF_NO_K_ROTATION = 4194304             /* round 6: every row tile of the unsplit 64 x 64 tiles of 8-bit weights starts its K loop at step 0 */
+    GEMLITE_TF_NO_K_ROTATION = 4194304,            /* round 6: every row tile of the unsplit tiles of 8-bit weights walks K in the plain order */
+    GEMLITE_TF_K_ORDER_GROUP_MASK = 0x0F000000     /* round 6: bits 24 .. 27 = 1 + log2(steps per group) of the grouped K order between the row tiles of a column tile (0 = the planner's choice) */
 };
 
 /* Library / ABI identification (host only, no device access). */

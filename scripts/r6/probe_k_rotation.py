@@ -17,6 +17,8 @@ bench.WORKLOADS.setdefault("a16w4_4096_m192", (4096, 4096, 4, 128, 192, "bf16", 
 bench.WORKLOADS.setdefault("a16w4_4096_m128", (4096, 4096, 4, 128, 128, "bf16", 32, "mfma"))
 bench.WORKLOADS.setdefault("a16w4_11008_m256", (11008, 4096, 4, 128, 256, "bf16", 16, "mfma"))
 bench.WORKLOADS.setdefault("a16w4_8192x4096_m256", (8192, 4096, 4, 128, 256, "bf16", 16, "mfma"))
+bench.WORKLOADS.setdefault("a8w8_16384_m256", (16384, 16384, 8, 16384, 256, "int8", 2, "mfma"))
+bench.WORKLOADS.setdefault("fp8_8192_m512", (8192, 8192, 8, 8192, 512, "fp8w8", 8, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_8192_m512", (8192, 8192, 8, 8192, 512, "int8", 8, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_4096_m1024", (4096, 4096, 8, 4096, 1024, "int8", 32, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_4096_m128", (4096, 4096, 8, 4096, 128, "int8", 32, "mfma"))
@@ -30,7 +32,8 @@ bench.WORKLOADS.setdefault("mx_a8w8_4096_m128", (4096, 4096, 8, 32, 128, "mxa8",
 for name in names:
     first = None
     for rep in range(2):
-        for t in ((0, 0, 0, 0), (0, 0, 0, 4194304), (0, 0, 0, 16777216)):
+        G = lambda n: (n << 24)
+        for t in ((0, 0, 0, 0), (0, 0, 0, 4194304), (0, 0, 0, G(1)), (0, 0, 0, G(2))):
             core.TUNING_OVERRIDE = t if any(t) else None
             try:
                 r = bench.Runner(name, dev, lib)

@@ -997,3 +997,33 @@ def test_group_index_by_multiply_high():
         q = np.concatenate([np.arange(0, min(kmax // 32, 1 << 16), dtype=np.uint64), rng.integers(0, kmax // 32, size=1 << 16, dtype=np.uint64),
                             np.array([kmax // 32 - 1], dtype=np.uint64)])
         assert np.array_equal((q * np.uint64(magic)) >> np.uint64(32), q // np.uint64(d)), gs
+
+
+def test_k_order_is_a_permutation_of_the_k_steps():
+    """k_order() (gl_async.h, round 6): the order in which row tile mt of a weight column tile walks its K steps — whole-K rotation or groups of 2^gsh steps
+    rotated inside every run of mtiles groups, plain order in a tail of fewer than mtiles groups.  Restated here: for every (nsteps, mtiles, mode) it must
+    visit every step exactly once, and in the grouped mode each row tile must LEAD (be the first to reach) a different group of every full run."""
+    def k_order(step, mt, mtiles, nsteps, gm):
+        if mtiles < 2:
+            return step
+        if gm == 0:
+            k = step + (mt * nsteps) // mtiles
+            return k - nsteps if k >= nsteps else k
+        gsh = gm - 1
+        g, i = step >> gsh, step & ((1 << gsh) - 1)
+        base = (g // mtiles) * mtiles
+        if base + mtiles <= (nsteps >> gsh):
+            g = base + (g - base + mt) % mtiles
+        return (g << gsh) + i
+
+    for nsteps in list(range(1, 40)) + [56, 64, 112, 128]:
+        for mtiles in (1, 2, 3, 4, 5, 8):
+            for gm in (0, 1, 2, 3, 4):
+                orders = [[k_order(s, mt, mtiles, nsteps, gm) for s in range(nsteps)] for mt in range(mtiles)]
+                for o in orders:
+                    assert sorted(o) == list(range(nsteps)), (nsteps, mtiles, gm)
+                if gm >= 1 and mtiles >= 2:
+                    G = 1 << (gm - 1)
+                    for run in range((nsteps // G) // mtiles):
+                        first = [orders[mt][run * mtiles * G] // G for mt in range(mtiles)]   # the group each tile starts the run with
+                        assert sorted(first) == list(range(run * mtiles, run * mtiles + mtiles)), (nsteps, mtiles, gm, run)
