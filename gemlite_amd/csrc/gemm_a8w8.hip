@@ -692,7 +692,9 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_a8w8_sq_kernel(c
     //  staggering the column tiles that share a row tile of x as well: nothing.  It pays only while the weight tiles an XCD works on at a time stay in
     //  its L2 — the planner sets bit 30 of flags by that rule (k_rotation_pays() below: 4096 x 14336 M = 256, 7 MB per XCD, 34.4 -> 40.2 us).
     //  profiles/r06/probe_a8w8_sq_k_rotation.log, probe_k_rotation_*.log; tuning[3] & 4194304 = never, for A/B runs)
-    auto kof = [&](int step) __attribute__((always_inline)) { return k_order(step, mt, mtiles, nsteps, p.flags); };
+    KOrder kord;
+    kord.init(mt, mtiles, nsteps, p.flags);
+    auto kof = [&](int step) __attribute__((always_inline)) { return kord.at(step); };
     auto request = [&](int stage, int step) __attribute__((always_inline)) {
         const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(kof(step) * KSTEP);
 #pragma unroll
@@ -877,8 +879,10 @@ __global__ __launch_bounds__(512, 2) void gemm_a8w8_sq128_kernel(const GenericPa
     // (K rotation between the row tiles of a column tile, which pays on the 64 x 64 tiles, LOSES here: FP8 16384^2 M = 256 94.5 -> 113 us, int8 8192^2
     //  M = 512 46.6 -> 51.2, 4096^2 M = 1024 27.5 -> 28.0 — the sibling runs half of a 2-MB weight tile ahead, far more than an XCD's L2 keeps, and the
     //  lockstep sharing of today is lost: profiles/r06/probe_k_rotation_sq128_slower.log)
+    KOrder kord;
+    kord.init(mt, mtiles, nsteps, p.flags);
     auto request = [&](int stage, int step) __attribute__((always_inline)) {
-        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(k_order(step, mt, mtiles, nsteps, p.flags) * KSTEP);
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(kord.at(step) * KSTEP);
 #pragma unroll
         for (int j = 0; j < PX; ++j) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], so);
 #pragma unroll

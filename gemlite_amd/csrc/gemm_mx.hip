@@ -1469,8 +1469,10 @@ __global__ __launch_bounds__(512, (NST <= 2 ? 2 : 1)) void gemm_mx_sq_kernel(con
     // that each sibling CU pulls a different part of the HBM-cold weights and finds the rest in L2 (MXFP8 4096^2 M = 256 16.1 -> 12.3 us, MXFP4 9.5 ..
     // 10.6 -> 9.0, 4096 x 8192 27.8 -> 25.1: profiles/r06/probe_k_rotation_mx_and_int8_64x64.log).  The planner sets bit 30 of flags where the weight
     // tiles an XCD works on at a time fit its L2 (k_rotation_pays(), gemm_a8w8.hip); tuning[3] & 4194304 = never (A/B runs)
+    KOrder kord;
+    kord.init(mt, mtiles, nsteps, p.flags);
     auto request = [&](int stage, int step) __attribute__((always_inline)) {
-        step = k_order(step, mt, mtiles, nsteps, p.flags);
+        step = kord.at(step);
 #pragma unroll
         for (int j = 0; j < PX; ++j) req_lds16(rsX, ldsx + (uint32_t)(stage * STAGE + j * 1024), xvoff[j], (uint32_t)__builtin_amdgcn_readfirstlane(step * PA));
 #pragma unroll

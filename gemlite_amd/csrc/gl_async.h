@@ -66,21 +66,45 @@ __device__ __forceinline__ void req_lds4(srd_t rs, uint32_t lds_addr, uint32_t v
 // K order of the row tiles that share a weight column tile (round 6; gemm_a8w8_sq_kernel has the reasoning).  flags bit 30 = on; bits 24 .. 27 = 0: row tile
 // mt starts at step mt nsteps / mtiles (whole-K rotation); = 1 + log2(G): the K steps form groups of G, and inside every run of mtiles groups row tile mt takes
 // them in the order mt, mt + 1, ... — each tile LEADS (pulls HBM-cold lines) on one group of the run and follows its siblings on the others, so the lines only have
-// to survive mtiles - 1 groups in L2 instead of a whole rotation.  A tail of fewer than mtiles groups keeps the plain order.  All operands are wave-uniform.
-__device__ __forceinline__ int k_order(int step, int mt, int mtiles, int nsteps, int flags) {
-    if (!(flags & (1 << 30)) || mtiles < 2) return step;
-    const int gm = (flags >> 24) & 15;
-    if (gm == 0) {
-        const int k = step + (mt * nsteps) / mtiles;
-        return k >= nsteps ? k - nsteps : k;
+// to survive mtiles - 1 groups in L2 instead of a whole rotation.  A tail of fewer than mtiles groups keeps the plain order.
+// Everything per step is SCALAR arithmetic (the quotient by mtiles through a multiply-high with a constant set up once): the step offset feeds the soffset operand
+// of inline-asm requests, and an SGPR written by v_readfirstlane right in front of them would need wait states nothing inserts.
+struct KOrder {
+    int mode;        // 0 plain, 1 whole-K rotation, 2 grouped
+    int rot, nsteps; // whole rotation
+    int gsh, P, mt, ngroups;
+    uint32_t magic;  // ceil(2^32 / P)
+    __device__ __forceinline__ void init(int mt_, int mtiles, int nsteps_, int flags) {
+        mode = 0; rot = 0; nsteps = nsteps_; gsh = 0; P = mtiles; mt = mt_; ngroups = 0; magic = 0u;
+        if (!(flags & (1 << 30)) || mtiles < 2) return;
+        const int gm = (flags >> 24) & 15;
+        if (gm == 0) {
+            mode = 1;
+            rot = __builtin_amdgcn_readfirstlane((mt_ * nsteps_) / mtiles);
+        } else {
+            mode = 2;
+            gsh = gm - 1;
+            ngroups = nsteps_ >> gsh;
+            magic = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(((1ull << 32) + (uint64_t)mtiles - 1ull) / (uint64_t)mtiles));
+        }
     }
-    const int gsh = gm - 1;
-    int g = step >> gsh;
-    const int i = step & ((1 << gsh) - 1);
-    const int base = (g / mtiles) * mtiles;
-    if (base + mtiles <= (nsteps >> gsh)) g = base + (g - base + mt) % mtiles;
-    return (g << gsh) + i;
-}
+    __device__ __forceinline__ int at(int step) const {
+        if (mode == 0) return step;
+        if (mode == 1) {
+            const int k = step + rot;
+            return k >= nsteps ? k - nsteps : k;
+        }
+        int g = step >> gsh;
+        const int i = step & ((1 << gsh) - 1);
+        const int base = (int)__umulhi((uint32_t)g, magic) * P;  // (g / P) * P: exact while g P < 2^32
+        if (base + P <= ngroups) {
+            int r = g - base + mt;
+            if (r >= P) r -= P;
+            g = base + r;
+        }
+        return (g << gsh) + i;
+    }
+};
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void tie(uint32_t& v) { asm volatile("" : "+v"(v)); }

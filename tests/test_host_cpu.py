@@ -1011,9 +1011,12 @@ def test_k_order_is_a_permutation_of_the_k_steps():
             return k - nsteps if k >= nsteps else k
         gsh = gm - 1
         g, i = step >> gsh, step & ((1 << gsh) - 1)
-        base = (g // mtiles) * mtiles
+        magic = ((1 << 32) + mtiles - 1) // mtiles          # the kernel's quotient: one scalar multiply-high
+        base = ((g * magic) >> 32) * mtiles
+        assert base == (g // mtiles) * mtiles
         if base + mtiles <= (nsteps >> gsh):
-            g = base + (g - base + mt) % mtiles
+            r = g - base + mt
+            g = base + (r - mtiles if r >= mtiles else r)
         return (g << gsh) + i
 
     for nsteps in list(range(1, 40)) + [56, 64, 112, 128]:
