@@ -385,11 +385,12 @@ static bool rows5_pays(int64_t M, int64_t N, int64_t K, int gs_shift) {
 // When the unsplit 128 x 128 A8W8 tiles are the default (profiles/r05/probe_a8w8_sq128.log): more than 64 rows, and the 128 x 128 tiles
 // number 192 .. 256 — one round with most CUs busy (FP8 16384^2 M = 256: 95.8 vs 98.5 us; int8 8192^2 M = 512: 47.0 vs 52.7;
 // 4096^2 M = 1024: 27.5 vs 32.2; 14336 x 4096 M = 256: 29.0 vs 31.1).  Fewer tiles (8192^2 M = 256: 44.5 vs 36.1 us) and several rounds
-// (8192^2 M = 1024: 89.8 vs 76.3) stay on the 128- / 256-row tiles with K slices.
+// (8192^2 M = 1024: 89.8 vs 76.3) stay on the 128- / 256-row tiles with K slices.  Late round 6: from 160 tiles (11008 x 4096 M = 256, 172 tiles: 38.4 -> 28.1 us;
+// 128 tiles still lose: 8192^2 M = 256 44.6 vs 34.2 — profiles/r06/probe_a8w8_forms.log).
 static bool a8w8_sq128_pays(const gemlite_hip_forward_args& a) {
     if (a.M <= 64 || a.N % 128 != 0 || a.K < 4096) return false;
     const int64_t tiles = (a.N / 128) * ((a.M + 127) / 128);
-    return tiles >= 192 && tiles <= gl::resident_block_limit();
+    return tiles >= 160 && tiles <= gl::resident_block_limit();
 }
 
 static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {
