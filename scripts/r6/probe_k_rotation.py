@@ -19,6 +19,10 @@ bench.WORKLOADS.setdefault("a16w4_11008_m256", (11008, 4096, 4, 128, 256, "bf16"
 bench.WORKLOADS.setdefault("a16w4_8192x4096_m256", (8192, 4096, 4, 128, 256, "bf16", 16, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_16384_m256", (16384, 16384, 8, 16384, 256, "int8", 2, "mfma"))
 bench.WORKLOADS.setdefault("fp8_8192_m512", (8192, 8192, 8, 8192, 512, "fp8w8", 8, "mfma"))
+bench.WORKLOADS.setdefault("a8w8_8192_m256", (8192, 8192, 8, 8192, 256, "int8", 8, "mfma"))
+bench.WORKLOADS.setdefault("fp8_8192_m256", (8192, 8192, 8, 8192, 256, "fp8w8", 8, "mfma"))
+bench.WORKLOADS.setdefault("a8w8_8192_m1024", (8192, 8192, 8, 8192, 1024, "int8", 8, "mfma"))
+bench.WORKLOADS.setdefault("a8w8_4096_m2048", (4096, 4096, 8, 4096, 2048, "int8", 16, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_8192_m512", (8192, 8192, 8, 8192, 512, "int8", 8, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_4096_m1024", (4096, 4096, 8, 4096, 1024, "int8", 32, "mfma"))
 bench.WORKLOADS.setdefault("a8w8_4096_m128", (4096, 4096, 8, 4096, 128, "int8", 32, "mfma"))
@@ -33,7 +37,7 @@ for name in names:
     first = None
     for rep in range(2):
         G = lambda n: (n << 24)
-        for t in ((0, 0, 0, 0), (0, 0, 0, 4194304), (0, 0, 0, G(1)), (0, 0, 0, G(2))):
+        for t in ((0, 0, 0, 0), (0, 0, 0, 4194304), (0, 0, 0, G(1)), (0, 0, 0, G(2)), (0, 0, 0, G(3))):
             core.TUNING_OVERRIDE = t if any(t) else None
             try:
                 r = bench.Runner(name, dev, lib)
