@@ -241,8 +241,12 @@ static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, cons
     //  rows — 4096^2 M = 256: fp8 27.2 -> 17.4 us, fp4 29.7 -> 13.7; at 512 rows for fp4 x fp4 and for one-round shapes)
     // Up to 64 rows they take what the few-row kernel's budget refuses (plan_mx_rows): fp4 x fp4 anywhere, fp8 activations from 128 column tiles.
     const bool sq_few = a.M >= 2 && a.M <= 64 && ((g.mx_x == MX_FP4 && g.mx_w == MX_FP4) || a.N / 64 >= 128);
-    const bool sq_auto = sq_few || (a.M > 64 && (a.M <= 384 || (a.M <= 512 && ((g.mx_x == MX_FP4 && g.mx_w == MX_FP4) ||
-                                                                                ((a.N / 64) * ((a.M + 63) / 64) <= 512 && a.K <= 4096)))));
+    // Late round 6 (the tiles walk K in the rotated / grouped order now and are 10 - 25 % faster: profiles/r06/probe_mx_forms*.log): up to 1024 rows — MXFP8 4096^2 M = 768 / 1024
+    // 62.5 / 52.2 (128-column tiles) -> 34.8 / 35.2 us, 8192^2 M = 512 / 1024 94.0 / 134.8 -> 82.7 / 127.3, 4096 x 14336 M = 512 87.1 -> 84.2; MXFP4 4096^2 M = 1024 37.9 -> 22.4, but
+    // 8192^2 M = 1024 75.0 (256 x 256 tiles) vs 87.5.  2048 rows: the 256 x 256 tiles (59.3 vs 73.5, fp4 43.0 vs 46.3).
+    // fp4 WEIGHTS (fp4 x fp4 and fp8 x fp4: 8192^2 M = 1024 111.9 (256 x 256) vs 119.7) above 512 rows only up to N K = 4096^2 (M = 1024: 38.9 -> 33.0).
+    const bool mx_w4 = g.mx_w == MX_FP4;
+    const bool sq_auto = sq_few || (a.M > 64 && (a.M <= 512 || (a.M <= 1024 && (!mx_w4 || (int64_t)a.N * a.K <= (1ll << 24)))));
     if ((a.tuning[0] == 6 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && sq_auto)) && plan_gemm_mx_sq(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
     // decode sizes of what is left (K % 64 != 0 ...): the streaming kernel
     if ((a.tuning[0] == 5 || (a.tuning[0] == 0 && !a16_over)) && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }

@@ -196,7 +196,9 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(args(16, 8, 65, 4)) == "gemm_mx_a8w8_sq_kernel<64x64>"
     assert name(args(16, 8, 512, 4)) == "gemm_mx_a8w8_sq_kernel<64x64>"    # 512 tiles, K <= 4096
     assert name(args(17, 4, 512, 4, N=8192, K=8192)) == "gemm_mx_a4w4_sq_kernel<64x64>"
-    assert name(args(16, 4, 512, 2, N=8192, K=8192)) == "gemm_mx_a8w4_kernel<128x128>"
+    assert name(args(16, 4, 512, 2, N=8192, K=8192)) == "gemm_mx_a8w4_sq_kernel<64x64>"   # (late round 6: up to 512 rows everywhere — 77.8 -> 70.4 us)
+    assert name(args(16, 8, 1024, 4)) == "gemm_mx_a8w8_sq_kernel<64x64>"                    # fp8 weights: up to 1024 rows (4096^2: 52.2 -> 35.2 us)
+    assert name(args(16, 4, 1024, 2, N=8192, K=8192)) != "gemm_mx_a8w4_sq_kernel<64x64>"   # fp4 weights above 512 rows: only up to N K = 4096^2
     a = args(16, 8, 256, 4)
     a.tuning[0] = 2                                                       # A/B switch: the 128-column kernel with K slices
     assert name(a) == "gemm_mx_a8w8_kernel<128x128>"  # the tallest tile that fills the chip with <= K / 1024 slices
@@ -204,7 +206,7 @@ def test_c_abi_routes_block_scaled_formats():
     a.M = 700
     assert name(a) == "gemm_mx_a8w8_sq_kernel<64x64>"
     assert name(args(16, 8, 2048, 4, N=8192, K=8192)) == "gemm_mx_a8w8_tile_kernel<256x256>"  # >= 96 tiles of 256 x 256
-    assert name(args(16, 8, 512, 4, N=8192, K=8192)) == "gemm_mx_a8w8_kernel<128x128>"        # 64 tiles: the 128-row kernel
+    assert name(args(16, 8, 512, 4, N=8192, K=8192)) == "gemm_mx_a8w8_sq_kernel<64x64>"       # (late round 6: 94.0 -> 82.7 us; rounds 4-5: the 128-row kernel)
     assert name(args(16, 8, 1, 4)) == "mx_rows_a8w8_kernel<16x16>"    # round 4: fp8 / fp4 activations take the few-row MFMA kernel from 1 row
     assert name(args(17, 4, 4, 4)) == "mx_rows_a4w4_kernel<16x16>"
     a = args(16, 8, 1, 4)
