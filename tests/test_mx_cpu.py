@@ -239,7 +239,8 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(args(17, 4, 300, 4, K=11008)) == "gemm_mx_a4w4_sq_kernel<64x64>"  # fp4 activations, K % 512 != 0 but K % 256 == 0: the 64 x 64 tiles take it (round 4)
     assert name(args(17, 4, 600, 4, K=11008)) == "mx_rows_a4w4_kernel<64x16>"   # ... above their row range: no tile kernel -> 64-row tiles of the few-row kernel
     assert name(args(17, 4, 300, 4, K=4096)) == "gemm_mx_a4w4_sq_kernel<64x64>"
-    assert name(args(17, 4, 600, 4, K=4096)) == "gemm_mx_a4w4_kernel<128x128>"
+    assert name(args(17, 4, 600, 4, K=4096)) == "gemm_mx_a4w4_sq_kernel<64x64>"   # (late round 6: fp4 weights up to 1024 rows while N K <= 4096^2)
+    assert name(args(17, 4, 1100, 4, K=4096)) == "gemm_mx_a4w4_kernel<128x128>"
     assert name(args(16, 8, 5, 4)) == "mx_rows_a8w8_kernel<16x16>"       # round 4: 5 .. 64 rows, 16-column blocks
     assert name(args(16, 4, 33, 2)) == "mx_rows_a8w4_kernel<64x16>"
     assert name(args(17, 4, 20, 4)) == "mx_rows_a4w4_kernel<32x16>"
