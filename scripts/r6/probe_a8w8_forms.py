@@ -15,11 +15,16 @@ SH = {"a8w8_8192_m256": (8192, 8192, 8, 8192, 256, "int8", 8, "mfma"), "fp8_8192
       "a8w8_8192_m128": (8192, 8192, 8, 8192, 128, "int8", 8, "mfma"), "a8w8_14336x4096_m256": (14336, 4096, 8, 4096, 256, "int8", 8, "mfma"),
       "a8w8_8192x4096_m256": (8192, 4096, 8, 4096, 256, "int8", 16, "mfma"), "a8w8_4096_m384": (4096, 4096, 8, 4096, 384, "int8", 32, "mfma"),
       "a8w8_11008x4096_m256": (11008, 4096, 8, 4096, 256, "int8", 8, "mfma")}
+for m in (512, 768, 1024, 1536, 2048):
+    SH[f"a8w8_4096_m{m}"] = (4096, 4096, 8, 4096, m, "int8", 16, "mfma")
+    SH[f"fp8_4096_m{m}"] = (4096, 4096, 8, 4096, m, "fp8w8", 16, "mfma")
+SH["a8w8_8192_m512"] = (8192, 8192, 8, 8192, 512, "int8", 8, "mfma")
+SH["a8w8_8192_m1024"] = (8192, 8192, 8, 8192, 1024, "int8", 8, "mfma")
 bench.WORKLOADS.update(SH)
 for name in (sys.argv[1:] or list(SH)):
     first = None
     for rep in range(2):
-        for t in ((0, 0, 0, 0), (5, 0, 0, 0), (5, 0, 2, 0), (5, 0, 4, 0), (10, 0, 0, 0), (6, 0, 0, 0)):
+        for t in ((0, 0, 0, 0), (5, 0, 0, 0), (10, 0, 0, 0), (6, 0, 0, 0)):
             core.TUNING_OVERRIDE = t if any(t) else None
             try:
                 r = bench.Runner(name, dev, lib)
