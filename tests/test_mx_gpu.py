@@ -356,7 +356,7 @@ def test_nvfp4_few_row_kernel_against_the_oracle_and_the_tile_kernel():
 def test_fp4_activations_with_k_not_a_multiple_of_512_leave_the_coverage_kernel():
     """The fp4 x fp4 tile kernels step 512 k; K = 11008 (Llama down_proj) is 21.5 such steps and ran on the coverage kernel in rounds 2-3
     (4.5 ms at 4096 x 11008).  Round 4: any M on 64-row tiles of the few-row kernel (grid.y), 128-k chunks; 65 .. 512 rows on the 64 x 64
-    tile kernel (256-k steps: K = 1280 and 11008 are whole numbers of them), K % 256 != 0 still on the few-row kernel."""
+    tile kernel (256-k steps: K = 1280 and 11008 are whole numbers of them; late round 6: up to 1024 rows), K % 256 != 0 still on the few-row kernel."""
     tdt = torch.bfloat16
     N, K = 256, 1280
     lin = _linear(N, K, tdt, seed=21)
@@ -366,7 +366,7 @@ def test_fp4_activations_with_k_not_a_multiple_of_512_leave_the_coverage_kernel(
     for M in (7, 64, 65, 100, 300, 600):
         x = (torch.randn(M, K, generator=g) / 4).to(tdt).to(DEV)
         name = _kernel_name(layer, x)
-        assert name.startswith("gemm_mx_a4w4_sq_kernel" if 22 < M <= 512 else "mx_rows_a4w4_kernel"), name
+        assert name.startswith("gemm_mx_a4w4_sq_kernel" if 22 < M <= 1024 else "mx_rows_a4w4_kernel"), name   # (late round 6: up to 1024 rows while N K <= 4096^2)
         _check(f"a4w4 K=1280 M={M} {name}", layer(x), _oracle(layer, x) + bias, tdt)
     lin2 = _linear(N, K + 128, tdt, seed=22)
     layer2 = PROCS["A4W4_MXFP_dynamic"](tdt).from_linear(lin2, del_orig=False)
@@ -473,7 +473,8 @@ def test_prefill_tile_kernel_is_the_default_when_the_tiles_fill_the_chip():
     x = (torch.randn(M, K, generator=torch.Generator().manual_seed(3)) / 4).to(tdt).to(DEV)
     assert _kernel_name(layer, x).startswith("gemm_mx_a4w4_tile_kernel")
     _check("tile kernel, natural", layer(x), _oracle(layer, x), tdt)
-    assert _kernel_name(layer, x[:1024]).startswith("gemm_mx_a4w4_kernel")  # 64 tiles: the 128-row kernel
+    assert _kernel_name(layer, x[:1100]).startswith("gemm_mx_a4w4_kernel")  # 80 tiles: the 128-row kernel (up to 1024 rows: the unsplit 64 x 64 tiles, late round 6)
+    assert _kernel_name(layer, x[:1024]).startswith("gemm_mx_a4w4_sq_kernel")
 
 
 @pytest.mark.parametrize("proc", ["A4W4_MXFP_dynamic", "A8W8_MXFP_dynamic_post", "A16W4_MXFP", "A4W4_NVFP_dynamic"])
