@@ -187,7 +187,7 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
     if ((a.stride_xm * es) % 16 != 0 || ((uintptr_t)a.x % 16) != 0) return false;  // 16-byte LDS-DMA pieces
     const int oal = a.output_dtype == GEMLITE_DT_FP32 ? 16 : 8;  // 4 outputs per store
     if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
-    if (p.group_size % 64 != 0) {
+    if (p.group_size % 64 != 0 || p.gs_shift < 0) {  // (gs_shift < 0: group sizes that are not a power of two — multiples of 64 included — on the NGS = 2 form, the one that can divide)
         // Groups of 32 (round 6): 32-row tiles with TWO (scale, zero) pairs per column and 64-k sub-block (template parameter NGS = 2).
         // What reaches this: 1- and 8-bit packed words and fp8 activations x 4- / 2-bit words at M >= 2 (4- / 2-bit words under 16-bit activations
         // have the rows kernel in front) — shapes that ran on the coverage kernel until round 5 (4096^2 M = 64: ~3.8 ms).
