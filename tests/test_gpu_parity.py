@@ -1184,6 +1184,35 @@ def test_a8w8_rows_lds_kernel(kind):
         assert torch.equal(y, y_r4), M
 
 
+def test_w8_rows_lds_kernel_reads_rows_by_their_stride():
+    """w8_rows_lds_kernel builds the source addresses of its LDS-DMA pieces from stride_xm (rows of a wider tensor, e.g. one projection's slice of a
+    fused activation buffer): a strided x must give the bits of the contiguous copy, for every row-tile height, 8-bit and 16-bit x."""
+    from gemlite_amd.core import _hip_matmul
+    H = gemlite_amd.helper
+    g = torch.Generator().manual_seed(77)
+    N, K = 256, 1024
+    W = (torch.randn(N, K, generator=g) / 30).half()
+    lin8 = H.A8W8_int8_dynamic(device=DEV, dtype=torch.float16).from_weights(W)
+    lin16 = H.A16W8(device=DEV, dtype=torch.float16).from_weights(W)
+    for M in (5, 20, 40, 64):
+        wide = (torch.randn(M, 3 * K, generator=g) / 10).half().to(DEV)
+        x = wide[:, K:2 * K]                              # row stride 3 K, 16-byte aligned
+        assert not x.is_contiguous() and x.stride(0) == 3 * K
+        tun = (4, 0, 0, 0)
+        assert _kernel_name(lin16, x, -1, tun).startswith("a16w8_rows_lds_kernel<")
+        y = _hip_matmul(x, lin16.W_q, lin16.scales, lin16.zeros, None, lin16.get_meta_args(), -1, tun)
+        y_c = _hip_matmul(x.contiguous(), lin16.W_q, lin16.scales, lin16.zeros, None, lin16.get_meta_args(), -1, tun)
+        xq, sx = scale_activations_per_token(x.contiguous(), torch.int8)
+        wide_q = torch.zeros(M, 3 * K, dtype=torch.int8, device=DEV)
+        wide_q[:, K:2 * K] = xq
+        xq_s = wide_q[:, K:2 * K]
+        assert _kernel_name(lin8, xq_s, -1, tun).startswith("a8w8_rows_lds_kernel<")
+        z = _hip_matmul(xq_s, lin8.W_q, lin8.scales, lin8.zeros, sx, lin8.get_meta_args(), -1, tun)
+        z_c = _hip_matmul(xq, lin8.W_q, lin8.scales, lin8.zeros, sx, lin8.get_meta_args(), -1, tun)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_c) and torch.equal(z, z_c), M
+
+
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("proc", ["A16W8_INT8", "A16W8_INT8_post", "A16W8_FP8", "A16W8_FP8e5"])
 def test_a16w8_rows_lds_kernel(proc, tdt):
