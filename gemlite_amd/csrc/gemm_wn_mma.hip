@@ -33,6 +33,10 @@ static int narrow_auto(int64_t M, int64_t N, int64_t K, int es) {
     if (t64 >= (M <= 64 ? 64 : 96) && t64 <= 128 && K / 256 >= 8 && (M > 64 || K <= 8192)) return 2;
     // (late round 6, planner re-validation: a short K has nothing to slice — 4096 x 1024 M = 128, 128 tiles: 9.27 (32 x 128 tiles) -> 6.92 us unsplit)
     if (M > 64 && t64 >= 96 && t64 <= 128 && K / 256 < 8) return 1;
+    // ... and narrow layers (N <= 1024: the k / v projections of grouped-query models) with 32 .. 64 tiles: two K slices — 1024 x 4096 M = 96 / 128 / 192 / 256
+    // 12.4 / 12.5 / 13.5 / 12.8 -> 11.0 / 11.2 / 11.3 / 11.4 us (profiles/r06/probe_mma_narrow_shapes_more_m.log; wider layers with as few tiles — 1536 x 8960 — lose with it)
+    // (2-bit words: 15.5 .. 17.6 -> 11.3 .. 11.7; K = 8192 the other way round, 14.6 vs 15.6: up to K = 4096 — profiles/r06/probe_narrow_layers_two_slices.log)
+    if (M > 64 && N / 64 <= 16 && t64 >= 32 && t64 <= 64 && K / 256 >= 8 && K / 256 <= 16) return 2;
     return 0;
 }
 
