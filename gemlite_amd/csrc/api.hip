@@ -322,7 +322,12 @@ static bool a8w8_sq_pays(const gemlite_hip_forward_args& a) {
     if (a.N % 64 != 0) return false;
     if (a.M <= 64) return a.M >= 2 && a.N / 64 >= 128 && a.N / 64 <= 512;
     const int64_t tiles = (a.N / 64) * ((a.M + 63) / 64);
-    return tiles <= 256 || (tiles <= 512 && a.K <= 4096);
+    // late round 6 (profiles/r06/scan_a8w8_*.log, 20 LLM layer shapes x M = 96 .. 512): two rounds hold up to K = 8192 since the requests sit between
+    // the MFMAs and the row tiles rotate their K order (8192^2 M = 256: 35.4 -> 32.7 us, 13824 x 5120 M = 128: 37.9 -> 25.0, 3072 x 8192 M = 512:
+    // 43.4 -> 27.2; K = 11008 / 13824 still lose: 4096 x 11008 M = 512 58.8 vs 43.7); a very long K under few tiles goes to the K slices of the
+    // 128 x 128 tiles (4096 x 14336 M = 96 / 128: 28.2 / 30.6 -> 26.4 / 27.5; M = 256 stays: 30.4 vs 38.2)
+    if (a.K >= 14336 && a.M <= 128 && tiles <= 128 && a.N % 128 == 0) return false;
+    return tiles <= 256 || (tiles <= 512 && a.K <= 8192);
 }
 
 // When gemm_w4_rows_kernel (gemm_wn_rows.hip, round 5) is the default for A16W4 (profiles/r05/probe_rows5_v2*.log: 14 layer shapes x
@@ -392,9 +397,12 @@ static bool rows5_pays(int64_t M, int64_t N, int64_t K, int gs_shift) {
 // (8192^2 M = 1024: 89.8 vs 76.3) stay on the 128- / 256-row tiles with K slices.  Late round 6: from 160 tiles (11008 x 4096 M = 256, 172 tiles: 38.4 -> 28.1 us;
 // 128 tiles still lose: 8192^2 M = 256 44.6 vs 34.2 — profiles/r06/probe_a8w8_forms.log).
 static bool a8w8_sq128_pays(const gemlite_hip_forward_args& a) {
-    if (a.M <= 64 || a.N % 128 != 0 || a.K < 4096) return false;
+    // From 144 tiles (6144 x 4096 M = 384: 36.2 -> 26.1 us); a short K (< 4096) only where the 64 x 64 tiles would need more than two rounds
+    // (8192 x 2048 / x 3072 M = 384: 30.0 / 33.5 -> 17.9 / 23.1; 8960 x 1536 M = 256, 140 tiles: 28.5 -> 16.4) — profiles/r06/scan_a8w8_*.log.
+    if (a.M <= 64 || a.N % 128 != 0) return false;
     const int64_t tiles = (a.N / 128) * ((a.M + 127) / 128);
-    return tiles >= 160 && tiles <= gl::resident_block_limit();
+    if (a.K < 4096) return tiles >= 136 && tiles <= gl::resident_block_limit() && (a.N / 64) * ((a.M + 63) / 64) > 512;
+    return tiles >= 144 && tiles <= gl::resident_block_limit();
 }
 
 static void resolve(const gemlite_hip_forward_args& a, Resolved& r) {

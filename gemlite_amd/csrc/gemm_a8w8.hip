@@ -1173,8 +1173,12 @@ bool plan_gemm_a8w8_mma(const gemlite_hip_forward_args& a, GenericParams& g, Lau
         if (a.tuning[1] > units) return false;
         splitk = a.tuning[1];
     } else {
+        // (the LDS-fed tiles hold one block per CU: a slice count that spills into a second round loses to the one before it while that one
+        //  keeps half the chip busy — 8192 x 2048 M = 384, 192 tiles: two slices 30.1 us, one 19.6; 4096 x 14336 M = 384, 96 tiles: three 65.9,
+        //  two 47.6; profiles/r06/scan_a8w8_*.log)
         for (int sk = 1; sk <= units && sk <= 32; ++sk) {
             if (units / sk < (lds_b ? 4 : 2)) continue;
+            if (lds_b && splitk >= 1 && tiles * sk > gl::resident_block_limit() && tiles * splitk >= 128) break;
             splitk = sk;
             if (tiles * sk >= 224) break;
         }

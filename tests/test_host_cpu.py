@@ -228,13 +228,16 @@ def test_struct_abi_and_validation():
     (dict(M=65, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # round 4: unsplit 64 x 64 tiles while they fit
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),  # one round of CUs (config 4: 21.7 -> 13.6 us) ...
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_lds_kernel<128x128>"),   # (tuning[0] = 6: the round-3 tile, both operands through LDS)
-    (dict(M=256, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # ... two rounds of a long K: the 128-row tile
+    (dict(M=256, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # ... two rounds up to K = 8192 (late round 6: 35.4 -> 32.7 us)
+    (dict(M=512, N=4096, K=11008, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # ... of a longer K: the 128-row tile with K slices (58.8 vs 43.7)
+    (dict(M=384, N=8192, K=2048, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<128x128>"),   # late round 6: short K, 192 tiles of 128 x 128 (30.0 -> 17.9)
+    (dict(M=128, N=4096, K=14336, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),   # late round 6: very long K under 128 tiles (30.6 -> 27.5)
     (dict(M=256, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(0, 0, 0, 64)), "gemm_a8w8_mma_kernel<128x128>"),   # A/B switch
     (dict(M=512, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<64x64>"),   # two rounds at K = 4096: 2 stages, two blocks per CU
     (dict(M=1024, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<128x128>"),   # round 5: 256 unsplit 128 x 128 tiles (27.5 vs 32.2 us)
     (dict(M=1024, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_lds_kernel<128x128>"),   # (round 3; 256-row tiles would leave half the chip idle)
     (dict(M=512, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<128x128>"),   # 256 tiles again (47.0 vs 52.7 us)
-    (dict(M=256, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<128x128>"),  # 128 tiles: K slices (36 vs 44 us)
+    (dict(M=256, N=8192, K=8192, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_lds_kernel<128x128>"),  # (round 3: 128 tiles with K slices; 128 x 128 unsplit: 44 us)
     (dict(M=4096, nbits=8, e=1, in_dt=4, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_lds_kernel<256x128>"),
     (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1), "gemm_a8w8_sq_kernel<128x128>"),  # config 5, round 5: 256 unsplit 128 x 128 tiles (95.8 vs 98.5 us)
     (dict(M=256, N=16384, K=16384, nbits=8, e=1, in_dt=3, w_mode=0, c_mode=3, out_dt=1, tuning=(6, 0, 0, 0)), "gemm_a8w8_lds_kernel<256x128>"),  # (round 3: 128 tiles x 2 slices of a long K)
