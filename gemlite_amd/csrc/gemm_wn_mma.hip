@@ -68,7 +68,13 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         if (((uintptr_t)a.out % oal) != 0 || (a.stride_om * (oal / 4)) % oal != 0) return false;
         if (k8 && p.epi.c_mode != 0 && p.epi.c_mode != 2 && ((uintptr_t)p.epi.scales_w % 16) != 0) return false;  // 4 channel scales per load
     }
-    const int nauto = (a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384)) ? narrow_auto(a.M, a.N, a.K, 2) : 0;
+    int nauto = (a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384)) ? narrow_auto(a.M, a.N, a.K, 2) : 0;
+    const bool k8_auto = k8 && a.M > 64 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384);
+    // plain 8-bit weights (late round 6, profiles/r06/scan_a16w8_*.log): very few narrow tiles take FOUR K slices while those stay one round
+    // (1024 x 4096 M = 128: 14.8 -> 12.6 us; 1536 x 8960 / 2048 x 8192 M = 96 .. 128: 26 .. 28 -> 17.6 .. 18.1)
+    if (k8_auto && a.N % 64 == 0 && a.K % 256 == 0 && (a.N / 64) * ((a.M + 63) / 64) * 4 <= 256 && a.K / 256 >= 16) nauto = 4;
+    // ... and two slices of a very long K lose to seven of the 128 x 128 tiles (4096 x 11008 / x 14336 M = 96 .. 128: 33.8 .. 42.4 -> 30.0 .. 36.9)
+    if (k8_auto && nauto == 2 && a.K > 10240 && a.N % 128 == 0) nauto = 0;
     if (a.tuning[2] == 32 || nauto) {  // narrow tiles (64 x 64, 256-k steps, KH = 4; round 4, late): tuning[2] = 32 forces them, [1] = K slices
         if (a.N % 64 != 0 || a.K % 256 != 0) return false;
         const int units = (int)(a.K / 256), splitk = a.tuning[2] == 32 ? (a.tuning[1] > 0 ? a.tuning[1] : 1) : nauto;
@@ -114,6 +120,31 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
             if (a.K % kstep_of(c) == 0 && (a.N / mma::BN) * ((a.M + 32 * c - 1) / (32 * c)) >= want) found = c;
         if (found) { mi = found; break; }
     }
+    // Plain 8-bit weights above 64 rows (late round 6; 20 LLM layer shapes x M = 96 .. 512 against every forced form, profiles/r06/scan_a16w8_*.log):
+    // the weight conversion is per 128 columns whatever the tile's rows, so the 64-row tiles never pay (5120 x 13824 M = 256: 106.6 us vs 56.8 on 128 rows);
+    // these tiles hold one block per CU, so K slices never spill into a second round while half the chip stays busy (8960 x 1536 M = 256: 35.3 -> 19.3,
+    // 11008 x 4096 M = 128: 45.7 -> 30.5) and a slice keeps >= 1024 k; 256 rows where the model below says so — per block and 1024 k: 8.2 us on 128 rows,
+    // 17 on 256, 6 fixed, ~1 per slice — i.e. where the 128-row tiles leave the chip half idle or need two rounds (5120^2 M = 512: 62.7 -> 45.9).
+    const int64_t resident = resident_block_limit();
+    auto k8_slices = [&](int64_t tiles, int units) {
+        int sk = 1;
+        for (int s = 2; s <= units && s <= 32 && tiles * sk < 224; ++s) {
+            if (units / s < 8) break;
+            if (tiles * s > resident && tiles * sk >= 128) break;
+            sk = s;
+        }
+        return sk;
+    };
+    int k8_sk = 0;
+    if (k8_auto) {
+        double best = 0;
+        for (int c = 4; c <= cap; c <<= 1) {
+            const int64_t t = (int64_t)(a.N / mma::BN) * ((a.M + 32 * c - 1) / (32 * c));
+            const int sk = k8_slices(t, (int)(a.K / 128));
+            const double est = (double)((t * sk + resident - 1) / resident) * (6.0 + (c == 4 ? 8.2 : 17.0) * (double)a.K / sk / 1024.0) + (sk > 1 ? sk : 0);
+            if (k8_sk == 0 || est < best) { best = est; mi = c; k8_sk = sk; }
+        }
+    }
     if (a.tuning[2] == 1 || a.tuning[2] == 2 || a.tuning[2] == 4 || a.tuning[2] == 8) mi = a.tuning[2];
     else if (a.tuning[2] != 0) return false;
     if (a.K % kstep_of(mi) != 0) {
@@ -125,6 +156,7 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     const int64_t tiles = (int64_t)(a.N / mma::BN) * ((a.M + bm - 1) / bm);
     int splitk = 0;
     if (a.tuning[1] > 0) splitk = a.tuning[1];
+    else if (k8_sk) splitk = k8_sk;
     else {
         for (int sk = 1; sk <= units && sk <= 32; ++sk) {
             if (sk > 1 && units / sk < 4) continue;

@@ -254,7 +254,7 @@ def test_struct_abi_and_validation():
     (dict(M=64, N=4096, K=14336, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=14336), "gemm_a16w8_kernel<64x128>"),   # 470 MB: the tile kernel (29.6 vs 34.3 us)
     (dict(M=16, N=8192, K=8192, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=8192), "a16w8_rows_lds_kernel<16x16,2/cu>"),  # more blocks than CUs: up to 16 rows ahead of the tiles (24.4 -> 21.7 us)
     (dict(M=24, N=8192, K=8192, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=8192), "gemm_a16w8_kernel<32x128>"),
-    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "gemm_a16w8_kernel<64x128>"),  # above 64 rows: the MFMA tile kernel
+    (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096), "gemm_a16w8_kernel<128x128>"),  # above 64 rows: the MFMA tile kernel (late round 6: never the 64-row tiles there)
     (dict(M=65, nbits=8, e=1, in_dt=2, w_dtype=3, w_mode=0, c_mode=1, gs=4096), "gemm_a16w8_kernel<64x64>"),  # round 4, late: narrow 64 x 64 tiles where narrow_auto() fires
     (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(4, 0, 0, 0)), "a16w8_rows_lds_kernel<64x16>"),  # 64-row tiles along grid.y
     (dict(M=300, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=4096, tuning=(4, 0, 0, 524288)), "a16w8_rows_kernel<64x16>"),
