@@ -246,7 +246,22 @@ static void resolve_mx_plan(const gemlite_hip_forward_args& a, Resolved& r, cons
     // 8192^2 M = 1024 75.0 (256 x 256 tiles) vs 87.5.  2048 rows: the 256 x 256 tiles (59.3 vs 73.5, fp4 43.0 vs 46.3).
     // fp4 WEIGHTS (fp4 x fp4 and fp8 x fp4: 8192^2 M = 1024 111.9 (256 x 256) vs 119.7) above 512 rows only up to N K = 4096^2 (M = 1024: 38.9 -> 33.0).
     const bool mx_w4 = g.mx_w == MX_FP4;
-    const bool sq_auto = sq_few || (a.M > 64 && (a.M <= 512 || (a.M <= 1024 && (!mx_w4 || (int64_t)a.N * a.K <= (1ll << 24)))));
+    // ... and a long K (> 8192) under 320 .. 640 of these tiles goes back to the 128-row tiles, whose slice count now minimises rounds x slice length (plan_gemm_mx_mma;
+    // profiles/r06/scan_mx_*.log, 20 LLM layer shapes x M = 128 .. 512): MXFP8 5120 x 13824 M = 256 / 512 62.0 / 134.0 -> 55.9 / 104.4 us, 2560 x 9728 M = 448 / 512 48.5 / 47.7 -> 40.3 / 43.4
+    // (4096 x 11008 / x 14336 M = 448 / 512 stay although the slices are 7 - 14 % ahead there); fp4 weights only on the largest of them (fp8 x fp4 5120 x 13824: 49.1 / 86.8 -> 40.7 / 76.1; 2560 x 9728 M = 512 the other way, 29.8 vs 32.6)
+    const int64_t sq_tiles = (a.N / 64) * ((a.M + 63) / 64);
+    // Two of these tiles share a CU, so 257 .. 512 of them cost what 512 do: the hand-over only where they fill less than 0.7 of their last round (320 / 640 tiles: 0.625;
+    // at 384 / 480 they win by 1.3 - 1.5x — M = 384 on the same layers, scan_mx_a8w8_long_k_*.log)
+    const int64_t sq_slots = (sq_tiles + 511) / 512 * 512;
+    // ... and only where one to three slices of the 128-row tiles fill >= 0.9 of one or two rounds of CUs (4096 x 14336 M = 320: 96 tiles x 2 = 0.75 -> 76.8 us vs 55.8 here)
+    bool slices_fill = false;
+    for (int64_t sk = 1, t128 = (a.N / 128) * ((a.M + 127) / 128), cus = gl::resident_block_limit(); sk <= 3 && sk * 1024 <= a.K && !slices_fill; ++sk) {
+        const int64_t rounds = (t128 * sk + cus - 1) / cus;
+        slices_fill = rounds <= 2 && t128 * sk * 10 >= rounds * cus * 9;
+    }
+    const bool long_k_slices = a.M > 128 && a.K > 8192 && a.N % 128 == 0 && sq_tiles > 256 && sq_tiles <= 720 && sq_tiles * 10 < sq_slots * 7 && slices_fill &&
+                               (!mx_w4 || ((int64_t)a.N * a.K > (1ll << 26) && g.mx_x == MX_FP8));
+    const bool sq_auto = sq_few || (a.M > 64 && !long_k_slices && (a.M <= 512 || (a.M <= 1024 && (!mx_w4 || (int64_t)a.N * a.K <= (1ll << 24)))));
     if ((a.tuning[0] == 6 || (a.tuning[0] == 0 && a.tuning[1] == 0 && a.tuning[2] == 0 && sq_auto)) && plan_gemm_mx_sq(a, r.gp, r.lp)) { r.kind = K_A8_MMA; return; }
     // decode sizes of what is left (K % 64 != 0 ...): the streaming kernel
     if ((a.tuning[0] == 5 || (a.tuning[0] == 0 && !a16_over)) && a.tuning[1] == 0 && a.tuning[2] == 0 && plan_mx_gemv(a, r.gp, r.lp)) { r.kind = K_KMAJOR; return; }

@@ -1677,6 +1677,17 @@ bool plan_gemm_mx_mma(const gemlite_hip_forward_args& a, GenericParams& g, Launc
             if (tiles * sk >= 224) break;
         }
     }
+    // 128-row tiles, late round 6 (profiles/r06/scan_mx_*.log): two blocks share a CU, and blocks past one per CU cost a second round — 5120 x 13824 M = 512,
+    // 160 tiles: one slice 131 us, two (320 blocks) 142, three (480) 104.  The slice count that minimises rounds x slice length + 3.3 us per slice
+    // (slab traffic and the combine; 9.5 us per block and 1024 k) — equal to the rule above wherever that one stays within one round.
+    if (mi == 4 && a.tuning[1] == 0 && !(a.tuning[3] & 16384)) {
+        const int64_t cus = resident_block_limit();
+        double best = 0;
+        for (int sk = 1; sk <= sk_max && sk <= units; ++sk) {
+            const double est = (double)((tiles * sk + cus - 1) / cus) * 9.5 * (double)a.K / 1024.0 / sk + 3.3 * sk;
+            if (sk == 1 || est < best) { best = est; splitk = sk; }
+        }
+    }
     if (splitk > 1 && tiles > MAX_SPLITK_COUNTERS) return false;
     if ((uint64_t)splitk * bm * 128 * 4 >= (1ull << 31)) return false;
     const void* fn = g.mx_x == MX_FP8 ? (g.mx_w == MX_FP8 ? mx_pick<0, 0>(mi) : mx_pick<0, 4>(mi)) : mx_pick<4, 4>(mi);

@@ -207,6 +207,14 @@ def test_c_abi_routes_block_scaled_formats():
     assert name(a) == "gemm_mx_a8w8_sq_kernel<64x64>"
     assert name(args(16, 8, 2048, 4, N=8192, K=8192)) == "gemm_mx_a8w8_tile_kernel<256x256>"  # >= 96 tiles of 256 x 256
     assert name(args(16, 8, 512, 4, N=8192, K=8192)) == "gemm_mx_a8w8_sq_kernel<64x64>"       # (late round 6: 94.0 -> 82.7 us; rounds 4-5: the 128-row kernel)
+    # late round 6: a long K under 320 .. 640 of the 64 x 64 tiles goes back to the 128-row tiles with K slices (5120 x 13824 M = 512: 134.0 -> 104.4 us)
+    assert name(args(16, 8, 512, 4, N=5120, K=13824)) == "gemm_mx_a8w8_kernel<128x128>"
+    assert name(args(16, 8, 512, 4, N=2560, K=9728)) == "gemm_mx_a8w8_kernel<128x128>"      # 320 tiles: 0.625 of a round of 512
+    assert name(args(16, 8, 384, 4, N=5120, K=13824)) == "gemm_mx_a8w8_sq_kernel<64x64>"    # 480 tiles: 0.94 (59.8 vs 76.1 us)
+    assert name(args(16, 4, 256, 2, N=5120, K=13824)) == "gemm_mx_a8w4_kernel<128x128>"     # fp4 weights: only the largest layers
+    assert name(args(16, 4, 512, 2, N=2560, K=9728)) == "gemm_mx_a8w4_sq_kernel<64x64>"
+    assert name(args(17, 4, 512, 4, N=5120, K=13824)) == "gemm_mx_a4w4_sq_kernel<64x64>"    # fp4 x fp4 stays (65.1 vs 65.7)
+    assert name(args(16, 8, 256, 4, N=4096, K=14336)) == "gemm_mx_a8w8_sq_kernel<64x64>"    # 256 tiles stay (38.0 vs 53.0)
     assert name(args(16, 8, 1, 4)) == "mx_rows_a8w8_kernel<16x16>"    # round 4: fp8 / fp4 activations take the few-row MFMA kernel from 1 row
     assert name(args(17, 4, 4, 4)) == "mx_rows_a4w4_kernel<16x16>"
     a = args(16, 8, 1, 4)
