@@ -388,6 +388,30 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
             }
             if (!splitk) splitk = 1;
         }
+        // 2-bit words under 16-bit activations above 64 rows, late round 6 (20 LLM layer shapes x M = 128 .. 512 against every forced form,
+        // profiles/r06/scan_a16w2_*.log: the rule of thumb above within 3 % of the best form on 25 of 60 cells — its slice count spills into a second
+        // round of one-block-per-CU tiles (8960 x 1536 M = 256: two slices 30.8 us, one 16.0) and its 64-row tiles lose wherever 128 rows fill the
+        // chip (5120 x 13824 M = 256: 77.2 vs 50.4)).  A block-time model instead, rounds x (fixed + us per 1024 k) + 1 us per slice, per block:
+        // 64 rows 5 + 5.0, 128 rows 7 + 6.1, 256 rows 9 + 12; a slice keeps >= 1024 k.  60 cells after: 50 within 3 %, 58 within 10 %.
+        if (nbits == 2 && x16 && a.M > 64 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384)) {
+            static const double FIX[3] = {5.0, 7.0, 9.0}, PER_K[3] = {5.0, 6.1, 12.0};
+            const int64_t cus = resident_block_limit();
+            double best = 1e30;
+            for (int c = 2; c <= cap; c <<= 1) {
+                if (a.K % kstep_of(c) != 0) continue;
+                const int i = c == 2 ? 0 : (c == 4 ? 1 : 2);
+                const int64_t t = (int64_t)(a.N / mma::BN) * ((a.M + 32 * c - 1) / (32 * c));
+                for (int sk = 1; sk <= 16 && (sk == 1 || a.K / sk >= 1024); ++sk) {
+                    // (+ the weights once per row tile at ~4 TB/s: the row tiles of a column tile run at the same time and each pulls its own copy —
+                    //  BASELINE config 5, 16384^2 M = 256: 256 rows x 2 slices 140 us, 128 rows 151)
+                    //  — for weights past the 32 MB of the eight L2s; smaller ones are re-read from there: 14336 x 4096 M = 256: 128 rows 39.0 us, 256 rows 44.5)
+                    const double w_bytes = (double)a.N * a.K * nbits / 8.0;
+                    const double w_us = w_bytes > 32.0 * 1048576.0 ? w_bytes * (double)((a.M + 32 * c - 1) / (32 * c)) / 4e6 : 0.0;
+                    const double est = (double)((t * sk + cus - 1) / cus) * (FIX[i] + PER_K[i] * (double)a.K / sk / 1024.0) + (sk > 1 ? sk : 0) + w_us;
+                    if (est < best) { best = est; mi = c; splitk = sk; }
+                }
+            }
+        }
     } else {
         double best = 1e30;
         // second pass: K = 128 * odd (896, 640, ...) divides only the 128-k steps of the 128- / 256-row tiles — those then
