@@ -22,7 +22,7 @@ for M in MS:
     for (N, K) in SHAPES:
         name = f"a16w{BITS}_{N}x{K}_m{M}"
         nl = max(2, min(12, int(2.4e9 // (N * K * BITS))))
-        bench.WORKLOADS[name] = (N, K, BITS, 128, M, "fp16", nl, "mfma")
+        bench.WORKLOADS[name] = (N, K, BITS, 128, M, os.environ.get("GL_DT", "fp16"), nl, "mfma")
         rec = dict(M=M, N=N, K=K, us={}, kern={})
         for vn, t in VARIANTS:
             if vn in ("w256", "w256_sk1", "w256_sk2") and M <= 128:
