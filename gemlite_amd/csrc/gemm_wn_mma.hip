@@ -69,12 +69,13 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         if (k8 && p.epi.c_mode != 0 && p.epi.c_mode != 2 && ((uintptr_t)p.epi.scales_w % 16) != 0) return false;  // 4 channel scales per load
     }
     int nauto = (a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384)) ? narrow_auto(a.M, a.N, a.K, 2) : 0;
-    const bool k8_auto = k8 && a.M > 64 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384);
+    // (first fitted on the plain 8-bit weights, then found to hold for the block-scaled ones as well: scan_mxa16_w{4,8}_*.log — 22 / 16 of 60 cells within 3 % before)
+    const bool k8_auto = a.M > 64 && a.tuning[1] == 0 && a.tuning[2] == 0 && !(a.tuning[3] & 16384);
     // plain 8-bit weights (late round 6, profiles/r06/scan_a16w8_*.log): very few narrow tiles take FOUR K slices while those stay one round
     // (1024 x 4096 M = 128: 14.8 -> 12.6 us; 1536 x 8960 / 2048 x 8192 M = 96 .. 128: 26 .. 28 -> 17.6 .. 18.1)
     if (k8_auto && a.N % 64 == 0 && a.K % 256 == 0 && (a.N / 64) * ((a.M + 63) / 64) * 4 <= 256 && a.K / 256 >= 16) nauto = 4;
     // ... and two slices of a very long K lose to seven of the 128 x 128 tiles (4096 x 11008 / x 14336 M = 96 .. 128: 33.8 .. 42.4 -> 30.0 .. 36.9)
-    if (k8_auto && nauto == 2 && a.K > 10240 && a.N % 128 == 0) nauto = 0;
+    if (k8 && k8_auto && nauto == 2 && a.K > 10240 && a.N % 128 == 0) nauto = 0;
     if (a.tuning[2] == 32 || nauto) {  // narrow tiles (64 x 64, 256-k steps, KH = 4; round 4, late): tuning[2] = 32 forces them, [1] = K slices
         if (a.N % 64 != 0 || a.K % 256 != 0) return false;
         const int units = (int)(a.K / 256), splitk = a.tuning[2] == 32 ? (a.tuning[1] > 0 ? a.tuning[1] : 1) : nauto;
@@ -129,7 +130,7 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
     auto k8_slices = [&](int64_t tiles, int units) {
         int sk = 1;
         for (int s = 2; s <= units && s <= 32 && tiles * sk < 224; ++s) {
-            if (units / s < 8) break;
+            if (units / s < (k8 ? 8 : 12)) break;  // (block-scaled: >= 1536 k — 8192 x 2048 M = 256 A16W4_MXFP two slices 19.4 us, one 16.1)
             if (tiles * s > resident && tiles * sk >= 128) break;
             sk = s;
         }
@@ -141,7 +142,12 @@ bool plan_gemm_wn_mma_mx(const gemlite_hip_forward_args& a, WnParams& p, LaunchP
         for (int c = 4; c <= cap; c <<= 1) {
             const int64_t t = (int64_t)(a.N / mma::BN) * ((a.M + 32 * c - 1) / (32 * c));
             const int sk = k8_slices(t, (int)(a.K / 128));
-            const double est = (double)((t * sk + resident - 1) / resident) * (6.0 + (c == 4 ? 8.2 : 17.0) * (double)a.K / sk / 1024.0) + (sk > 1 ? sk : 0);
+            // per block: fixed us, us per 1024 k — plain 8-bit 6 + 8.2 / 17 (128 / 256 rows); block-scaled 8-bit 5 + 8.5 / 8.4 + 11.3; block-scaled 4-bit (MX, NVFP4) 4.2 + 6.4 / 7.4 + 10.2
+            const double fix = k8 ? 6.0 : (nb == mma::MXW8 ? (c == 4 ? 5.0 : 8.4) : (c == 4 ? 4.2 : 7.4));
+            const double per_k = k8 ? (c == 4 ? 8.2 : 17.0) : (nb == mma::MXW8 ? (c == 4 ? 8.5 : 11.3) : (c == 4 ? 6.4 : 10.2));
+            // (a slice of a 256-row block-scaled tile costs ~5 us, slab and combine: 11008 x 4096 M = 256 A16W4_MXFP, 86 tiles x 2 slices 38.9 us vs 172 tiles of 128 rows 31.3)
+            const double per_slice = (!k8 && c == 8) ? 5.0 : 1.0;
+            const double est = (double)((t * sk + resident - 1) / resident) * (fix + per_k * (double)a.K / sk / 1024.0) + (sk > 1 ? per_slice * sk : 0);
             if (k8_sk == 0 || est < best) { best = est; mi = c; k8_sk = sk; }
         }
     }

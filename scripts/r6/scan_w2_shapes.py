@@ -18,11 +18,13 @@ MS = [int(v) for v in sys.argv[1:]] or [128, 256]
 BITS = int(os.environ.get("GL_BITS", "2"))
 VARIANTS = (("auto", (0, 0, 0, 0)), ("n1", (0, 1, 32, 0)), ("n2", (0, 2, 32, 0)), ("w64", (0, 0, 2, 0)), ("w128", (0, 0, 4, 0)), ("w256", (0, 0, 8, 0)),
             ("w128_sk1", (0, 1, 4, 0)), ("w128_sk2", (0, 2, 4, 0)), ("w128_sk3", (0, 3, 4, 0)), ("w256_sk1", (0, 1, 8, 0)), ("w256_sk2", (0, 2, 8, 0)))
+if os.environ.get("GL_VARIANTS"):  # e.g. auto,n1,w64,w128,w128_sk1,w256_sk1,w256_sk2
+    VARIANTS = tuple(v for v in VARIANTS if v[0] in os.environ["GL_VARIANTS"].split(","))
 for M in MS:
     for (N, K) in SHAPES:
         name = f"a16w{BITS}_{N}x{K}_m{M}"
         nl = max(2, min(12, int(2.4e9 // (N * K * BITS))))
-        bench.WORKLOADS[name] = (N, K, BITS, 128, M, os.environ.get("GL_DT", "fp16"), nl, "mfma")
+        bench.WORKLOADS[name] = (N, K, BITS, int(os.environ.get("GL_GROUP", "128")), M, os.environ.get("GL_DT", "fp16"), nl, "mfma")
         rec = dict(M=M, N=N, K=K, us={}, kern={})
         for vn, t in VARIANTS:
             if vn in ("w256", "w256_sk1", "w256_sk2") and M <= 128:
