@@ -294,7 +294,10 @@ bool plan_gemm_wn_mma(const gemlite_hip_forward_args& a, WnParams& p, LaunchPlan
         const int64_t blocks = (a.N / mma::BN) * (mpad / (32 * c)) * sk;
         const double rounds = (double)((blocks + 255) / 256);
         const double slab_mb = sk > 1 ? (double)sk * mpad * a.N * 8e-6 : 0.0;
-        const double x_mb = (double)(a.N / mma::BN) * mpad * a.K * 2e-6;
+        // (x rows past M are never requested — late round 6: the padded rows of a 256-row tile at M = 384 were priced as traffic, and 336 tiles of 128 rows in two
+        //  rounds were chosen over 224 of 256 rows in one: 14336 x 4096 69.0 vs 60.5 us, profiles/r06/scan_a16w4_m384_m512.log)
+        const int64_t m_req = (a.M + 31) / 32 * 32 < mpad ? (a.M + 31) / 32 * 32 : mpad;
+        const double x_mb = (double)(a.N / mma::BN) * m_req * a.K * 2e-6;
         return rounds * (P[i] + steps * S[i] + (sk > 1 ? Q[i] + sk * R[i] : 0.0)) + 0.0955 * slab_mb + 0.0484 * x_mb;
     };
     int mi = 0, splitk = 0;
