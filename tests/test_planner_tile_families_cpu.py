@@ -1,5 +1,5 @@
 """End of round 6: the plans of the tile families that were re-fitted against every forced tile form (profiles/r06/scan_*.log) are frozen in
-tests/golden/planner_tile_families.json — kernel name AND launch grid (tiles x K slices) per (family, M, N, K) over the 20 LLM layer shapes x M in {128, 256, 512} —
+tests/golden/planner_tile_families.json — kernel name AND launch grid (tiles x K slices) per (family, M, N, K) over the 20 LLM layer shapes x M in {128, 256, 384, 512} —
 so that a rule edited for one shape does not silently move the others, and the two properties those scans were about hold by construction:
 the LDS-fed 128- / 256-row tiles never take more blocks than the next whole round of CUs needs while half the chip is already busy.
 Regenerate after an intended change: `python tests/test_planner_tile_families_cpu.py --write`."""
@@ -17,7 +17,7 @@ from tests.test_host_cpu import _args  # noqa: E402
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "planner_tile_families.json")
 SHAPES = [(1024, 4096), (1536, 8960), (2048, 8192), (2560, 9728), (3072, 8192), (4096, 1024), (4096, 4096), (4096, 11008), (4096, 14336), (5120, 5120), (5120, 13824), (6144, 4096),
           (8192, 2048), (8192, 3072), (8192, 8192), (8960, 1536), (11008, 4096), (12288, 4096), (13824, 5120), (14336, 4096)]
-MS = (128, 256, 512)
+MS = (128, 256, 384, 512)
 
 
 def _mx(in_dt, nbits, M, c_mode, N, K, group=32):
@@ -52,6 +52,7 @@ FAMILIES = {
     "a8w8_fp8": lambda M, N, K: _a8(3, M, N, K),
     "a16w8_int8": lambda M, N, K: _args(M=M, N=N, K=K, nbits=8, e=1, in_dt=1, w_dtype=4, w_mode=2, gs=K),
     "a16w2": lambda M, N, K: _args(M=M, N=N, K=K, nbits=2, gs=128, in_dt=1),
+    "a16w4": lambda M, N, K: _args(M=M, N=N, K=K, nbits=4, gs=128, in_dt=2),
     "mx_a8w8": lambda M, N, K: _mx(16, 8, M, 4, N, K),
     "mx_a8w4": lambda M, N, K: _mx(16, 4, M, 2, N, K),
     "mx_a4w4": lambda M, N, K: _mx(17, 4, M, 4, N, K),
@@ -82,7 +83,7 @@ def _rows():
 
 def test_tile_family_plans_are_frozen():
     fx = json.load(open(GOLDEN))["rows"]
-    assert len(fx) >= 9 * 3 * 20 - 30
+    assert len(fx) >= 10 * 4 * 20 - 40
     got = {tuple(r[:4]): (r[4], r[5]) for r in _rows()}
     moved = [(tuple(r[:4]), (r[4], r[5]), got.get(tuple(r[:4]))) for r in fx if got.get(tuple(r[:4])) != (r[4], r[5])]
     assert not moved, moved[:8]
@@ -115,7 +116,7 @@ def test_lds_fed_tiles_do_not_spill_their_k_slices_into_a_second_round():
 if __name__ == "__main__" and "--write" in sys.argv:
     rows = _rows()
     with open(GOLDEN, "w") as f:
-        f.write('{"_note": "kernel name and workspace bytes (= counter page + tiles x K slices x tile bytes) the C ABI plans for the re-fitted tile families over 20 LLM layer shapes x M = 128 / 256 / 512 '
+        f.write('{"_note": "kernel name and workspace bytes (= counter page + tiles x K slices x tile bytes) the C ABI plans for the re-fitted tile families over 20 LLM layer shapes x M = 128 / 256 / 384 / 512 '
                 '(end of round 6, profiles/r06/scan_*.log); regenerate with python tests/test_planner_tile_families_cpu.py --write", "rows": [\n')
         f.write(",\n".join(" " + json.dumps(r) for r in rows))
         f.write("\n]}\n")
