@@ -29,6 +29,10 @@ static int narrow_auto(int64_t M, int64_t N, int64_t K, int es) {
     if (M <= 32 || N % 64 != 0 || K % 256 != 0) return 0;
     const int64_t t64 = (N / 64) * ((M + 63) / 64);
     const int64_t x_bytes = (N / 64) * ((M + 63) / 64 * 64) * K * es;
+    // (end of round 6: very few tiles take FOUR slices while those stay one round of CUs — 16-bit activations, 4- and 2-bit words alike:
+    //  1536 x 8960 M = 96 / 128 16.4 / 16.5 -> 13.6 / 13.8 us, 2048 x 8192 16.4 / 16.9 -> 13.9 / 14.3, 1024 x 4096 M = 128 / 256 11.9 / 12.2 -> 10.7 / 11.4; with 80 or more
+    //  tiles four slices lose (2560 x 9728 M = 128: 19.0 vs 24.2) — profiles/r06/probe_narrow_four_slices_w{4,2}.log)
+    if (M > 64 && es == 2 && t64 * 4 <= 256 && K / 256 >= 16) return 4;
     if (t64 >= (M <= 64 ? 140 : 192) && t64 <= 256 && x_bytes <= (160ll << 20)) return 1;
     if (t64 >= (M <= 64 ? 64 : 96) && t64 <= 128 && K / 256 >= 8 && (M > 64 || K <= 8192)) return 2;
     // (late round 6, planner re-validation: a short K has nothing to slice — 4096 x 1024 M = 128, 128 tiles: 9.27 (32 x 128 tiles) -> 6.92 us unsplit)

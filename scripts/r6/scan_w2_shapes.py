@@ -16,7 +16,7 @@ if os.environ.get("GL_SHAPE"):  # e.g. 16384x16384
     SHAPES = [tuple(int(v) for v in sh.split("x")) for sh in os.environ["GL_SHAPE"].split(",")]
 MS = [int(v) for v in sys.argv[1:]] or [128, 256]
 BITS = int(os.environ.get("GL_BITS", "2"))
-VARIANTS = (("auto", (0, 0, 0, 0)), ("n1", (0, 1, 32, 0)), ("n2", (0, 2, 32, 0)), ("w64", (0, 0, 2, 0)), ("w128", (0, 0, 4, 0)), ("w256", (0, 0, 8, 0)),
+VARIANTS = (("auto", (0, 0, 0, 0)), ("n1", (0, 1, 32, 0)), ("n2", (0, 2, 32, 0)), ("n4", (0, 4, 32, 0)), ("w64", (0, 0, 2, 0)), ("w128", (0, 0, 4, 0)), ("w256", (0, 0, 8, 0)),
             ("w128_sk1", (0, 1, 4, 0)), ("w128_sk2", (0, 2, 4, 0)), ("w128_sk3", (0, 3, 4, 0)), ("w256_sk1", (0, 1, 8, 0)), ("w256_sk2", (0, 2, 8, 0)))
 if os.environ.get("GL_VARIANTS"):  # e.g. auto,n1,w64,w128,w128_sk1,w256_sk1,w256_sk2
     VARIANTS = tuple(v for v in VARIANTS if v[0] in os.environ["GL_VARIANTS"].split(","))

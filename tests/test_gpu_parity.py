@@ -859,6 +859,20 @@ def test_mma_kernel_narrow_tiles_all_modes_and_headline_choice():
     assert _kernel_name(lin, x) == "gemm_w4_mma_kernel<64x64>", _kernel_name(lin, x)
 
 
+@pytest.mark.parametrize("bits", [4, 2])
+def test_narrow_tiles_with_four_k_slices_where_the_tiles_are_few(bits):
+    """End of round 6: at most 64 narrow 64 x 64 tiles over K >= 4096 take four K slices by default (1024 x 4096: 16 column tiles x 2 row tiles x 4 = 128 blocks,
+    combined by ticket through the slabs)."""
+    lin = _make_layer(1024, 4096, bits, 128, torch.float16, seed=97 + bits)
+    for M in (96, 128, 250):
+        x = torch.from_numpy(O.gen_x(M, 4096, seed=M)).to(DEV)
+        name = _kernel_name(lin, x)
+        assert name == f"gemm_w{bits}_mma_kernel<64x64>", name
+        y = lin(x)
+        torch.cuda.synchronize()
+        _compare(f"mma_narrow/four_slices/w{bits}/M{M}", y, _oracle_from_layer(lin, x), lin.output_dtype.value, abs_gate=1e-3)
+
+
 @pytest.mark.parametrize("K", [64, 128, 256, 384])
 def test_mma_kernel_fewer_k_steps_than_stages(K):
     """One to six K steps: fewer than the LDS stages / the register ring of every tile variant (the run-ahead requests repeat the
